@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- log-likelihood evaluations per second at N=1024 nodes, M=1e6 events on MI355X.
+
+One "step" = one complete loglikelihood(process, data) -> scalar (reference:
+src/continuous.jl:210-276) with the event data AND the parameters already resident in HBM
+(PCIe-inclusive rate: DESIGN.md).  Workloads follow SURVEY.md 8d "S-metric": continuous
+exponential standard Hawkes, N=1024, M=1e6, Δtmax=1, mean look-back window K̄ events.
+
+    python bench.py --gpus N --steps K --warmup W [--workload windowed_k8|windowed_k64|
+                                                   windowed_k512|recursive|logitnormal_k8]
+
+N>1: launched by torch.distributed.run, one rank per GPU; every rank evaluates its own
+independent stream (chains / restarts shard embarrassingly), weak scaling, and the
+per-rank results are gathered over RCCL.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    "windowed_k8": dict(kind="exponential", kbar=8.0, recursive=False),
+    "windowed_k64": dict(kind="exponential", kbar=64.0, recursive=False),
+    "windowed_k512": dict(kind="exponential", kbar=512.0, recursive=False),
+    "recursive": dict(kind="exponential", kbar=8.0, recursive=True),
+    "logitnormal_k8": dict(kind="logitnormal", kbar=8.0, recursive=False),
+}
+
+
+def algorithmic_bytes(N, M, kind):
+    """B_alg = 16·M + 8·P + 8: times f64 + nodes at the reference's Int64 width,
+    every parameter once (P = N + 2N² exponential, N + 3N² logit-normal), one scalar out."""
+    P = N + (2 if kind == "exponential" else 3) * N * N
+    return 16 * M + 8 * P + 8
+
+
+def run_workload(nhp, ctx, name, N, M, steps, warmup, sync):
+    import ctypes as C
+    from nhp_amd import _lib
+    w = WORKLOADS[name]
+    times, nodes, T = nhp.synthetic.s_metric_data(N, M, kbar=w["kbar"])
+    proc = nhp.synthetic.s_metric_process(N, M, T, w["kind"], 1.0)
+    ds = nhp.device_dataset(proc, (times, nodes, T), ctx)
+    model = proc.device_model(ctx)
+    flags = _lib.LL_RECURSIVE if w["recursive"] else 0
+    lib = _lib.lib()
+
+    def enqueue(k):
+        _lib.check(lib.nhp_cont_loglik_enqueue(ctx.h, ds.h, model.h, flags, k % _lib.MAX_SLOTS), ctx.h)
+
+    for k in range(warmup):
+        enqueue(k)
+    ctx.synchronize()
+    sync()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for k in range(steps):
+        enqueue(k)
+    dev_ms = ctx.timer_stop()           # hipEvents on the stream the kernels run on; also drains it
+    sync()
+    wall = time.perf_counter() - t0
+    ll = ctx.fetch(0, 1)[0]
+    return dict(name=name, wall=wall, dev_ms=dev_ms, ll=float(ll), pairs=int(ds.pairs), M=M, N=N,
+                kind=w["kind"], data=(times, nodes, T), proc=proc, recursive=w["recursive"])
+
+
+def cpu_baseline(r, budget_s=12.0):
+    """The oracle (a C restatement of the reference's loops, 1 thread) on a bounded prefix of the
+    same workload; evals/s extrapolated linearly in M (both formulations are linear in M)."""
+    from oracle import oracle as orc
+    times, nodes, T = r["data"]
+    proc = r["proc"]
+    kw = dict(theta=proc.impulses.θ) if r["kind"] == "exponential" else dict(mu=proc.impulses.μ, tau=proc.impulses.τ)
+    om = orc.ContModel(proc.baseline.λ, proc.weights.W, dt_max=1.0, **kw)
+    M = len(times)
+
+    def run(m):
+        t0 = time.perf_counter()
+        orc.loglik(om, times[:m], nodes[:m], T * m / M, recursive=r["recursive"], flags=orc.FAST_INTEGRAL)
+        return time.perf_counter() - t0
+
+    probe = min(M, 2000 if r["recursive"] else 50_000)
+    tp = run(probe)
+    m = int(min(M, max(probe, probe * budget_s / max(tp, 1e-6))))
+    ts = run(m) if m > probe else tp
+    return dict(value=1.0 / (ts * M / m), unit="log-likelihood evals/sec", cores=1, kind="port",
+                sample=f"oracle C restatement, 1 thread, first {m} of {M} events "
+                       f"({ts:.2f} s), scaled linearly to M; row sums of W hoisted (stronger baseline)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=os.environ.get("NHP_BENCH_WORKLOAD", "windowed_k8"), choices=sorted(WORKLOADS))
+    ap.add_argument("--nodes", type=int, default=1024)
+    ap.add_argument("--events", type=int, default=1_000_000)
+    ap.add_argument("--extra", default=os.environ.get("NHP_BENCH_EXTRA", "windowed_k64,windowed_k512,recursive"),
+                    help="comma list of secondary workloads reported under 'other_workloads' (N=1 only)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch                       # first: libnhp.so must bind to torch's HIP runtime copy
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import __graft_entry__ as entry
+    nhp = entry.load_package()
+    ctx = nhp.Context(local)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    r = run_workload(nhp, ctx, args.workload, args.nodes, args.events, args.steps, args.warmup, sync)
+    wall = torch.tensor([r["wall"]], dtype=torch.float64, device="cuda")
+    lls = torch.tensor([r["ll"]], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+        gathered = [torch.zeros_like(lls) for _ in range(world)] if rank == 0 else None
+        dist.gather(lls, gathered, dst=0)                  # the per-chain results, over RCCL/xGMI
+        if rank == 0:
+            lls = torch.cat(gathered)
+    wall_s = float(wall.item())
+
+    if rank == 0:
+        B = algorithmic_bytes(r["N"], r["M"], r["kind"])
+        ms_kernel = r["dev_ms"] / args.steps
+        out = {
+            "metric": "log-likelihood evals/sec (N=1024, M=1e6)",
+            "value": world * args.steps / wall_s,
+            "unit": "log-likelihood evals/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * wall_s / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"continuous exponential standard Hawkes, N={r['N']}, M={r['M']}, "
+                                   f"dt_max=1, {args.workload} (S-metric, SURVEY 8d)",
+                       "pairs_per_eval": r["pairs"], "independent_streams": world},
+            "roofline": {"bound": "hbm", "achieved": B / (ms_kernel * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": B / (ms_kernel * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes": B, "kernel_ms": ms_kernel,
+                         "pair_rate_per_s": r["pairs"] / (ms_kernel * 1e-3)},
+            "loglik": [float(v) for v in lls.cpu()],
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(r)
+            out["speedup_vs_cpu_core"] = out["value"] / out["cpu_baseline"]["value"]
+        if world == 1 and args.extra:
+            others = []
+            for name in [s for s in args.extra.split(",") if s and s != args.workload]:
+                steps = max(3, args.steps // (10 if name in ("recursive", "windowed_k512") else 2))
+                o = run_workload(nhp, ctx, name, args.nodes, args.events, steps, 2, sync)
+                Bo = algorithmic_bytes(o["N"], o["M"], o["kind"])
+                mk = o["dev_ms"] / steps
+                others.append({"workload": name, "value": steps / o["wall"], "kernel_ms": mk, "steps": steps,
+                               "pairs_per_eval": o["pairs"], "hbm_frac": Bo / (mk * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "loglik": o["ll"]})
+            out["other_workloads"] = others
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,188 @@
+/*
+ * include/nhp.h -- C ABI of libnhp.so, the MI355X (gfx950) hot path for network Hawkes
+ * processes.
+ *
+ * The reference (cswaney/NetworkHawkesProcesses.jl v0.1.0) is pure Julia and has no FFI:
+ * its "plug-in API" is multiple dispatch on Baseline / ImpulseResponse / Weights / Network
+ * components composed into process structs (src/continuous.jl:108-112,315-321;
+ * src/discrete.jl:161-170,395-402).  This header is the boundary a Julia shim binds with
+ * `ccall`: each component lowers to plain arrays + a kind enum in
+ * nhp_cont_model_desc, and each entry point below replaces the Julia method cited next to
+ * it.  Citations are file:line in the reference checkout.
+ *
+ * Conventions
+ *  - Julia layout is kept so the shim passes its arrays untouched: matrices are
+ *    column-major, X[p,c] at p + c*N (p = parent node, c = child node,
+ *    src/continuous.jl:303); theta[p,c,b] at p + c*N + b*N*N; data[n,t] at n + t*N;
+ *    convolved[t,n,b] at t + n*T + b*T*N.
+ *  - `nodes` are the reference's 1-based Int64 (src/continuous.jl:14).  Parent indices
+ *    returned are 1-based event indices, 0 = baseline (src/parents.jl:41-45).
+ *  - Host pointers are borrowed for the duration of the call only.  Device memory belongs
+ *    to the ctx / dataset / model handles and is released by the *_destroy functions.
+ *  - No exception crosses the boundary: every function returns an nhp_status; the message
+ *    is available from nhp_last_error().  The shim maps NHP_EDOMAIN -> DomainError
+ *    (src/baselines.jl:100,106,111,116), NHP_ESHAPE/NHP_EINVAL -> ErrorException
+ *    (src/impulses.jl:44-45, src/weights.jl:10-11).
+ *  - A ctx owns one HIP device and one stream and is not thread-safe; distinct ctx are
+ *    independent (one host thread or process per GPU).
+ */
+#ifndef NHP_H
+#define NHP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    NHP_OK = 0,
+    NHP_EINVAL = 1,   /* bad argument / unsorted events */
+    NHP_EDOMAIN = 2,  /* negative time or duration, node id out of 1..N, non-positive intensity */
+    NHP_ESHAPE = 3,   /* array length does not match the model */
+    NHP_ENOMEM = 4,
+    NHP_EHIP = 5,     /* HIP runtime error (no device, launch failure, ...) */
+    NHP_ENOTIMPL = 6
+} nhp_status;
+
+enum { NHP_BASELINE_HOMOGENEOUS = 0, NHP_BASELINE_LGCP = 1 };
+enum { NHP_IMPULSE_EXPONENTIAL = 0, NHP_IMPULSE_LOGITNORMAL = 1 };
+
+/* flags for nhp_cont_loglik* */
+enum {
+    NHP_LL_RECURSIVE = 1,        /* loglikelihood(...; recursive=true) for exponential impulses
+                                    (src/continuous.jl:212-214,361-363): O(M*N) recursion that
+                                    ignores dt_max; for other impulses the flag is ignored, as
+                                    in the reference */
+};
+
+typedef struct nhp_ctx nhp_ctx;
+typedef struct nhp_cont_dataset nhp_cont_dataset;
+typedef struct nhp_cont_model nhp_cont_model;
+typedef struct nhp_disc_dataset nhp_disc_dataset;
+
+/* The lowered form of (Baseline, ImpulseResponse, Weights, adjacency_matrix):
+ *   HomogeneousProcess.λ                      src/baselines.jl:27-39
+ *   LogGaussianCoxProcess.x / .λ              src/baselines.jl:148-173 (evaluator only)
+ *   ExponentialImpulseResponse.θ / .Δtmax     src/impulses.jl:30-37
+ *   LogitNormalImpulseResponse.μ / .τ / .Δtmax src/impulses.jl:138-148
+ *   DenseWeightModel.W                        src/weights.jl:47-55
+ *   ContinuousNetworkHawkesProcess.adjacency_matrix  src/continuous.jl:315-321 */
+typedef struct {
+    int32_t n_nodes;
+    int32_t baseline_kind;
+    const double *lambda0;   /* homogeneous: [N]; LGCP: [N*grid_n], node c at c*grid_n */
+    const double *grid_x;    /* LGCP grid points [grid_n], strictly increasing, x[0] = 0 */
+    int32_t grid_n;          /* 0 for the homogeneous baseline */
+    int32_t impulse_kind;
+    const double *theta;     /* exponential: [N*N] */
+    const double *mu;        /* logit-normal: [N*N] */
+    const double *tau;       /* logit-normal: [N*N] */
+    double dt_max;           /* must equal the dataset's dt_max */
+    const double *W;         /* [N*N] */
+    const double *A;         /* [N*N] of 0.0/1.0, or NULL for the standard (dense) process */
+} nhp_cont_model_desc;
+
+/* Gibbs sufficient statistics emitted by the parent sampler in the same pass
+ * (src/baselines.jl:87-96; src/parents.jl:61-79; src/impulses.jl:84-96,216-252).
+ * Any pointer may be NULL.  All are [N] or [N*N] column-major doubles, as the reference
+ * stores counts in Float64 `zeros`. */
+typedef struct {
+    double *cnt0;   /* [N]   baseline-attributed events per node */
+    double *Mn;     /* [N]   events per node */
+    double *Mnm;    /* [N*N] events on c attributed to a parent on p */
+    double *Xnm;    /* [N*N] exponential: mean Δt (NaN -> 0); logit-normal: mean log(Δt/(Δtmax-Δt)) (NaN kept) */
+    double *Vnm;    /* [N*N] logit-normal: Σ (log-duration - Xnm)^2; untouched for exponential */
+} nhp_cont_stats;
+
+/* ---- context ------------------------------------------------------------------------- */
+nhp_status nhp_ctx_create(int32_t device, nhp_ctx **out);
+void nhp_ctx_destroy(nhp_ctx *ctx);
+const char *nhp_last_error(const nhp_ctx *ctx);      /* ctx may be NULL: last global error */
+nhp_status nhp_ctx_synchronize(nhp_ctx *ctx);
+/* hipEvent pair on the ctx stream, for measuring kernel time without host overhead */
+nhp_status nhp_ctx_timer_start(nhp_ctx *ctx);
+nhp_status nhp_ctx_timer_stop(nhp_ctx *ctx, double *elapsed_ms);
+int32_t nhp_abi_version(void);
+
+/* ---- continuous data: (events, nodes, duration)  src/continuous.jl:14,29-36 ----------- */
+/* Validates (sorted, >= 0, nodes in 1..N, duration >= 0), runs the look-back pre-pass for
+ * dt_max (window starts, node buckets, work partition) and uploads once. */
+nhp_status nhp_cont_dataset_create(nhp_ctx *ctx, const double *events, const int64_t *nodes,
+                                   int64_t n_events, int32_t n_nodes, double duration,
+                                   double dt_max, nhp_cont_dataset **out);
+void nhp_cont_dataset_destroy(nhp_cont_dataset *ds);
+/* Σ_i K_i: parent-child pairs inside the look-back window (SURVEY 8d F_alg) */
+int64_t nhp_cont_dataset_pairs(const nhp_cont_dataset *ds);
+
+/* ---- continuous model: device-resident parameter blob --------------------------------- */
+nhp_status nhp_cont_model_create(nhp_ctx *ctx, const nhp_cont_model_desc *desc, nhp_cont_model **out);
+/* re-upload all parameters (same kinds / shapes as at creation) */
+nhp_status nhp_cont_model_update(nhp_ctx *ctx, nhp_cont_model *model, const nhp_cont_model_desc *desc);
+/* params!(process, x) for the standard process: x = [λ0; θ | μ; τ; W]  src/continuous.jl:121-129 */
+nhp_status nhp_cont_model_set_params(nhp_ctx *ctx, nhp_cont_model *model, const double *x, int64_t len);
+void nhp_cont_model_destroy(nhp_cont_model *model);
+
+/* ---- loglikelihood(process, data; recursive)  src/continuous.jl:210-276,360-442 -------- */
+nhp_status nhp_cont_loglik(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *model,
+                           int32_t flags, double *ll);
+/* Asynchronous form for batches (finite-difference sweeps, chains): enqueue evaluations
+ * into result slots [0, NHP_MAX_SLOTS), then fetch them with one synchronisation. */
+#define NHP_MAX_SLOTS 4096
+nhp_status nhp_cont_loglik_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds,
+                                   const nhp_cont_model *model, int32_t flags, int32_t slot);
+nhp_status nhp_ctx_fetch(nhp_ctx *ctx, int32_t first_slot, int32_t n, double *out);
+
+/* log-likelihood and its analytic gradient in params! order [λ0; θ | μ; τ; W] (homogeneous
+ * baseline).  Replaces the 2P finite-difference objective calls Optim makes inside mle!
+ * (src/continuous.jl:144-198). */
+nhp_status nhp_cont_loglik_grad(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *model,
+                                int32_t flags, double *ll, double *grad, int64_t grad_len);
+
+/* total_intensity at every event, λ_{c_i}(t_i)  src/continuous.jl:286-300,391-405 */
+nhp_status nhp_cont_event_intensity(nhp_ctx *ctx, const nhp_cont_dataset *ds,
+                                    const nhp_cont_model *model, double *lambda /* [M] */);
+
+/* intensity(process, data, times) -> Q x N column-major  src/continuous.jl:76-96 */
+nhp_status nhp_cont_intensity(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *model,
+                              const double *times, int64_t n_times, double *out);
+
+/* resample_parents(process, data)  src/parents.jl:1-46.  One categorical draw per event from
+ * an explicit uniform stream: `u` (host, [M]) if non-NULL, else Philox4x32-10 keyed by
+ * (seed, step, event index).  parents / parentnodes may be NULL (statistics only). */
+nhp_status nhp_cont_resample_parents(nhp_ctx *ctx, const nhp_cont_dataset *ds,
+                                     const nhp_cont_model *model, const double *u,
+                                     uint64_t seed, uint64_t step,
+                                     int64_t *parents, int64_t *parentnodes, nhp_cont_stats *stats);
+/* the uniform stream itself (host side, same bits as the kernel draws) */
+void nhp_uniform_stream(uint64_t seed, uint64_t step, int64_t n, double *u);
+
+/* ---- discrete data: N x T counts  src/discrete.jl:18,80 -------------------------------- */
+nhp_status nhp_disc_dataset_create(nhp_ctx *ctx, const int64_t *data, int32_t n_nodes, int64_t n_bins,
+                                   nhp_disc_dataset **out);
+void nhp_disc_dataset_destroy(nhp_disc_dataset *ds);
+/* basis(impulse)  src/impulses.jl:321-335 -> phi [L*B], lag fastest (host) */
+nhp_status nhp_disc_basis(int32_t n_lags, int32_t n_basis, double dt, double *phi);
+/* convolve(process, data)  src/discrete.jl:146-151; keeps the T x N x B result on the device
+ * and copies it to `out` if non-NULL */
+nhp_status nhp_disc_convolve(nhp_ctx *ctx, nhp_disc_dataset *ds, const double *phi, int32_t n_lags,
+                             int32_t n_basis, double *out);
+/* intensity(process, convolved)  src/discrete.jl:115-129 -> T x N; A may be NULL */
+nhp_status nhp_disc_intensity(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
+                              const double *W, const double *theta, const double *A, double dt,
+                              double *lam);
+/* loglikelihood(process, data, convolved)  src/discrete.jl:91-102 */
+nhp_status nhp_disc_loglik(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
+                           const double *W, const double *theta, const double *A, double dt,
+                           double *ll);
+/* one update!(process, data, convolved) mean-field step  src/discrete.jl:369-375;
+ * variational parameters are read and overwritten in place (host arrays) */
+nhp_status nhp_disc_vb_step(nhp_ctx *ctx, const nhp_disc_dataset *ds, double dt,
+                            double alpha0, double beta0, double kappa, double nu, double gamma,
+                            double *alpha_v, double *beta_v, double *kappa_v, double *nu_v,
+                            double *gamma_v);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

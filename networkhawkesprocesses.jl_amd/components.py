@@ -1,0 +1,255 @@
+"""Plug-in components: the reference's Baseline / ImpulseResponse / Weights / Network types
+with the same names, fields and constructor defaults, as plain parameter holders.
+
+The reference dispatches a scalar method per (parent, child) pair on these types inside its
+innermost loops; here they only carry arrays, which `lower()` in
+continuous.py turns into the nhp_cont_model_desc blob the HIP kernels read.  Field names
+keep the reference's Unicode spelling (θ, λ, Δtmax ...) so code written against the Julia
+package reads the same.  Matrices are indexed [parent, child] (src/continuous.jl:303).
+
+Host-side random draws (Gibbs conjugate updates, src/baselines.jl:72-77,
+src/weights.jl:59-64, src/impulses.jl:68-73,204-214, src/networks.jl:65-78) use numpy's
+Generator: statistically, not bitwise, the same as Julia's samplers.
+"""
+import numpy as np
+
+from ._lib import DomainError
+
+
+def _fillna(x, value):
+    """fillna!(X, value): src/utils/helpers.jl:18-25"""
+    x = np.array(x, dtype=np.float64)
+    x[np.isnan(x)] = value
+    return x
+
+
+# ------------------------------------------------------------------------------ baselines
+class Baseline:
+    pass
+
+
+class HomogeneousProcess(Baseline):
+    """HomogeneousProcess(λ[, α0, β0]) -- src/baselines.jl:27-39."""
+
+    def __init__(self, λ, α0=1.0, β0=1.0):
+        λ = np.array(λ, dtype=np.float64)
+        if np.any(λ < 0):
+            raise DomainError("HomogeneousProcess: intensity parameter λ must be non-negative")
+        if not α0 > 0:
+            raise DomainError("HomogeneousProcess: shape parameter α0 must be positive")
+        if not β0 > 0:
+            raise DomainError("HomogeneousProcess: rate parameter β0 must be positive")
+        self.λ, self.α0, self.β0 = λ, float(α0), float(β0)
+
+    def ndims(self):
+        return len(self.λ)
+
+    def params(self):
+        return self.λ.copy()
+
+    def params_(self, x):
+        """params!: src/baselines.jl:44-50"""
+        if len(x) != len(self.λ):
+            raise ValueError("Parameter vector length does not match model parameter length.")
+        self.λ[:] = x
+
+    def intensity(self, node=None, time=0.0):
+        """src/baselines.jl:110-118"""
+        if time < 0:
+            raise DomainError("time must be non-negative")
+        return self.λ.copy() if node is None else self.λ[node - 1]
+
+    def integrated_intensity(self, duration, node=None):
+        """src/baselines.jl:98-108"""
+        if duration < 0:
+            raise DomainError("duration must be non-negative")
+        return self.λ * duration if node is None else self.λ[node - 1] * duration
+
+    def resample_(self, cnt0, duration, rng):
+        """resample!: λ ~ Gamma(α0 + counts, 1/(β0 + T)) -- src/baselines.jl:72-77"""
+        self.λ = rng.gamma(self.α0 + cnt0, 1.0 / (self.β0 + duration))
+        return self.λ
+
+
+class LogGaussianCoxProcess(Baseline):
+    """Evaluator part of LogGaussianCoxProcess(x, λ, Σ, m) -- src/baselines.jl:148-173:
+    piecewise-linear intensity through (x, λ[k]) per node (src/utils/interpolation.jl)."""
+
+    def __init__(self, x, λ, Σ=None, m=0.0):
+        x = np.asarray(x, dtype=np.float64)
+        if x[0] != 0.0:
+            raise DomainError("Grid points x must start at 0.")
+        self.x = x
+        self.λ = [np.asarray(v, dtype=np.float64) for v in λ]
+        for v in self.λ:
+            if len(v) != len(x):
+                raise ValueError("intensity vectors must match the grid")
+        self.Σ, self.m = Σ, float(m)
+
+    def ndims(self):
+        return len(self.λ)
+
+    def __len__(self):
+        return self.x[-1]
+
+    def params(self):
+        return np.concatenate(self.λ)
+
+    def integrated_intensity(self, duration=None):
+        """integrate.(LinearInterpolator) -- src/baselines.jl:336; ignores duration"""
+        dx = np.diff(self.x)
+        return np.array([np.sum(0.5 * (y[:-1] + y[1:]) * dx) for y in self.λ])
+
+
+# ------------------------------------------------------------------------------ impulses
+class ImpulseResponse:
+    pass
+
+
+class ExponentialImpulseResponse(ImpulseResponse):
+    """ExponentialImpulseResponse(θ[, α, β, Δtmax]); 1-arg default Δtmax = Inf -- src/impulses.jl:30-37."""
+
+    def __init__(self, θ, α=1.0, β=1.0, Δtmax=np.inf):
+        self.θ = np.array(θ, dtype=np.float64)
+        self.α, self.β, self.Δtmax = float(α), float(β), float(Δtmax)
+
+    def size(self):
+        return self.θ.shape[0]
+
+    def params(self):
+        return self.θ.ravel(order="F").copy()
+
+    def params_(self, x):
+        """params!: src/impulses.jl:43-51"""
+        if len(x) != self.θ.size:
+            raise ValueError("Parameter vector length does not match model parameter length.")
+        n = self.size()
+        self.θ = np.asarray(x, dtype=np.float64).reshape((n, n), order="F").copy()
+
+    def resample_(self, Mnm, Xnm, rng):
+        """resample!: θ ~ Gamma(α + Mnm, 1/(β + Mnm·Xnm)) -- src/impulses.jl:68-73"""
+        self.θ = rng.gamma(self.α + Mnm, 1.0 / (self.β + Mnm * Xnm))
+        return self.θ
+
+
+class LogitNormalImpulseResponse(ImpulseResponse):
+    """LogitNormalImpulseResponse(μ, τ, [μμ, κμ, α0, β0,] Δtmax) -- src/impulses.jl:138-148."""
+
+    def __init__(self, μ, τ, *args):
+        if len(args) == 1:
+            μμ, κμ, α0, β0, Δtmax = 1.0, 1.0, 1.0, 1.0, args[0]
+        elif len(args) == 5:
+            μμ, κμ, α0, β0, Δtmax = args
+        else:
+            raise TypeError("LogitNormalImpulseResponse(μ, τ, Δtmax) or (μ, τ, μμ, κμ, α0, β0, Δtmax)")
+        self.μ = np.array(μ, dtype=np.float64)
+        self.τ = np.array(τ, dtype=np.float64)
+        self.μμ, self.κμ, self.α0, self.β0, self.Δtmax = float(μμ), float(κμ), float(α0), float(β0), float(Δtmax)
+
+    def size(self):
+        return self.μ.shape[0]
+
+    def params(self):
+        return np.concatenate([self.μ.ravel(order="F"), self.τ.ravel(order="F")])
+
+    def params_(self, x):
+        """params!: src/impulses.jl:154-162"""
+        if len(x) != self.μ.size + self.τ.size:
+            raise ValueError("Parameter vector length does not match model parameter length.")
+        n = self.size()
+        x = np.asarray(x, dtype=np.float64)
+        self.μ = x[: n * n].reshape((n, n), order="F").copy()
+        self.τ = x[n * n:].reshape((n, n), order="F").copy()
+
+    def resample_(self, Mnm, Xnm, Vnm, rng):
+        """resample!: normal-gamma conjugate draw -- src/impulses.jl:204-214"""
+        with np.errstate(invalid="ignore", divide="ignore"):
+            αnm = self.α0 + Mnm / 2
+            βnm = _fillna(Vnm / 2 + Mnm * self.κμ / (Mnm + self.κμ) * (Xnm - self.μμ) ** 2 / 2, self.β0)
+            self.τ = rng.gamma(αnm, 1.0 / βnm)
+            κnm = self.κμ + Mnm
+            μnm = _fillna((self.κμ * self.μμ + Mnm * Xnm) / (self.κμ + Mnm), self.μμ)
+            σ = (1.0 / (κnm * self.τ)) ** 0.5
+            self.μ = rng.normal(μnm, σ)
+        return self.μ.copy(), self.τ.copy()
+
+
+# ------------------------------------------------------------------------------ weights
+class Weights:
+    pass
+
+
+class DenseWeightModel(Weights):
+    """DenseWeightModel(W[, κ, ν, κv, νv]) -- src/weights.jl:47-55."""
+
+    def __init__(self, W, κ=1.0, ν=1.0, κv=None, νv=None):
+        self.W = np.array(W, dtype=np.float64)
+        self.κ, self.ν = float(κ), float(ν)
+        self.κv = np.ones_like(self.W) if κv is None else np.array(κv, dtype=np.float64)
+        self.νv = np.ones_like(self.W) if νv is None else np.array(νv, dtype=np.float64)
+
+    def size(self):
+        return self.W.shape[0]
+
+    def params(self):
+        return self.W.ravel(order="F").copy()
+
+    def params_(self, x):
+        """params!: src/weights.jl:9-15"""
+        if len(x) != self.W.size:
+            raise ValueError("Parameter vector length does not match model parameter length.")
+        self.W = np.asarray(x, dtype=np.float64).reshape(self.W.shape, order="F").copy()
+
+    def resample_(self, Mn, Mnm, rng):
+        """resample!: W ~ Gamma(κ + Mnm, 1/(ν + Mn[p])) -- src/weights.jl:59-64"""
+        self.W = rng.gamma(self.κ + Mnm, 1.0 / (self.ν + Mn)[:, None] * np.ones_like(Mnm))
+        return self.W
+
+    def variational_params(self):
+        return np.concatenate([self.κv.ravel(order="F"), self.νv.ravel(order="F")])
+
+
+# ------------------------------------------------------------------------------ networks
+class Network:
+    pass
+
+
+class DenseNetworkModel(Network):
+    """src/networks.jl:13-31: every link present."""
+
+    def __init__(self, nnodes):
+        self.nnodes = int(nnodes)
+
+    def params(self):
+        return np.array([])
+
+    def link_probability(self):
+        return np.ones((self.nnodes, self.nnodes))
+
+    def rand(self, rng):
+        return np.ones((self.nnodes, self.nnodes))
+
+    def resample_(self, A, rng):
+        return None
+
+
+class BernoulliNetworkModel(Network):
+    """BernoulliNetworkModel(ρ, N) with Beta(α, β) prior -- src/networks.jl:34-78."""
+
+    def __init__(self, ρ, nnodes, α=1.0, β=1.0):
+        self.ρ, self.α, self.β, self.nnodes = float(ρ), float(α), float(β), int(nnodes)
+
+    def params(self):
+        return np.array([self.ρ])
+
+    def link_probability(self):
+        return self.ρ * np.ones((self.nnodes, self.nnodes))
+
+    def rand(self, rng):
+        return (rng.uniform(size=(self.nnodes, self.nnodes)) < self.ρ).astype(np.float64)
+
+    def resample_(self, A, rng):
+        """resample!: ρ ~ Beta(α + ΣA, β + N² - ΣA) -- src/networks.jl:70-78"""
+        s = float(np.sum(A))
+        self.ρ = rng.beta(self.α + s, self.β + A.size - s)
+        return self.ρ

@@ -1,0 +1,257 @@
+"""Continuous-time process models: host mirror of src/continuous.jl on top of libnhp.so.
+
+Same entry points and argument meaning as the reference --
+loglikelihood(process, data; recursive=true), intensity(process, data, times),
+params / params!, resample_parents -- but every inner loop runs in a HIP kernel.
+`data` is the reference's tuple (events sorted ascending, nodes 1-based, duration)
+(src/continuous.jl:14,29-36).
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _lib
+from ._lib import DomainError
+from .components import (BernoulliNetworkModel, DenseNetworkModel, ExponentialImpulseResponse,
+                         HomogeneousProcess, LogGaussianCoxProcess, LogitNormalImpulseResponse)
+
+
+class HawkesProcess:
+    pass
+
+
+class ContinuousHawkesProcess(HawkesProcess):
+    def ndims(self):
+        return self.baseline.ndims()
+
+    # ---- lowering: components -> nhp_cont_model_desc
+    def lower(self):
+        N = self.ndims()
+        keep = {}
+        d = _lib.ModelDesc()
+        d.n_nodes = N
+        if isinstance(self.baseline, HomogeneousProcess):
+            d.baseline_kind, d.grid_n = _lib.BASELINE_HOMOGENEOUS, 0
+            keep["l0"] = _lib.f64(self.baseline.λ)
+        elif isinstance(self.baseline, LogGaussianCoxProcess):
+            d.baseline_kind, d.grid_n = _lib.BASELINE_LGCP, len(self.baseline.x)
+            keep["l0"] = _lib.f64(np.concatenate(self.baseline.λ))
+            keep["gx"] = _lib.f64(self.baseline.x)
+            d.grid_x = _lib.dptr(keep["gx"])
+        else:
+            raise TypeError("unsupported baseline")
+        if len(keep["l0"]) != (N if d.grid_n == 0 else N * d.grid_n):
+            raise ValueError("Parameter vector length does not match model parameter length.")
+        d.lambda0 = _lib.dptr(keep["l0"])
+        imp = self.impulses
+        if isinstance(imp, ExponentialImpulseResponse):
+            d.impulse_kind = _lib.IMPULSE_EXPONENTIAL
+            keep["th"] = _lib.colmajor(imp.θ)
+            d.theta = _lib.dptr(keep["th"])
+            shapes = [imp.θ.shape]
+        elif isinstance(imp, LogitNormalImpulseResponse):
+            d.impulse_kind = _lib.IMPULSE_LOGITNORMAL
+            keep["mu"], keep["tau"] = _lib.colmajor(imp.μ), _lib.colmajor(imp.τ)
+            d.mu, d.tau = _lib.dptr(keep["mu"]), _lib.dptr(keep["tau"])
+            shapes = [imp.μ.shape, imp.τ.shape]
+        else:
+            raise TypeError("unsupported impulse response")
+        d.dt_max = float(imp.Δtmax)
+        keep["W"] = _lib.colmajor(self.weights.W)
+        d.W = _lib.dptr(keep["W"])
+        shapes.append(self.weights.W.shape)
+        A = getattr(self, "adjacency_matrix", None)
+        if A is not None:
+            keep["A"] = _lib.colmajor(np.asarray(A, dtype=np.float64))
+            d.A = _lib.dptr(keep["A"])
+            shapes.append(np.asarray(A).shape)
+        if any(s != (N, N) for s in shapes):
+            raise ValueError("Parameter vector length does not match model parameter length.")
+        return d, keep
+
+    def device_model(self, ctx=None):
+        """Create (first call) or refresh the device-resident parameter blob."""
+        ctx = ctx or _lib.default_context()
+        d, keep = self.lower()
+        cached = getattr(self, "_dev", None)
+        if cached is not None and cached.ctx is ctx and cached.signature == _signature(d):
+            cached.update(d)
+        else:
+            self._dev = cached = DeviceModel(ctx, d)
+        del keep
+        return cached
+
+
+def _signature(d):
+    return (d.n_nodes, d.baseline_kind, d.grid_n, d.impulse_kind, bool(d.A))
+
+
+class DeviceModel:
+    """nhp_cont_model handle."""
+
+    def __init__(self, ctx, desc):
+        self.ctx, self.signature = ctx, _signature(desc)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().nhp_cont_model_create(ctx.h, C.byref(desc), C.byref(h)), ctx.h)
+        self.h = h
+        self._fin = weakref.finalize(self, _lib.lib().nhp_cont_model_destroy, h)
+
+    def update(self, desc):
+        _lib.check(_lib.lib().nhp_cont_model_update(self.ctx.h, self.h, C.byref(desc)), self.ctx.h)
+
+    def set_params(self, x):
+        x = _lib.f64(x)
+        _lib.check(_lib.lib().nhp_cont_model_set_params(self.ctx.h, self.h, _lib.dptr(x), len(x)), self.ctx.h)
+
+
+class DeviceDataset:
+    """nhp_cont_dataset handle: (events, nodes, duration) uploaded once, pre-pass done for Δtmax."""
+
+    def __init__(self, ctx, data, nnodes, Δtmax):
+        events, nodes, duration = data
+        self.events = _lib.f64(events)
+        self.nodes = np.ascontiguousarray(nodes, dtype=np.int64)
+        if len(self.events) != len(self.nodes):
+            raise ValueError("events and nodes must have the same length")
+        self.duration, self.Δtmax, self.nnodes, self.ctx = float(duration), float(Δtmax), int(nnodes), ctx
+        h = C.c_void_p()
+        _lib.check(_lib.lib().nhp_cont_dataset_create(ctx.h, _lib.dptr(self.events), _lib.iptr(self.nodes),
+                                                      len(self.events), nnodes, self.duration, self.Δtmax,
+                                                      C.byref(h)), ctx.h)
+        self.h = h
+        self._fin = weakref.finalize(self, _lib.lib().nhp_cont_dataset_destroy, h)
+
+    def __len__(self):
+        return len(self.events)
+
+    @property
+    def pairs(self):
+        return _lib.lib().nhp_cont_dataset_pairs(self.h)
+
+
+_ds_cache = {}
+
+
+def device_dataset(process, data, ctx=None):
+    """Upload `data` once per (arrays, Δtmax); repeated calls (mle!, mcmc!) reuse the device copy."""
+    if isinstance(data, DeviceDataset):
+        return data
+    ctx = ctx or _lib.default_context()
+    events, nodes, duration = data
+    key = (id(events), id(nodes), len(events), float(duration), float(process.impulses.Δtmax), process.ndims(), id(ctx))
+    hit = _ds_cache.get(key)
+    if hit is not None and hit[1]() is events:
+        return hit[0]
+    ds = DeviceDataset(ctx, data, process.ndims(), process.impulses.Δtmax)
+    try:
+        ref = weakref.ref(events)
+    except TypeError:
+        return ds          # plain lists cannot be weak-referenced: no caching
+    if len(_ds_cache) > 16:
+        _ds_cache.clear()
+    _ds_cache[key] = (ds, ref)
+    return ds
+
+
+class ContinuousStandardHawkesProcess(ContinuousHawkesProcess):
+    """ContinuousStandardHawkesProcess(baseline, impulses, weights) -- src/continuous.jl:108-112."""
+
+    def __init__(self, baseline, impulses, weights):
+        self.baseline, self.impulses, self.weights = baseline, impulses, weights
+
+    def isstable(self):
+        """src/continuous.jl:114"""
+        return np.max(np.abs(np.linalg.eigvals(self.weights.W))) < 1.0
+
+    def params(self):
+        """[baseline; impulses; weights] -- src/continuous.jl:116-119"""
+        return np.concatenate([self.baseline.params(), self.impulses.params(), self.weights.params()])
+
+    def params_(self, x):
+        """params!(process, x) -- src/continuous.jl:121-129"""
+        nb, nw, ni = len(self.baseline.params()), len(self.weights.params()), len(self.impulses.params())
+        x = np.asarray(x, dtype=np.float64)
+        if len(x) != nb + ni + nw:
+            raise ValueError("Parameter vector length does not match model parameter length.")
+        self.baseline.params_(x[:nb])
+        self.impulses.params_(x[nb:nb + ni])
+        self.weights.params_(x[nb + ni:nb + ni + nw])
+
+
+class ContinuousNetworkHawkesProcess(ContinuousHawkesProcess):
+    """ContinuousNetworkHawkesProcess(baseline, impulses, weights, adjacency_matrix, network)
+    -- src/continuous.jl:315-321."""
+
+    def __init__(self, baseline, impulses, weights, adjacency_matrix, network):
+        self.baseline, self.impulses, self.weights = baseline, impulses, weights
+        self.adjacency_matrix = np.array(adjacency_matrix, dtype=np.float64)
+        self.network = network
+
+    def isstable(self):
+        """src/continuous.jl:323"""
+        return np.max(np.abs(np.linalg.eigvals(self.adjacency_matrix * self.weights.W))) < 1.0
+
+    def params(self):
+        """[ρ; λ0; W; θ; vec(A)] -- src/continuous.jl:325-333"""
+        return np.concatenate([self.network.params(), self.baseline.params(), self.weights.params(),
+                               self.impulses.params(), self.adjacency_matrix.ravel(order="F")])
+
+
+def _check_recursive(process, recursive):
+    return _lib.LL_RECURSIVE if (recursive and isinstance(process.impulses, ExponentialImpulseResponse)) else 0
+
+
+def loglikelihood(process, data, recursive=True, ctx=None):
+    """loglikelihood(process, data; recursive=true) -- src/continuous.jl:210-239,360-389.
+
+    Exponential impulses with `recursive` take the O(M·N) recursion that ignores Δtmax
+    (:212-214); everything else takes the windowed sum."""
+    ctx = ctx or _lib.default_context()
+    ds = device_dataset(process, data, ctx)
+    model = process.device_model(ctx)
+    ll = C.c_double()
+    _lib.check(_lib.lib().nhp_cont_loglik(ctx.h, ds.h, model.h, _check_recursive(process, recursive), C.byref(ll)), ctx.h)
+    return ll.value
+
+
+def total_intensity(process, data, ctx=None):
+    """total_intensity for every event -- src/continuous.jl:286-300,391-405 (vectorised)."""
+    ctx = ctx or _lib.default_context()
+    ds = device_dataset(process, data, ctx)
+    model = process.device_model(ctx)
+    out = np.empty(len(ds))
+    _lib.check(_lib.lib().nhp_cont_event_intensity(ctx.h, ds.h, model.h, _lib.dptr(out)), ctx.h)
+    return out
+
+
+def intensity(process, data, times, ctx=None):
+    """intensity(process, data, times) -> len(times) x N; a scalar time gives a length-N vector
+    -- src/continuous.jl:76-96."""
+    ctx = ctx or _lib.default_context()
+    scalar = np.isscalar(times)
+    q = _lib.f64(np.atleast_1d(times))
+    if isinstance(process.baseline, HomogeneousProcess) and np.any(q < 0):
+        raise DomainError("time must be non-negative")
+    ds = device_dataset(process, data, ctx)
+    model = process.device_model(ctx)
+    N = process.ndims()
+    out = np.empty((N, len(q)))
+    _lib.check(_lib.lib().nhp_cont_intensity(ctx.h, ds.h, model.h, _lib.dptr(q), len(q), _lib.dptr(out)), ctx.h)
+    res = out.T.copy()
+    return res[0] if scalar else res
+
+
+def loglikelihood_gradient(process, data, recursive=True, ctx=None):
+    """(ll, ∇ll) with the gradient in params! order [λ0; θ | μ; τ; W].  The reference supplies no
+    gradient to Optim (src/continuous.jl:190), which then spends 2P objective calls on finite
+    differences; this is one fused pass."""
+    ctx = ctx or _lib.default_context()
+    ds = device_dataset(process, data, ctx)
+    model = process.device_model(ctx)
+    P = len(process.params())
+    g = np.empty(P)
+    ll = C.c_double()
+    _lib.check(_lib.lib().nhp_cont_loglik_grad(ctx.h, ds.h, model.h, _check_recursive(process, recursive),
+                                               C.byref(ll), _lib.dptr(g), P), ctx.h)
+    return ll.value, g

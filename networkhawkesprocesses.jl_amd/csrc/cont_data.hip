@@ -1,0 +1,280 @@
+// Continuous datasets (events, nodes, duration) and device-resident models.
+//
+// Dataset creation does, once per dataset, everything that does not depend on the
+// parameters: validation with the reference's error conditions, the look-back pre-pass
+// (first parent of every event's Δtmax window, using the reference's own fp64 test
+// `events[j] > t - Δtmax`, src/continuous.jl:291), the node bucketing of child events and
+// the partition of buckets into workgroup-sized items.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "nhp_internal.h"
+
+template <typename T>
+static nhp_status upload(nhp_ctx *ctx, T **dst, const T *src, size_t n)
+{
+    *dst = nullptr;
+    if (n == 0) n = 1;
+    NHP_HIP(ctx, hipMalloc((void **)dst, sizeof(T) * n));
+    if (src) NHP_HIP(ctx, hipMemcpyAsync(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice, ctx->stream));
+    return NHP_OK;
+}
+
+static int pick_group(double kbar)
+{
+    const char *env = getenv("NHP_GROUP");
+    if (env) {
+        int g = atoi(env);
+        if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64) return g;
+    }
+    int g = 1;
+    while (g < 64 && (double)g * 2.0 <= kbar) g *= 2;   // largest power of two <= kbar
+    return g;
+}
+
+extern "C" nhp_status nhp_cont_dataset_create(nhp_ctx *ctx, const double *events, const int64_t *nodes,
+                                              int64_t M, int32_t N, double duration, double dt_max,
+                                              nhp_cont_dataset **out)
+{
+    if (!ctx || !out || M < 0 || N < 1 || (M > 0 && (!events || !nodes))) return NHP_EINVAL;
+    *out = nullptr;
+    if (M >= (int64_t)1 << 31) { nhp_set_error(ctx, "n_events must be < 2^31"); return NHP_EINVAL; }
+    if (!(duration >= 0.0)) { nhp_set_error(ctx, "duration must be non-negative"); return NHP_EDOMAIN; }
+    if (!(dt_max > 0.0)) { nhp_set_error(ctx, "dt_max must be positive"); return NHP_EDOMAIN; }
+    for (int64_t i = 0; i < M; ++i) {
+        if (nodes[i] < 1 || nodes[i] > N) {
+            nhp_set_error(ctx, "node id %lld at event %lld outside 1..%d", (long long)nodes[i], (long long)(i + 1), N);
+            return NHP_EDOMAIN;
+        }
+        if (!(events[i] >= 0.0)) { nhp_set_error(ctx, "time must be non-negative (event %lld)", (long long)(i + 1)); return NHP_EDOMAIN; }
+        if (i > 0 && events[i] < events[i - 1]) { nhp_set_error(ctx, "events must be sorted (event %lld)", (long long)(i + 1)); return NHP_EINVAL; }
+    }
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+
+    nhp_cont_dataset *ds = new nhp_cont_dataset();
+    ds->ctx = ctx; ds->M = M; ds->N = N; ds->duration = duration; ds->dt_max = dt_max;
+    ds->t_last = M > 0 ? events[M - 1] : 0.0;
+
+    std::vector<int32_t> node32((size_t)M), first((size_t)M);
+    ds->h_cnt.assign((size_t)N, 0.0);
+    int64_t pairs = 0, f = 0;
+    for (int64_t i = 0; i < M; ++i) {
+        node32[i] = (int32_t)(nodes[i] - 1);
+        ds->h_cnt[node32[i]] += 1.0;
+        double thr = events[i] - dt_max;
+        while (f < i && !(events[f] > thr)) ++f;
+        first[i] = (int32_t)f;
+        pairs += i - f;
+    }
+    ds->pairs = pairs;
+    ds->group = pick_group(M > 0 ? (double)pairs / (double)M : 0.0);
+
+    // stable counting sort of children by node
+    ds->h_boff.assign((size_t)N + 1, 0);
+    for (int64_t i = 0; i < M; ++i) ds->h_boff[node32[i] + 1]++;
+    for (int32_t c = 0; c < N; ++c) ds->h_boff[c + 1] += ds->h_boff[c];
+    std::vector<nhp_child> child((size_t)M);
+    {
+        std::vector<int32_t> cur(ds->h_boff.begin(), ds->h_boff.end() - 1);
+        for (int64_t i = 0; i < M; ++i) {
+            nhp_child &r = child[cur[node32[i]]++];
+            r.t = events[i]; r.first = first[i]; r.idx = (int32_t)i;
+        }
+    }
+    // partition buckets into items of at most `chunk` children; every node gets >= 1 item
+    int64_t chunk = (M + 2047) / 2048;
+    chunk = std::max<int64_t>(32, std::min<int64_t>(1024, chunk));
+    const char *env = getenv("NHP_CHUNK");
+    if (env && atoi(env) > 0) chunk = atoi(env);
+    std::vector<nhp_item> items;
+    for (int32_t c = 0; c < N; ++c) {
+        int32_t b = ds->h_boff[c], e = ds->h_boff[c + 1];
+        int32_t n = e - b;
+        int32_t parts = std::max<int32_t>(1, (int32_t)((n + chunk - 1) / chunk));
+        for (int32_t q = 0; q < parts; ++q) {
+            nhp_item it;
+            it.node = c;
+            it.kbeg = b + (int32_t)((int64_t)n * q / parts);
+            it.kend = b + (int32_t)((int64_t)n * (q + 1) / parts);
+            it.first = q == 0;
+            items.push_back(it);
+        }
+    }
+    ds->n_items = (int32_t)items.size();
+
+    nhp_status s;
+    if ((s = upload(ctx, &ds->d_times, events, (size_t)M)) != NHP_OK ||
+        (s = upload(ctx, &ds->d_nodes, node32.data(), (size_t)M)) != NHP_OK ||
+        (s = upload(ctx, &ds->d_child, child.data(), (size_t)M)) != NHP_OK ||
+        (s = upload(ctx, &ds->d_boff, ds->h_boff.data(), (size_t)N + 1)) != NHP_OK ||
+        (s = upload(ctx, &ds->d_items, items.data(), items.size())) != NHP_OK ||
+        (s = upload(ctx, &ds->d_cnt, ds->h_cnt.data(), (size_t)N)) != NHP_OK) {
+        nhp_cont_dataset_destroy(ds);
+        return s;
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);   // host vectors go out of scope below
+    if (e != hipSuccess) { nhp_set_error(ctx, "upload failed: %s", hipGetErrorString(e)); nhp_cont_dataset_destroy(ds); return NHP_EHIP; }
+    *out = ds;
+    return NHP_OK;
+}
+
+extern "C" void nhp_cont_dataset_destroy(nhp_cont_dataset *ds)
+{
+    if (!ds) return;
+    (void)hipSetDevice(ds->ctx->device);
+    (void)hipStreamSynchronize(ds->ctx->stream);
+    (void)hipFree(ds->d_times); (void)hipFree(ds->d_nodes); (void)hipFree(ds->d_child);
+    (void)hipFree(ds->d_boff); (void)hipFree(ds->d_items); (void)hipFree(ds->d_cnt);
+    delete ds;
+}
+
+extern "C" int64_t nhp_cont_dataset_pairs(const nhp_cont_dataset *ds) { return ds ? ds->pairs : -1; }
+
+// ---- model ------------------------------------------------------------------------------
+
+static nhp_status check_desc(nhp_ctx *ctx, const nhp_cont_model_desc *d)
+{
+    if (!d || d->n_nodes < 1 || !d->W || !d->lambda0) { nhp_set_error(ctx, "model: missing W / lambda0"); return NHP_EINVAL; }
+    if (d->baseline_kind == NHP_BASELINE_LGCP) {
+        if (!d->grid_x || d->grid_n < 2) { nhp_set_error(ctx, "LGCP baseline needs a grid of >= 2 points"); return NHP_ESHAPE; }
+        if (d->grid_x[0] != 0.0) { nhp_set_error(ctx, "Grid points x must start at 0."); return NHP_EDOMAIN; }
+    } else if (d->baseline_kind != NHP_BASELINE_HOMOGENEOUS) {
+        return NHP_EINVAL;
+    }
+    if (d->impulse_kind == NHP_IMPULSE_EXPONENTIAL) {
+        if (!d->theta) { nhp_set_error(ctx, "exponential impulse needs theta"); return NHP_EINVAL; }
+    } else if (d->impulse_kind == NHP_IMPULSE_LOGITNORMAL) {
+        if (!d->mu || !d->tau) { nhp_set_error(ctx, "logit-normal impulse needs mu and tau"); return NHP_EINVAL; }
+        if (!(d->dt_max < INFINITY)) { nhp_set_error(ctx, "logit-normal impulse needs a finite dt_max"); return NHP_EDOMAIN; }
+    } else {
+        return NHP_EINVAL;
+    }
+    if (!(d->dt_max > 0.0)) { nhp_set_error(ctx, "dt_max must be positive"); return NHP_EDOMAIN; }
+    return NHP_OK;
+}
+
+static nhp_status copy_params(nhp_ctx *ctx, nhp_cont_model *m, const nhp_cont_model_desc *d)
+{
+    size_t NN = (size_t)m->N * m->N;
+    size_t nl = m->baseline_kind == NHP_BASELINE_LGCP ? (size_t)m->N * m->grid_n : (size_t)m->N;
+    hipStream_t st = ctx->stream;
+    NHP_HIP(ctx, hipMemcpyAsync(m->d_lambda0, d->lambda0, sizeof(double) * nl, hipMemcpyHostToDevice, st));
+    if (m->grid_n) {
+        NHP_HIP(ctx, hipMemcpyAsync(m->d_grid, d->grid_x, sizeof(double) * m->grid_n, hipMemcpyHostToDevice, st));
+        m->grid_end = d->grid_x[m->grid_n - 1];
+    }
+    if (m->impulse_kind == NHP_IMPULSE_EXPONENTIAL) {
+        NHP_HIP(ctx, hipMemcpyAsync(m->d_p1, d->theta, sizeof(double) * NN, hipMemcpyHostToDevice, st));
+    } else {
+        NHP_HIP(ctx, hipMemcpyAsync(m->d_p1, d->mu, sizeof(double) * NN, hipMemcpyHostToDevice, st));
+        NHP_HIP(ctx, hipMemcpyAsync(m->d_p2, d->tau, sizeof(double) * NN, hipMemcpyHostToDevice, st));
+    }
+    NHP_HIP(ctx, hipMemcpyAsync(m->d_W, d->W, sizeof(double) * NN, hipMemcpyHostToDevice, st));
+    if (m->has_A) NHP_HIP(ctx, hipMemcpyAsync(m->d_A, d->A, sizeof(double) * NN, hipMemcpyHostToDevice, st));
+    NHP_HIP(ctx, hipStreamSynchronize(st));   // host pointers are only borrowed for the call
+    return NHP_OK;
+}
+
+extern "C" nhp_status nhp_cont_model_create(nhp_ctx *ctx, const nhp_cont_model_desc *d, nhp_cont_model **out)
+{
+    if (!ctx || !out) return NHP_EINVAL;
+    *out = nullptr;
+    NHP_TRY(check_desc(ctx, d));
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    nhp_cont_model *m = new nhp_cont_model();
+    m->ctx = ctx; m->N = d->n_nodes; m->baseline_kind = d->baseline_kind;
+    m->grid_n = d->baseline_kind == NHP_BASELINE_LGCP ? d->grid_n : 0;
+    m->impulse_kind = d->impulse_kind; m->has_A = d->A != nullptr; m->dt_max = d->dt_max;
+    size_t NN = (size_t)m->N * m->N;
+    size_t nl = m->grid_n ? (size_t)m->N * m->grid_n : (size_t)m->N;
+    nhp_status s = NHP_OK;
+    if ((s = upload<double>(ctx, &m->d_lambda0, nullptr, nl)) != NHP_OK ||
+        (m->grid_n && (s = upload<double>(ctx, &m->d_grid, nullptr, (size_t)m->grid_n)) != NHP_OK) ||
+        (s = upload<double>(ctx, &m->d_p1, nullptr, NN)) != NHP_OK ||
+        (m->impulse_kind == NHP_IMPULSE_LOGITNORMAL && (s = upload<double>(ctx, &m->d_p2, nullptr, NN)) != NHP_OK) ||
+        (s = upload<double>(ctx, &m->d_W, nullptr, NN)) != NHP_OK ||
+        (m->has_A && (s = upload<double>(ctx, &m->d_A, nullptr, NN)) != NHP_OK) ||
+        (s = copy_params(ctx, m, d)) != NHP_OK) {
+        nhp_cont_model_destroy(m);
+        return s;
+    }
+    *out = m;
+    return NHP_OK;
+}
+
+extern "C" nhp_status nhp_cont_model_update(nhp_ctx *ctx, nhp_cont_model *m, const nhp_cont_model_desc *d)
+{
+    if (!ctx || !m) return NHP_EINVAL;
+    NHP_TRY(check_desc(ctx, d));
+    int grid_n = d->baseline_kind == NHP_BASELINE_LGCP ? d->grid_n : 0;
+    if (d->n_nodes != m->N || d->baseline_kind != m->baseline_kind || grid_n != m->grid_n ||
+        d->impulse_kind != m->impulse_kind || (d->A != nullptr) != (m->has_A != 0)) {
+        nhp_set_error(ctx, "Parameter vector length does not match model parameter length.");
+        return NHP_ESHAPE;
+    }
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    m->dt_max = d->dt_max;
+    return copy_params(ctx, m, d);
+}
+
+// params!(process, x): [baseline; impulses; weights]  (src/continuous.jl:121-129)
+extern "C" nhp_status nhp_cont_model_set_params(nhp_ctx *ctx, nhp_cont_model *m, const double *x, int64_t len)
+{
+    if (!ctx || !m || !x) return NHP_EINVAL;
+    if (m->baseline_kind != NHP_BASELINE_HOMOGENEOUS) { nhp_set_error(ctx, "set_params: homogeneous baseline only"); return NHP_ENOTIMPL; }
+    size_t N = (size_t)m->N, NN = N * N;
+    size_t nimp = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? NN : 2 * NN;
+    if ((size_t)len != N + nimp + NN) {
+        nhp_set_error(ctx, "Parameter vector length does not match model parameter length.");
+        return NHP_ESHAPE;
+    }
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    NHP_HIP(ctx, hipMemcpyAsync(m->d_lambda0, x, sizeof(double) * N, hipMemcpyHostToDevice, st));
+    NHP_HIP(ctx, hipMemcpyAsync(m->d_p1, x + N, sizeof(double) * NN, hipMemcpyHostToDevice, st));
+    if (m->impulse_kind == NHP_IMPULSE_LOGITNORMAL)
+        NHP_HIP(ctx, hipMemcpyAsync(m->d_p2, x + N + NN, sizeof(double) * NN, hipMemcpyHostToDevice, st));
+    NHP_HIP(ctx, hipMemcpyAsync(m->d_W, x + N + nimp, sizeof(double) * NN, hipMemcpyHostToDevice, st));
+    NHP_HIP(ctx, hipStreamSynchronize(st));
+    return NHP_OK;
+}
+
+extern "C" void nhp_cont_model_destroy(nhp_cont_model *m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    (void)hipFree(m->d_lambda0); (void)hipFree(m->d_grid); (void)hipFree(m->d_p1);
+    (void)hipFree(m->d_p2); (void)hipFree(m->d_W); (void)hipFree(m->d_A);
+    delete m;
+}
+
+nhp_cont_args nhp_make_args(const nhp_cont_dataset *ds, const nhp_cont_model *m)
+{
+    nhp_cont_args a;
+    a.times = ds->d_times; a.nodes = ds->d_nodes; a.child = ds->d_child; a.boff = ds->d_boff;
+    a.items = ds->d_items; a.cnt = ds->d_cnt;
+    a.lambda0 = m->d_lambda0; a.grid = m->d_grid; a.p1 = m->d_p1; a.p2 = m->d_p2; a.W = m->d_W;
+    a.A = m->has_A ? m->d_A : nullptr;
+    a.M = ds->M; a.N = ds->N; a.grid_n = m->grid_n; a.baseline_kind = m->baseline_kind;
+    a.impulse_kind = m->impulse_kind; a.dt_max = ds->dt_max; a.inv_dtmax = 1.0 / ds->dt_max;
+    a.duration = ds->duration;
+    return a;
+}
+
+nhp_status nhp_check_pair(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m)
+{
+    if (!ctx || !ds || !m) return NHP_EINVAL;
+    if (ds->ctx != ctx || m->ctx != ctx) { nhp_set_error(ctx, "dataset / model belong to another ctx"); return NHP_EINVAL; }
+    if (ds->N != m->N) { nhp_set_error(ctx, "dataset has %d nodes, model %d", ds->N, m->N); return NHP_ESHAPE; }
+    if (!(ds->dt_max == m->dt_max)) { nhp_set_error(ctx, "dataset dt_max %g != model dt_max %g", ds->dt_max, m->dt_max); return NHP_EINVAL; }
+    // LinearInterpolator throws DomainError outside its support (src/utils/interpolation.jl:29)
+    if (m->baseline_kind == NHP_BASELINE_LGCP && ds->M > 0 && ds->t_last > m->grid_end) {
+        nhp_set_error(ctx, "Value is outside interpolation support (0, %g)", m->grid_end);
+        return NHP_EDOMAIN;
+    }
+    return NHP_OK;
+}

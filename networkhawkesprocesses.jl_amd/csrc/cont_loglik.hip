@@ -1,0 +1,233 @@
+// Windowed continuous log-likelihood: Σ_i log λ_{c_i}(t_i) with
+//   λ_c(t_i) = λ0_c(t_i) + Σ_{j<i, t_j > t_i-Δtmax} A[n_j,c] W[n_j,c] ħ(t_i - t_j; θ[n_j,c])
+// (reference: loglikelihood src/continuous.jl:210-239,360-389; total_intensity :286-300,
+//  :391-405; impulse_response :302-305,:521-525).
+//
+// Mapping to CDNA4
+//  * Child events are bucketed by node (done once per dataset).  A workgroup owns a run of
+//    children of ONE node c, so column c of the parameter tables -- contiguous in the
+//    reference's column-major layout -- is staged once in LDS (16-24 B per parent node) and
+//    every W[n_j,c] / θ[n_j,c] gather becomes an LDS read instead of a random HBM/L2 access
+//    into an N x N table.
+//  * G lanes (a power of two chosen from the mean window length) cooperate on one child:
+//    lane g reads parents i-1-g, i-1-g-G, ... so a group's loads of (times, nodes) are
+//    contiguous, and the group sum is a log2(G)-step cross-lane reduction.
+//  * The per-event row-sum loop of the reference (Σ_i Σ_c W[n_i,c], :219-221) is regrouped
+//    as Σ_c Σ_p cnt[p] W[p,c] and folded into the column staging of the node's first item,
+//    so every parameter is read from HBM exactly once per evaluation.
+//  * Sums are reduced lane -> wave -> block -> one partial per workgroup; a one-block second
+//    kernel adds the partials in a fixed order (deterministic, no atomics).
+#include "nhp_internal.h"
+#include "nhp_math.h"
+
+template <int G>
+__device__ __forceinline__ double group_sum(double v)
+{
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Baseline intensity λ0_c(t): HomogeneousProcess (src/baselines.jl:115-118) or the
+// LogGaussianCoxProcess evaluator = LinearInterpolator on the grid
+// (src/baselines.jl:332-334, src/utils/interpolation.jl:27-36; bin i iff x[i] <= t < x[i+1],
+// y[end] at the right edge).  Binary search finds the same bin as the reference's scan.
+__device__ __forceinline__ double baseline_at(const nhp_cont_args &a, int c, double t)
+{
+#pragma clang fp contract(off)
+    if (a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) return a.lambda0[c];
+    const double *x = a.grid;
+    const double *y = a.lambda0 + (size_t)c * a.grid_n;
+    int lo = 0, hi = a.grid_n - 1;          // invariant: x[lo] <= t, and t < x[hi] or hi is the end
+    if (!(t < x[hi])) return y[hi];
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (t >= x[mid]) lo = mid; else hi = mid;
+    }
+    return (y[lo + 1] * (t - x[lo]) + y[lo] * (x[lo + 1] - t)) / (x[lo + 1] - x[lo]);
+}
+
+template <int IMP, int G>
+__global__ __launch_bounds__(NHP_BLOCK) void k_windowed(nhp_cont_args a, int mask_integral,
+                                                        double *__restrict__ partials,
+                                                        double *__restrict__ lambda_out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *red = reinterpret_cast<double *>(smem);                 // [NHP_WAVES]
+    double2 *col = reinterpret_cast<double2 *>(smem + 32);          // [N]
+    double *colw = reinterpret_cast<double *>(col + a.N);           // [N], logit-normal only
+
+    const nhp_item it = a.items[blockIdx.x];
+    const int c = it.node, N = a.N, tid = threadIdx.x;
+
+    // ---- stage column c; the node's first item also owns the column's integral term
+    double integ = 0.0;
+    for (int p = tid; p < N; p += NHP_BLOCK) {
+        const size_t k = (size_t)p + (size_t)c * N;
+        double w = a.W[k], wint = w;
+        if (a.A) {
+            w = a.A[k] * w;
+            if (mask_integral) wint = w;
+        }
+        if (IMP == NHP_IMPULSE_EXPONENTIAL) {
+            col[p] = make_double2(a.p1[k], w);
+        } else {
+            col[p] = make_double2(a.p1[k], __builtin_sqrt(a.p2[k]));
+            colw[p] = w;
+        }
+        if (it.first) integ += a.cnt[p] * wint;
+    }
+    __syncthreads();
+
+    // ---- children: G lanes per child
+    constexpr int GROUPS = NHP_BLOCK / G;
+    const int gid = tid / G, gl = tid % G;
+    double acc = 0.0;
+    for (int k = it.kbeg + gid; k < it.kend; k += GROUPS) {
+        const nhp_child ch = a.child[k];
+        double s = 0.0;
+        for (int j = ch.idx - 1 - gl; j >= ch.first; j -= G) {
+            const double dt = ch.t - a.times[j];
+            const int p = a.nodes[j];
+            const double2 q = col[p];
+            if (IMP == NHP_IMPULSE_EXPONENTIAL)
+                s += q.y * nhp_pdf_exponential(q.x, dt);
+            else
+                s += colw[p] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
+        }
+        s = group_sum<G>(s);
+        if (gl == 0) {
+            const double lam = baseline_at(a, c, ch.t) + s;
+            acc += nhp_log(lam);
+            if (lambda_out) lambda_out[ch.idx] = lam;
+        }
+    }
+    const double blk = nhp_block_sum(acc, red);
+    const double blk_int = nhp_block_sum(integ, red);
+    if (tid == 0) {
+        partials[2 * (size_t)blockIdx.x] = blk;
+        partials[2 * (size_t)blockIdx.x + 1] = blk_int;
+    }
+}
+
+// ll = -Σ_c ∫λ0_c - Σ_blocks integ + Σ_blocks loglam   (src/continuous.jl:216-221,237)
+// Baseline integral: λ .* duration (src/baselines.jl:98-102) or the trapezoid rule over the
+// grid, which ignores `duration` (src/baselines.jl:336, src/utils/interpolation.jl:40-48).
+__global__ __launch_bounds__(NHP_BLOCK) void k_finalize(nhp_cont_args a, const double *__restrict__ partials,
+                                                        int n_partials, double *__restrict__ out)
+{
+    __shared__ double red[NHP_WAVES];
+    double sl = 0.0, si = 0.0, sb = 0.0;
+    for (int i = threadIdx.x; i < n_partials; i += NHP_BLOCK) {
+        sl += partials[2 * (size_t)i];
+        si += partials[2 * (size_t)i + 1];
+    }
+    for (int c = threadIdx.x; c < a.N; c += NHP_BLOCK) {
+        if (a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) {
+            sb += a.lambda0[c] * a.duration;
+        } else {
+            const double *y = a.lambda0 + (size_t)c * a.grid_n;
+            double I = 0.0;
+            for (int i = 0; i + 1 < a.grid_n; ++i) I += 0.5 * (y[i] + y[i + 1]) * (a.grid[i + 1] - a.grid[i]);
+            sb += I;
+        }
+    }
+    sl = nhp_block_sum(sl, red);
+    si = nhp_block_sum(si, red);
+    sb = nhp_block_sum(sb, red);
+    if (threadIdx.x == 0) *out = (0.0 - sb) - si + sl;
+}
+
+template <int IMP>
+static void launch_group(int G, dim3 grid, size_t lds, hipStream_t st, const nhp_cont_args &a, int mask,
+                         double *partials, double *lambda_out)
+{
+#define NHP_CASE(g)                                                                                 \
+    case g:                                                                                         \
+        hipLaunchKernelGGL((k_windowed<IMP, g>), grid, dim3(NHP_BLOCK), lds, st, a, mask, partials, lambda_out); \
+        break;
+    switch (G) {
+        NHP_CASE(1) NHP_CASE(2) NHP_CASE(4) NHP_CASE(8) NHP_CASE(16) NHP_CASE(32)
+    default:
+        hipLaunchKernelGGL((k_windowed<IMP, 64>), grid, dim3(NHP_BLOCK), lds, st, a, mask, partials, lambda_out);
+    }
+#undef NHP_CASE
+}
+
+static nhp_status run_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m,
+                               double *d_out, double *d_lambda)
+{
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t per = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? 16 : 24;
+    const size_t lds = 32 + per * (size_t)ds->N;
+    if (lds > 160 * 1024) { nhp_set_error(ctx, "n_nodes = %d exceeds the LDS column budget", ds->N); return NHP_ENOTIMPL; }
+    NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)ds->n_items));
+    nhp_cont_args a = nhp_make_args(ds, m);
+    if (lds > 64 * 1024) {
+        // opt in to the large dynamic-LDS carve-out for every instantiation we may launch
+        nhp_set_error(ctx, "n_nodes = %d needs > 64 KiB LDS columns (not enabled yet)", ds->N);
+        return NHP_ENOTIMPL;
+    }
+    dim3 grid((unsigned)ds->n_items);
+    if (m->impulse_kind == NHP_IMPULSE_EXPONENTIAL)
+        launch_group<NHP_IMPULSE_EXPONENTIAL>(ds->group, grid, lds, ctx->stream, a, 1, ctx->d_partials, d_lambda);
+    else
+        launch_group<NHP_IMPULSE_LOGITNORMAL>(ds->group, grid, lds, ctx->stream, a, 1, ctx->d_partials, d_lambda);
+    NHP_HIP(ctx, hipGetLastError());
+    if (d_out) return nhp_launch_finalize(ctx, a, ds->n_items, d_out);
+    return NHP_OK;
+}
+
+nhp_status nhp_launch_finalize(nhp_ctx *ctx, const nhp_cont_args &a, int n_partials, double *d_out)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(NHP_BLOCK), 0, ctx->stream, a, ctx->d_partials, n_partials, d_out);
+    NHP_HIP(ctx, hipGetLastError());
+    return NHP_OK;
+}
+
+nhp_status nhp_launch_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_out)
+{
+    return run_windowed(ctx, ds, m, d_out, nullptr);
+}
+
+nhp_status nhp_launch_event_intensity(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_lambda)
+{
+    return run_windowed(ctx, ds, m, nullptr, d_lambda);
+}
+
+// ---- C ABI ------------------------------------------------------------------------------
+
+static nhp_status enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, int32_t flags, int32_t slot)
+{
+    NHP_TRY(nhp_check_pair(ctx, ds, m));
+    if (slot < 0 || slot >= NHP_MAX_SLOTS) return NHP_EINVAL;
+    if ((flags & NHP_LL_RECURSIVE) && m->impulse_kind == NHP_IMPULSE_EXPONENTIAL)
+        return nhp_launch_recursive(ctx, ds, m, ctx->d_results + slot);
+    return nhp_launch_windowed(ctx, ds, m, ctx->d_results + slot);
+}
+
+extern "C" nhp_status nhp_cont_loglik_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds,
+                                              const nhp_cont_model *m, int32_t flags, int32_t slot)
+{
+    return enqueue(ctx, ds, m, flags, slot);
+}
+
+extern "C" nhp_status nhp_cont_loglik(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m,
+                                      int32_t flags, double *ll)
+{
+    if (!ll) return NHP_EINVAL;
+    NHP_TRY(enqueue(ctx, ds, m, flags, 0));
+    return nhp_ctx_fetch(ctx, 0, 1, ll);
+}
+
+extern "C" nhp_status nhp_cont_event_intensity(nhp_ctx *ctx, const nhp_cont_dataset *ds,
+                                               const nhp_cont_model *m, double *lambda)
+{
+    if (!lambda) return NHP_EINVAL;
+    NHP_TRY(nhp_check_pair(ctx, ds, m));
+    NHP_TRY(nhp_ctx_reserve_scratch(ctx, sizeof(double) * (size_t)(ds->M > 0 ? ds->M : 1)));
+    NHP_TRY(nhp_launch_event_intensity(ctx, ds, m, (double *)ctx->d_scratch));
+    NHP_HIP(ctx, hipMemcpyAsync(lambda, ctx->d_scratch, sizeof(double) * (size_t)ds->M, hipMemcpyDeviceToHost, ctx->stream));
+    NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NHP_OK;
+}

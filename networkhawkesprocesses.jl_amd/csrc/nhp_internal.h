@@ -1,0 +1,143 @@
+// Internal declarations shared by the translation units of libnhp.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/nhp.h"
+
+#define NHP_BLOCK 256          // 4 waves of 64 lanes
+#define NHP_WAVES (NHP_BLOCK / 64)
+
+struct nhp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double *d_results = nullptr;        // [NHP_MAX_SLOTS] log-likelihood results
+    double *h_results = nullptr;        // pinned mirror
+    double *d_partials = nullptr;       // per-workgroup partial sums
+    size_t partials_cap = 0;            // in doubles
+    void *d_scratch = nullptr;          // general scratch (gradients, sampler output)
+    size_t scratch_cap = 0;             // bytes
+    int cu_count = 256;
+    std::string err;
+};
+
+// One contiguous run of bucketed children of a single node, processed by one workgroup.
+struct nhp_item {
+    int32_t node;      // child node c (0-based)
+    int32_t kbeg;      // first child slot in bucket order
+    int32_t kend;      // one past the last
+    int32_t first;     // 1 if this is the first item of its node (owns the column's integral term)
+};
+
+// A child event in node-bucketed order: everything a wave needs to walk its window.
+struct __attribute__((aligned(16))) nhp_child {
+    double t;          // event time
+    int32_t first;     // index of the first parent inside the look-back window
+    int32_t idx;       // original (time-ordered) index of this event; window = [first, idx)
+};
+
+struct nhp_cont_dataset {
+    nhp_ctx *ctx = nullptr;
+    int64_t M = 0;
+    int32_t N = 0;
+    double duration = 0.0, dt_max = 0.0, t_last = 0.0;
+    int64_t pairs = 0;
+    int32_t group = 8;                  // lanes cooperating on one child in the windowed kernels
+    int32_t n_items = 0;
+    // device arrays
+    double *d_times = nullptr;          // [M] time order
+    int32_t *d_nodes = nullptr;         // [M] 0-based
+    nhp_child *d_child = nullptr;       // [M] bucket order
+    int32_t *d_boff = nullptr;          // [N+1] bucket offsets
+    nhp_item *d_items = nullptr;        // [n_items]
+    double *d_cnt = nullptr;            // [N] events per node
+    // host copies kept for host-side helpers
+    std::vector<int32_t> h_boff;
+    std::vector<double> h_cnt;
+};
+
+struct nhp_cont_model {
+    nhp_ctx *ctx = nullptr;
+    int32_t N = 0, baseline_kind = 0, grid_n = 0, impulse_kind = 0, has_A = 0;
+    double dt_max = 0.0, grid_end = 0.0;
+    double *d_lambda0 = nullptr, *d_grid = nullptr;
+    double *d_p1 = nullptr;             // theta (exp) or mu (logit-normal)
+    double *d_p2 = nullptr;             // tau (logit-normal)
+    double *d_W = nullptr, *d_A = nullptr;
+};
+
+// Kernel-side view of model + data (passed by value).
+struct nhp_cont_args {
+    const double *times;
+    const int32_t *nodes;
+    const nhp_child *child;
+    const int32_t *boff;
+    const nhp_item *items;
+    const double *cnt;
+    const double *lambda0, *grid;
+    const double *p1, *p2, *W, *A;
+    int64_t M;
+    int32_t N, grid_n, baseline_kind, impulse_kind;
+    double dt_max, inv_dtmax, duration;
+};
+
+struct nhp_disc_dataset {
+    nhp_ctx *ctx = nullptr;
+    int32_t N = 0, B = 0, L = 0;
+    int64_t T = 0;
+    int32_t *d_data = nullptr;          // [N*T] counts narrowed to i32, node fastest
+    double *d_dataT = nullptr;          // [T*N] counts as f64, t fastest (GEMM operand)
+    double *d_conv = nullptr;           // [T*N*B] t fastest
+    double *d_colsum = nullptr;         // [N] Σ_t data[n,t]
+};
+
+// ---- error plumbing -------------------------------------------------------------------
+void nhp_set_error(nhp_ctx *ctx, const char *fmt, ...);
+#define NHP_HIP(ctx, call)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            nhp_set_error(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return NHP_EHIP;                                                                 \
+        }                                                                                    \
+    } while (0)
+#define NHP_TRY(expr)                      \
+    do {                                   \
+        nhp_status s_ = (expr);            \
+        if (s_ != NHP_OK) return s_;       \
+    } while (0)
+
+nhp_status nhp_ctx_reserve_partials(nhp_ctx *ctx, size_t n_doubles);
+nhp_status nhp_ctx_reserve_scratch(nhp_ctx *ctx, size_t bytes);
+nhp_cont_args nhp_make_args(const nhp_cont_dataset *ds, const nhp_cont_model *m);
+nhp_status nhp_check_pair(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m);
+
+// launchers implemented in the kernel translation units (all asynchronous on ctx->stream)
+nhp_status nhp_launch_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_out);
+nhp_status nhp_launch_recursive(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_out);
+nhp_status nhp_launch_finalize(nhp_ctx *ctx, const nhp_cont_args &a, int n_partials, double *d_out);
+nhp_status nhp_launch_event_intensity(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_lambda);
+
+// ---- device helpers --------------------------------------------------------------------
+__device__ __forceinline__ double nhp_wave_sum(double v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Sum over a 256-thread block; result valid in thread 0.  `red` holds >= NHP_WAVES doubles.
+__device__ __forceinline__ double nhp_block_sum(double v, double *red)
+{
+    v = nhp_wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < NHP_WAVES; ++w) s += red[w];
+    return s;
+}

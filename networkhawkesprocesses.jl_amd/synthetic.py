@@ -1,0 +1,84 @@
+"""Seeded synthetic workloads.  numpy PCG64, one seed per array, so the same
+inputs are regenerated anywhere (tests, bench.py, the GPU box) without shipping data.
+
+The reference's own generator (`rand(process, duration)`, src/continuous.jl:16-48) is a
+recursive branching simulator used for N=2 examples; `branching_sample` below is an
+independent iterative implementation of the same generative model for the README-sized case,
+and `s_metric` draws i.i.d. uniform event times for the large throughput configurations.
+"""
+import numpy as np
+
+from .components import (DenseWeightModel, ExponentialImpulseResponse, HomogeneousProcess,
+                         LogitNormalImpulseResponse)
+from .continuous import ContinuousNetworkHawkesProcess, ContinuousStandardHawkesProcess
+from .components import BernoulliNetworkModel
+
+
+def s_metric_data(N=1024, M=1_000_000, kbar=8.0, dt_max=1.0):
+    """times = sort(T·U[0,1)) seed 0, nodes ~ UniformInt{1..N} seed 1, T = M·Δtmax/K̄."""
+    T = M * dt_max / kbar
+    times = np.sort(np.random.default_rng(0).uniform(0.0, T, M))
+    nodes = np.random.default_rng(1).integers(1, N + 1, M).astype(np.int64)
+    return times, nodes, float(T)
+
+
+def s_metric_process(N, M, T, kind="exponential", dt_max=1.0, network=False):
+    """λ0 ~ U(.5,1.5)·0.5·M/(N·T); W ~ U(0,1)/N; θ ~ U(1,5)/Δtmax; μ ~ N(0,1); τ ~ U(.5,2);
+    A ~ Bernoulli(0.5).  Seeds 2-6."""
+    lam0 = np.random.default_rng(2).uniform(0.5, 1.5, N) * 0.5 * M / (N * T)
+    W = np.random.default_rng(3).uniform(0.0, 1.0, (N, N)) / N
+    baseline = HomogeneousProcess(lam0)
+    weights = DenseWeightModel(W)
+    if kind == "exponential":
+        theta = np.random.default_rng(4).uniform(1.0, 5.0, (N, N)) / (dt_max if np.isfinite(dt_max) else 1.0)
+        impulses = ExponentialImpulseResponse(theta, 1.0, 1.0, dt_max)
+    else:
+        mu = np.random.default_rng(4).normal(0.0, 1.0, (N, N))
+        tau = np.random.default_rng(5).uniform(0.5, 2.0, (N, N))
+        impulses = LogitNormalImpulseResponse(mu, tau, dt_max)
+    if not network:
+        return ContinuousStandardHawkesProcess(baseline, impulses, weights)
+    A = (np.random.default_rng(6).uniform(size=(N, N)) < 0.5).astype(np.float64)
+    return ContinuousNetworkHawkesProcess(baseline, impulses, weights, A, BernoulliNetworkModel(0.5, N))
+
+
+def branching_sample(lam0, W, theta, duration, seed=0, max_events=2_000_000):
+    """Exponential standard Hawkes process by generation-wise branching (the generative model of
+    src/continuous.jl:16-48,131-142: Poisson(W[p,c]) children at Exponential(1/θ[p,c]) delays)."""
+    rng = np.random.default_rng(seed)
+    lam0, W, theta = np.asarray(lam0, float), np.asarray(W, float), np.asarray(theta, float)
+    N = len(lam0)
+    times, nodes = [], []
+    gen_t, gen_n = [], []
+    for c in range(N):
+        n = rng.poisson(lam0[c] * duration)
+        gen_t.append(rng.uniform(0.0, duration, n))
+        gen_n.append(np.full(n, c))
+    gen_t, gen_n = np.concatenate(gen_t), np.concatenate(gen_n)
+    while len(gen_t):
+        times.append(gen_t)
+        nodes.append(gen_n)
+        if sum(len(t) for t in times) > max_events:
+            raise RuntimeError("branching process exploded (unstable weights?)")
+        nt, nn = [], []
+        for c in range(N):
+            k = rng.poisson(W[gen_n, c])
+            rep_t, rep_p = np.repeat(gen_t, k), np.repeat(gen_n, k)
+            child = rep_t + rng.exponential(1.0 / theta[rep_p, c])
+            keep = child <= duration
+            nt.append(child[keep])
+            nn.append(np.full(int(keep.sum()), c))
+        gen_t, gen_n = np.concatenate(nt), np.concatenate(nn)
+    times, nodes = np.concatenate(times), np.concatenate(nodes)
+    order = np.argsort(times, kind="stable")
+    return times[order], (nodes[order] + 1).astype(np.int64), float(duration)
+
+
+def readme_case(seed=0):
+    """C1: the README model verbatim (README.md:27-34): N=2, λ0=1, W=0.1, θ=1, Δtmax=Inf, T=1000."""
+    N, T = 2, 1000.0
+    process = ContinuousStandardHawkesProcess(HomogeneousProcess(np.ones(N)),
+                                              ExponentialImpulseResponse(np.ones((N, N))),
+                                              DenseWeightModel(0.1 * np.ones((N, N))))
+    data = branching_sample(np.ones(N), 0.1 * np.ones((N, N)), np.ones((N, N)), T, seed)
+    return process, data
