@@ -157,6 +157,11 @@ nhp_status nhp_cont_resample_parents(nhp_ctx *ctx, const nhp_cont_dataset *ds,
 /* the uniform stream itself (host side, same bits as the kernel draws) */
 void nhp_uniform_stream(uint64_t seed, uint64_t step, int64_t n, double *u);
 
+/* diagnostics: evaluate a device math primitive elementwise (op 0 exp, 1 log, 2 sqrt, 3 x/y,
+ * 4 exp for x<=0, 5 exponential pdf(θ=x, Δt=y), 6 logit-normal pdf(τ=x, Δt=y; μ=.25, Δtmax=2));
+ * lets tests hold the kernels' fixed operation sequences to a bitwise contract */
+nhp_status nhp_probe_math(nhp_ctx *ctx, int32_t op, const double *x, const double *y, int64_t n, double *out);
+
 /* ---- discrete data: N x T counts  src/discrete.jl:18,80 -------------------------------- */
 nhp_status nhp_disc_dataset_create(nhp_ctx *ctx, const int64_t *data, int32_t n_nodes, int64_t n_bins,
                                    nhp_disc_dataset **out);

@@ -12,4 +12,5 @@ from .components import (BernoulliNetworkModel, DenseNetworkModel, DenseWeightMo
 from .continuous import (ContinuousNetworkHawkesProcess, ContinuousStandardHawkesProcess,  # noqa: F401
                          DeviceDataset, device_dataset, intensity, loglikelihood,
                          loglikelihood_gradient, total_intensity)
+from .parents import node_counts, parent_counts, resample_parents, uniform_stream  # noqa: F401
 from . import synthetic  # noqa: F401

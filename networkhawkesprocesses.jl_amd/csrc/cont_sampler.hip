@@ -1,0 +1,293 @@
+// Parent-assignment sampler and Gibbs sufficient statistics (reference:
+// resample_parents / resample_parent src/parents.jl:1-46; node_counts / parent_counts
+// :61-79; baseline node_counts src/baselines.jl:87-96; duration_mean src/impulses.jl:84-96;
+// log_duration_sum / log_duration_variation :228-252).
+//
+// Sampler.  One categorical draw per event over the weights
+//     [A·W·ħ(t_i - t_{i-1}), A·W·ħ(t_i - t_{i-2}), ..., λ0_{c_i}(t_i)]
+// (most recent parent first, baseline last), normalised by their sum, with the inverse-CDF
+// rule of Distributions.jl: smallest k with cumsum_k > u, capped at the last entry.
+// BASELINE.json asks for indices that are bit-exact for a fixed uniform stream, so a child is
+// owned by ONE lane that (1) sums the weights in exactly the order Julia's `sum` uses on the
+// reference's Vector{Any} -- sequential up to 1024 entries, midpoint-split pairwise above --
+// and (2) rescans them in order; every weight is evaluated with the fixed operation sequence
+// of nhp_math.h.  The look-back window makes this embarrassingly parallel over events
+// (children are node-bucketed so column c of the parameter tables sits in LDS).
+// Uniforms: a caller-supplied array, or Philox4x32-10 keyed (seed, step, event index).
+//
+// Statistics.  The sampler also writes, in bucket order, each child's parent node and the
+// child-parent delay.  A second kernel gives workgroup c the children of node c and lets
+// lane p scan them for parent node p: no atomics, every (p,c) cell accumulates in child time
+// order -- the order the reference's serial loops use -- so ΣΔt is reproducible bit for bit.
+#include "nhp_internal.h"
+#include "nhp_math.h"
+
+struct samp_col {                  // staged column c of the parameter tables
+    const double2 *col;            // exp: {rate, a*w};  logit-normal: {mu, sqrt(tau)}
+    const double *colw;            // logit-normal: a*w
+};
+
+template <int IMP>
+__device__ __forceinline__ double samp_weight(const nhp_cont_args &a, const samp_col &sc, double t, int j)
+{
+#pragma clang fp contract(off)
+    const double dt = t - a.times[j];
+    const int p = a.nodes[j];
+    const double2 q = sc.col[p];
+    if (IMP == NHP_IMPULSE_EXPONENTIAL) return q.y * nhp_pdf_exponential(q.x, dt);
+    return sc.colw[p] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
+}
+
+__device__ __forceinline__ double samp_baseline(const nhp_cont_args &a, int c, double t)
+{
+#pragma clang fp contract(off)
+    if (a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) return a.lambda0[c];
+    const double *x = a.grid;
+    const double *y = a.lambda0 + (size_t)c * a.grid_n;
+    int lo = 0, hi = a.grid_n - 1;
+    if (!(t < x[hi])) return y[hi];
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (t >= x[mid]) lo = mid; else hi = mid;
+    }
+    return (y[lo + 1] * (t - x[lo]) + y[lo] * (x[lo + 1] - t)) / (x[lo + 1] - x[lo]);
+}
+
+// weight k of child i: k < n-1 -> parent i-1-k, k == n-1 -> baseline
+#define SAMP_W(k) ((k) < n - 1 ? samp_weight<IMP>(a, sc, t, i - 1 - (k)) : base)
+
+// Sequential left fold over [lo, hi] -- Julia's mapreduce_impl leaf (and the n < 16 path).
+template <int IMP>
+__device__ __forceinline__ double samp_fold(const nhp_cont_args &a, const samp_col &sc, double t, int i,
+                                            int n, double base, int lo, int hi)
+{
+#pragma clang fp contract(off)
+    double v = SAMP_W(lo);
+    for (int k = lo + 1; k <= hi; ++k) v = v + SAMP_W(k);
+    return v;
+}
+
+// Julia Base `sum` over n boxed elements: sequential for n <= 1024, otherwise split at
+// lo + (hi-lo)>>1 recursively (reduce.jl, pairwise_blocksize = 1024).  Iterative post-order.
+template <int IMP>
+__device__ double samp_sum(const nhp_cont_args &a, const samp_col &sc, double t, int i, int n, double base)
+{
+#pragma clang fp contract(off)
+    if (n <= 1024) return samp_fold<IMP>(a, sc, t, i, n, base, 0, n - 1);
+    int s_lo[24], s_hi[24], s_state[24];
+    double s_left[24];
+    int sp = 0;
+    double ret = 0.0;
+    s_lo[0] = 0; s_hi[0] = n - 1; s_state[0] = 0; sp = 1;
+    while (sp > 0) {
+        const int f = sp - 1;
+        const int lo = s_lo[f], hi = s_hi[f];
+        if (s_state[f] == 0) {
+            if (hi - lo < 1024) {
+                ret = samp_fold<IMP>(a, sc, t, i, n, base, lo, hi);
+                --sp;
+            } else {
+                s_state[f] = 1;
+                s_lo[sp] = lo; s_hi[sp] = lo + ((hi - lo) >> 1); s_state[sp] = 0; ++sp;
+            }
+        } else if (s_state[f] == 1) {
+            s_left[f] = ret;
+            s_state[f] = 2;
+            s_lo[sp] = lo + ((hi - lo) >> 1) + 1; s_hi[sp] = hi; s_state[sp] = 0; ++sp;
+        } else {
+            ret = s_left[f] + ret;
+            --sp;
+        }
+    }
+    return ret;
+}
+
+template <int IMP>
+__global__ __launch_bounds__(NHP_BLOCK) void k_sampler(nhp_cont_args a, const double *__restrict__ u,
+                                                       uint64_t seed, uint64_t step,
+                                                       int64_t *__restrict__ parents, int64_t *__restrict__ pnodes,
+                                                       int32_t *__restrict__ pn_b, double *__restrict__ dt_b,
+                                                       int *__restrict__ err)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 *col = reinterpret_cast<double2 *>(smem);
+    double *colw = reinterpret_cast<double *>(col + a.N);
+    const nhp_item it = a.items[blockIdx.x];
+    const int c = it.node, N = a.N, tid = threadIdx.x;
+    for (int p = tid; p < N; p += NHP_BLOCK) {
+        const size_t k = (size_t)p + (size_t)c * N;
+        double w = a.W[k];
+        if (a.A) w = a.A[k] * w;
+        if (IMP == NHP_IMPULSE_EXPONENTIAL) {
+            const double scale = 1.0 / a.p1[k];            // Exponential(1/θ) ...
+            col[p] = make_double2(1.0 / scale, w);         // ... and its rate inv(scale)
+        } else {
+            col[p] = make_double2(a.p1[k], __builtin_sqrt(a.p2[k]));
+            colw[p] = w;
+        }
+    }
+    __syncthreads();
+    samp_col sc{col, colw};
+
+    for (int k = it.kbeg + tid; k < it.kend; k += NHP_BLOCK) {
+        const nhp_child ch = a.child[k];
+        const int i = ch.idx;
+        const double t = ch.t;
+        int parent = -1;
+        if (i > 0) {                                       // index == 1 -> (0, 0): src/parents.jl:26-28
+            const int n = i - ch.first + 1;
+            const double base = samp_baseline(a, c, t);
+            const double s = samp_sum<IMP>(a, sc, t, i, n, base);
+            if (!(s > 0.0) || !(s < __builtin_inf())) *err = 1;
+            const double draw = u ? u[i] : nhp_philox_uniform(seed, step, (uint64_t)i);
+            int kk = 0;
+            double cp = SAMP_W(0) / s;
+            while (cp <= draw && kk < n - 1) {
+                ++kk;
+                cp = cp + SAMP_W(kk) / s;
+            }
+            if (kk < n - 1) parent = i - 1 - kk;
+        }
+        const int pnode = parent >= 0 ? a.nodes[parent] : -1;
+        if (parents) parents[i] = (int64_t)parent + 1;     // 1-based event index, 0 = baseline
+        if (pnodes) pnodes[i] = (int64_t)pnode + 1;
+        pn_b[k] = pnode;
+        dt_b[k] = parent >= 0 ? t - a.times[parent] : 0.0;
+    }
+}
+
+// ---- statistics: workgroup c, lane p scans the children of c ------------------------------
+#define STAT_PQ 4      // parent nodes per lane per sweep
+__global__ __launch_bounds__(NHP_BLOCK) void k_stats(nhp_cont_args a, const int32_t *__restrict__ pn_b,
+                                                     const double *__restrict__ dt_b,
+                                                     double *__restrict__ cnt0, double *__restrict__ Mn,
+                                                     double *__restrict__ Mnm, double *__restrict__ Xnm,
+                                                     double *__restrict__ Vnm)
+{
+#pragma clang fp contract(off)
+    __shared__ int s_pn[NHP_BLOCK];
+    __shared__ double s_v[NHP_BLOCK];
+    __shared__ double red[NHP_WAVES];
+    const int c = blockIdx.x, N = a.N, tid = threadIdx.x;
+    const int kb = a.boff[c], ke = a.boff[c + 1];
+    const bool lognorm = a.impulse_kind == NHP_IMPULSE_LOGITNORMAL;
+
+    for (int p0 = 0; p0 < N; p0 += NHP_BLOCK * STAT_PQ) {
+        double cnt[STAT_PQ], sx[STAT_PQ], sv[STAT_PQ], mean[STAT_PQ];
+#pragma unroll
+        for (int q = 0; q < STAT_PQ; ++q) { cnt[q] = 0.0; sx[q] = 0.0; sv[q] = 0.0; mean[q] = 0.0; }
+        for (int pass = 0; pass < (lognorm ? 2 : 1); ++pass) {
+            for (int k0 = kb; k0 < ke; k0 += NHP_BLOCK) {
+                __syncthreads();
+                const int k = k0 + tid;
+                int pn = -1;
+                double v = 0.0;
+                if (k < ke) {
+                    pn = pn_b[k];
+                    const double d = dt_b[k];
+                    // log_duration: log((child - parent) / (Δtmax - (child - parent)))  src/impulses.jl:228
+                    v = (lognorm && pn >= 0) ? nhp_log(d / (a.dt_max - d)) : d;
+                }
+                s_pn[tid] = pn;
+                s_v[tid] = v;
+                __syncthreads();
+                const int nb = min(NHP_BLOCK, ke - k0);
+                for (int e = 0; e < nb; ++e) {
+                    const int pe = s_pn[e];
+                    const double ve = s_v[e];
+#pragma unroll
+                    for (int q = 0; q < STAT_PQ; ++q) {
+                        if (pe == p0 + tid + q * NHP_BLOCK) {
+                            if (pass == 0) { cnt[q] += 1.0; sx[q] = sx[q] + ve; }
+                            else { const double dlt = ve - mean[q]; sv[q] = sv[q] + dlt * dlt; }
+                        }
+                    }
+                }
+            }
+            if (pass == 0) {
+#pragma unroll
+                for (int q = 0; q < STAT_PQ; ++q) mean[q] = sx[q] / cnt[q];      // NaN when cnt == 0
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < STAT_PQ; ++q) {
+            const int p = p0 + tid + q * NHP_BLOCK;
+            if (p < N) {
+                const size_t k = (size_t)p + (size_t)c * N;
+                if (Mnm) Mnm[k] = cnt[q];
+                // exponential: fillna!(Xnm ./ Mnm, 0) (src/impulses.jl:95); logit-normal keeps NaN (:222)
+                if (Xnm) Xnm[k] = (!lognorm && cnt[q] == 0.0) ? 0.0 : mean[q];
+                if (Vnm && lognorm) Vnm[k] = sv[q];
+            }
+        }
+    }
+    // baseline-attributed events on c and events on c
+    double b = 0.0;
+    for (int k = kb + tid; k < ke; k += NHP_BLOCK) b += pn_b[k] < 0 ? 1.0 : 0.0;
+    b = nhp_block_sum(b, red);
+    if (tid == 0) {
+        if (cnt0) cnt0[c] = b;
+        if (Mn) Mn[c] = (double)(ke - kb);
+    }
+}
+
+extern "C" nhp_status nhp_cont_resample_parents(nhp_ctx *ctx, const nhp_cont_dataset *ds,
+                                                const nhp_cont_model *m, const double *u,
+                                                uint64_t seed, uint64_t step,
+                                                int64_t *parents, int64_t *parentnodes, nhp_cont_stats *stats)
+{
+    NHP_TRY(nhp_check_pair(ctx, ds, m));
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t M = (size_t)ds->M, N = (size_t)ds->N, NN = N * N, Mp = M ? M : 1;
+    // scratch layout (8-byte aligned blocks)
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_par = carve(8 * Mp), o_pno = carve(8 * Mp), o_pnb = carve(4 * Mp), o_dtb = carve(8 * Mp);
+    const size_t o_u = carve(u ? 8 * Mp : 8), o_err = carve(8);
+    const size_t o_cnt0 = carve(8 * N), o_Mn = carve(8 * N), o_Mnm = carve(8 * NN), o_X = carve(8 * NN), o_V = carve(8 * NN);
+    NHP_TRY(nhp_ctx_reserve_scratch(ctx, off));
+    char *base = (char *)ctx->d_scratch;
+    int64_t *d_par = (int64_t *)(base + o_par), *d_pno = (int64_t *)(base + o_pno);
+    int32_t *d_pnb = (int32_t *)(base + o_pnb);
+    double *d_dtb = (double *)(base + o_dtb), *d_u = u ? (double *)(base + o_u) : nullptr;
+    int *d_err = (int *)(base + o_err);
+    hipStream_t st = ctx->stream;
+    NHP_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(int), st));
+    if (u && M) NHP_HIP(ctx, hipMemcpyAsync(d_u, u, 8 * M, hipMemcpyHostToDevice, st));
+
+    nhp_cont_args a = nhp_make_args(ds, m);
+    const size_t per = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? 16 : 24;
+    const size_t lds = per * N;
+    if (lds > 64 * 1024) { nhp_set_error(ctx, "n_nodes = %d exceeds the 64 KiB LDS column budget", ds->N); return NHP_ENOTIMPL; }
+    dim3 grid((unsigned)ds->n_items);
+    if (m->impulse_kind == NHP_IMPULSE_EXPONENTIAL)
+        hipLaunchKernelGGL((k_sampler<NHP_IMPULSE_EXPONENTIAL>), grid, dim3(NHP_BLOCK), lds, st, a, d_u, seed, step,
+                           parents ? d_par : nullptr, parentnodes ? d_pno : nullptr, d_pnb, d_dtb, d_err);
+    else
+        hipLaunchKernelGGL((k_sampler<NHP_IMPULSE_LOGITNORMAL>), grid, dim3(NHP_BLOCK), lds, st, a, d_u, seed, step,
+                           parents ? d_par : nullptr, parentnodes ? d_pno : nullptr, d_pnb, d_dtb, d_err);
+    NHP_HIP(ctx, hipGetLastError());
+    int h_err = 0;
+    NHP_HIP(ctx, hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (stats) {
+        double *d_cnt0 = (double *)(base + o_cnt0), *d_Mn = (double *)(base + o_Mn), *d_Mnm = (double *)(base + o_Mnm);
+        double *d_X = (double *)(base + o_X), *d_V = (double *)(base + o_V);
+        hipLaunchKernelGGL(k_stats, dim3((unsigned)N), dim3(NHP_BLOCK), 0, st, a, d_pnb, d_dtb, d_cnt0, d_Mn, d_Mnm, d_X, d_V);
+        NHP_HIP(ctx, hipGetLastError());
+        if (stats->cnt0) NHP_HIP(ctx, hipMemcpyAsync(stats->cnt0, d_cnt0, 8 * N, hipMemcpyDeviceToHost, st));
+        if (stats->Mn) NHP_HIP(ctx, hipMemcpyAsync(stats->Mn, d_Mn, 8 * N, hipMemcpyDeviceToHost, st));
+        if (stats->Mnm) NHP_HIP(ctx, hipMemcpyAsync(stats->Mnm, d_Mnm, 8 * NN, hipMemcpyDeviceToHost, st));
+        if (stats->Xnm) NHP_HIP(ctx, hipMemcpyAsync(stats->Xnm, d_X, 8 * NN, hipMemcpyDeviceToHost, st));
+        if (stats->Vnm && m->impulse_kind == NHP_IMPULSE_LOGITNORMAL)
+            NHP_HIP(ctx, hipMemcpyAsync(stats->Vnm, d_V, 8 * NN, hipMemcpyDeviceToHost, st));
+    }
+    if (parents && M) NHP_HIP(ctx, hipMemcpyAsync(parents, d_par, 8 * M, hipMemcpyDeviceToHost, st));
+    if (parentnodes && M) NHP_HIP(ctx, hipMemcpyAsync(parentnodes, d_pno, 8 * M, hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipStreamSynchronize(st));
+    if (h_err) {
+        nhp_set_error(ctx, "resample_parents: weights of some event do not sum to a positive finite value");
+        return NHP_EDOMAIN;
+    }
+    return NHP_OK;
+}

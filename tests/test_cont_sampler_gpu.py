@@ -1,0 +1,134 @@
+"""GPU parity for the parent sampler (reference src/parents.jl:1-79) and its fused Gibbs
+statistics.  Parent indices must be BIT-EXACT against the oracle for a fixed uniform stream
+(BASELINE.json north_star); that holds by construction because kernel and oracle evaluate
+every weight with the same IEEE operation sequence -- checked bitwise first."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import random_case
+
+pytestmark = pytest.mark.gpu
+
+
+def probe(nhp, op, x, y=None):
+    from nhp_amd import _lib
+    ctx = nhp.default_context()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = None if y is None else np.ascontiguousarray(y, dtype=np.float64)
+    out = np.empty_like(x)
+    _lib.check(_lib.lib().nhp_probe_math(ctx.h, op, _lib.dptr(x), _lib.dptr(y), len(x), _lib.dptr(out)), ctx.h)
+    return out
+
+
+def test_det_math_is_bitwise_identical(nhp, orc):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-708.0, 0.0, 200_000), -np.exp(rng.uniform(-40, 6, 100_000)), [0.0, -708.0, -745.0, -1e300]])
+    lib = orc.lib()
+    want = np.array([lib.orc_det_exp(float(v)) for v in x])
+    assert np.array_equal(probe(nhp, 4, x).view(np.uint64), want.view(np.uint64))          # exp, x <= 0
+    assert np.array_equal(probe(nhp, 0, x).view(np.uint64), want.view(np.uint64))          # general exp
+    y = np.concatenate([np.exp(rng.uniform(-700, 700, 200_000)), rng.uniform(0.5, 2.0, 100_000), [1.0, 5e-324, 2.2e-308]])
+    want = np.array([lib.orc_det_log(float(v)) for v in y])
+    assert np.array_equal(probe(nhp, 1, y).view(np.uint64), want.view(np.uint64))
+    # IEEE sqrt and division are correctly rounded on both sides
+    assert np.array_equal(probe(nhp, 2, y).view(np.uint64), np.sqrt(y).view(np.uint64))
+    z = np.exp(rng.uniform(-300, 300, len(y)))
+    assert np.array_equal(probe(nhp, 3, y, z).view(np.uint64), (y / z).view(np.uint64))
+    # the two pair evaluators, det mode
+    th, dt = rng.uniform(0.1, 9.0, 100_000), rng.uniform(0.0, 3.0, 100_000)
+    want = np.array([lib.orc_impulse_exponential(float(a), float(b), 1) for a, b in zip(th, dt)])
+    assert np.array_equal(probe(nhp, 5, th, dt).view(np.uint64), want.view(np.uint64))
+    tau, dt = rng.uniform(0.3, 3.0, 100_000), rng.uniform(0.0, 2.0, 100_000)
+    want = np.array([lib.orc_impulse_logitnormal(0.25, float(a), 2.0, float(b), 1) for a, b in zip(tau, dt)])
+    assert np.array_equal(probe(nhp, 6, tau, dt).view(np.uint64), want.view(np.uint64))
+
+
+def test_uniform_stream_matches_oracle(nhp, orc):
+    for seed, step in ((0, 0), (1, 7), (2 ** 63 + 5, 2 ** 40 + 3)):
+        assert np.array_equal(nhp.uniform_stream(seed, step, 1000), orc.uniform_stream(seed, step, 1000))
+
+
+@pytest.mark.parametrize("kind", ["exponential", "logitnormal"])
+@pytest.mark.parametrize("network,lgcp", [(False, False), (True, False), (True, True)])
+def test_parents_bit_exact(nhp, orc, kind, network, lgcp):
+    c = random_case(8, 6000, 300.0, kind, 1.0, network=network, lgcp=lgcp, seed=4, nhp=nhp, orc=orc)
+    u = np.random.default_rng(99).uniform(size=6000)
+    got_p, got_n = nhp.resample_parents(c["proc"], c["data"], u=u)
+    want_p, want_n = orc.resample_parents(c["om"], c["times"], c["nodes"], u, flags=orc.MATH_DET)
+    assert np.array_equal(got_p, want_p)
+    assert np.array_equal(got_n, want_n)
+    assert got_p[0] == 0 and got_n[0] == 0                       # event 1 -> (0, 0)  src/parents.jl:26-28
+    # Philox stream generated inside the kernel == host-supplied stream
+    p2, n2 = nhp.resample_parents(c["proc"], c["data"], seed=11, step=3)
+    w2, wn2 = orc.resample_parents(c["om"], c["times"], c["nodes"], orc.uniform_stream(11, 3, 6000), flags=orc.MATH_DET)
+    assert np.array_equal(p2, w2) and np.array_equal(n2, wn2)
+    # libm-evaluated reference-faithful weights give the same indices on this stream
+    w3, _ = orc.resample_parents(c["om"], c["times"], c["nodes"], u, flags=orc.MATH_LIBM)
+    assert np.array_equal(got_p, w3)
+
+
+def test_pairwise_sum_for_windows_above_1024(nhp, orc):
+    # Δtmax = Inf: event i has i+1 weights; Julia's sum switches to midpoint-split pairwise above 1024
+    c = random_case(4, 5000, 50.0, "exponential", np.inf, seed=6, nhp=nhp, orc=orc)
+    u = np.random.default_rng(5).uniform(size=5000)
+    got_p, got_n = nhp.resample_parents(c["proc"], c["data"], u=u)
+    want_p, want_n = orc.resample_parents(c["om"], c["times"], c["nodes"], u, flags=orc.MATH_DET)
+    assert np.array_equal(got_p, want_p) and np.array_equal(got_n, want_n)
+
+
+def test_extreme_uniforms_and_empty_windows(nhp):
+    c = random_case(5, 3000, 100.0, "exponential", 2.0, seed=2, nhp=nhp)
+    M = 3000
+    p, n = nhp.resample_parents(c["proc"], c["data"], u=np.zeros(M))
+    # u = 0 picks the first entry: the most recent parent (i-1) whenever the window is not empty
+    t = c["times"]
+    has_parent = np.concatenate([[False], t[:-1] > t[1:] - 2.0])
+    idx = np.arange(M)
+    assert np.array_equal(p[has_parent], idx[has_parent])        # 1-based index of event i-1 is i
+    assert np.all(p[~has_parent] == 0)
+    p, n = nhp.resample_parents(c["proc"], c["data"], u=np.full(M, np.nextafter(1.0, 0.0)))
+    assert np.all(p == 0) and np.all(n == 0)                     # u -> 1-: the last entry, the baseline
+    c = random_case(5, 500, 1e6, "exponential", 1e-3, seed=3, nhp=nhp)     # every window empty
+    p, n = nhp.resample_parents(c["proc"], c["data"], seed=1)
+    assert np.all(p == 0) and np.all(n == 0)
+
+
+def test_sampling_frequencies_chi2(nhp):
+    # one child with 3 possible parents + baseline, replicated through the step counter
+    from oracle import mp_eval
+    from oracle import oracle as orc
+    c = random_case(3, 4, 1.0, "exponential", 10.0, seed=7, nhp=nhp, orc=orc)
+    probs = np.array([float(v) for v in mp_eval.parent_probabilities(c["om"], c["times"], c["nodes"], 3)])
+    counts = np.zeros(4)
+    R = 4000
+    for step in range(R):
+        p, _ = nhp.resample_parents(c["proc"], c["data"], seed=123, step=step)
+        counts[3 if p[3] == 0 else 3 - p[3]] += 1              # parent index 3,2,1 -> slot 0,1,2; baseline -> 3
+    chi2 = np.sum((counts - R * probs) ** 2 / (R * probs))
+    assert chi2 < 21.1                                           # χ²(3) at p = 1e-4
+
+
+@pytest.mark.parametrize("kind", ["exponential", "logitnormal"])
+def test_fused_statistics_match_reference_helpers(nhp, orc, kind):
+    N, M = 6, 8000
+    c = random_case(N, M, 400.0, kind, 1.5, network=True, seed=13, nhp=nhp, orc=orc)
+    p, pn, st = nhp.resample_parents(c["proc"], c["data"], seed=5, step=2, with_stats=True)
+    nodes, times = c["nodes"], c["times"]
+    assert np.array_equal(st["cnt0"], orc.baseline_node_counts(nodes, pn, N))
+    assert np.array_equal(st["Mn"], orc.node_counts(nodes, N))
+    assert np.array_equal(st["Mnm"], orc.parent_counts(nodes, pn, N))
+    assert st["Mnm"].sum() + st["cnt0"].sum() == M
+    if kind == "exponential":
+        # same accumulation order as the reference's serial loop -> identical bits
+        assert np.array_equal(st["Xnm"], orc.duration_mean(times, nodes, p, N))
+    else:
+        X, V = orc.log_duration_stats(times, nodes, p, N, 1.5)
+        assert np.array_equal(np.isnan(st["Xnm"]), np.isnan(X))
+        m = ~np.isnan(X)
+        assert np.allclose(st["Xnm"][m], X[m], rtol=1e-12, atol=1e-13)
+        assert np.allclose(st["Vnm"], V, rtol=1e-11, atol=1e-12)
+    # statistics only (no parent vectors copied back)
+    _, _, st2 = nhp.resample_parents(c["proc"], c["data"], seed=5, step=2, with_stats=True, want_parents=False)
+    assert np.array_equal(st2["Mnm"], st["Mnm"])
