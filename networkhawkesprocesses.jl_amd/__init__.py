@@ -13,4 +13,6 @@ from .continuous import (ContinuousNetworkHawkesProcess, ContinuousStandardHawke
                          DeviceDataset, device_dataset, intensity, loglikelihood,
                          loglikelihood_gradient, total_intensity)
 from .parents import node_counts, parent_counts, resample_parents, uniform_stream  # noqa: F401
+from .inference import (MarkovChainMonteCarlo, MaximumLikelihood, logprior, mcmc_, mle_,  # noqa: F401
+                        resample_)
 from . import synthetic  # noqa: F401

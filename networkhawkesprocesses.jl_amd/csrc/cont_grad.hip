@@ -1,0 +1,255 @@
+// Log-likelihood + analytic gradient in params! order [λ0; θ | μ; τ; W].
+//
+// The reference hands Optim no gradient (src/continuous.jl:190), so every BFGS gradient inside
+// mle! costs it 2P finite-difference objective calls (P = N + 2N²).  These kernels
+// produce the exact gradient in about two log-likelihood passes.  With g_i = 1/λ_i:
+//   ∂/∂λ0[c]  = -T + Σ_{i on c} g_i
+//   ∂/∂W[p,c] = -cnt[p]·mask[p,c] + a[p,c] Σ_{i on c} g_i Σ_{j∈win(i), n_j=p} ħ(Δt_ij)
+//   ∂/∂θ[p,c] =  a·w Σ_i g_i Σ_j ∂ħ/∂θ,      ∂ħ/∂θ = (1 - θΔ) e^{-θΔ}                (exponential)
+//   ∂ħ/∂μ = ħ·τ(ℓ-μ),  ∂ħ/∂τ = ħ·(1 - τ(ℓ-μ)²)/(2τ),  ℓ = logit(Δ/Δtmax)            (logit-normal)
+// Validated against central finite differences of the oracle's log-likelihood in tests/.
+//
+// Windowed form: pass A is the log-likelihood kernel itself, which also stores λ_i; pass B
+// revisits each child's window with g_i known and accumulates Σ g·ħ and Σ g·∂ħ per parent node
+// in LDS (the child's node c is fixed per workgroup, so the accumulators are a column), then
+// scales by the column's constants and adds the column into the gradient.
+// Recursive form: the column-state recursion of cont_recursive.hip, extended with the
+// derivative state R_pc(t) = Σ_j (t - t_j) e^{-θ(t - t_j)}:  ∂λ/∂θ[p,c] = a·w·(S - θR).
+#include "nhp_internal.h"
+#include "nhp_math.h"
+
+template <int G>
+__device__ __forceinline__ double ggroup_sum(double v)
+{
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// grad <- the parameter-independent terms: -T, 0, -cnt[p]·mask
+__global__ __launch_bounds__(256) void k_grad_init(nhp_cont_args a, int mask_integral, double *__restrict__ grad)
+{
+    const size_t N = (size_t)a.N, NN = N * N;
+    const size_t nimp = a.impulse_kind == NHP_IMPULSE_EXPONENTIAL ? NN : 2 * NN;
+    const size_t P = N + nimp + NN;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x) {
+        double v = 0.0;
+        if (i < N) {
+            v = -a.duration;
+        } else if (i >= N + nimp) {
+            const size_t k = i - N - nimp;
+            const double mk = (a.A && mask_integral) ? a.A[k] : 1.0;
+            v = -a.cnt[k % N] * mk;
+        }
+        grad[i] = v;
+    }
+}
+
+template <int IMP, int G>
+__global__ __launch_bounds__(NHP_BLOCK) void k_grad_windowed(nhp_cont_args a, const double *__restrict__ lambda,
+                                                             double *__restrict__ grad)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *red = reinterpret_cast<double *>(smem);
+    double2 *col = reinterpret_cast<double2 *>(smem + 32);       // exp {θ, -}; logit {μ, sqrt τ}
+    double *accH = reinterpret_cast<double *>(col + a.N);        // Σ g·ħ
+    double *acc1 = accH + a.N;                                   // Σ g·∂ħ/∂θ  |  Σ g·ħ·sqrtτ·z
+    double *acc2 = acc1 + a.N;                                   // logit: Σ g·ħ·(1 - z²)
+
+    const nhp_item it = a.items[blockIdx.x];
+    const int c = it.node, N = a.N, tid = threadIdx.x;
+    for (int p = tid; p < N; p += NHP_BLOCK) {
+        const size_t k = (size_t)p + (size_t)c * N;
+        if (IMP == NHP_IMPULSE_EXPONENTIAL) col[p] = make_double2(a.p1[k], 0.0);
+        else col[p] = make_double2(a.p1[k], __builtin_sqrt(a.p2[k]));
+        accH[p] = 0.0; acc1[p] = 0.0;
+        if (IMP != NHP_IMPULSE_EXPONENTIAL) acc2[p] = 0.0;
+    }
+    __syncthreads();
+
+    constexpr int GROUPS = NHP_BLOCK / G;
+    const int gid = tid / G, gl = tid % G;
+    double gsum = 0.0;
+    for (int k = it.kbeg + gid; k < it.kend; k += GROUPS) {
+        const nhp_child ch = a.child[k];
+        const double g = 1.0 / lambda[ch.idx];
+        if (gl == 0) gsum += g;
+        for (int j = ch.idx - 1 - gl; j >= ch.first; j -= G) {
+            const double dt = ch.t - a.times[j];
+            const int p = a.nodes[j];
+            const double2 q = col[p];
+            if (IMP == NHP_IMPULSE_EXPONENTIAL) {
+                const double e = nhp_exp_neg(-(q.x * dt));
+                atomicAdd(&accH[p], g * (q.x * e));
+                atomicAdd(&acc1[p], g * ((1.0 - q.x * dt) * e));
+            } else {
+                const double x = dt * a.inv_dtmax;
+                if (x > 0.0 && x < 1.0) {
+                    const double o = 1.0 - x, qq = 1.0 / (x * o);
+                    const double z = (nhp_log((x * x) * qq) - q.x) * q.y;
+                    const double h = (nhp_exp_neg(-0.5 * (z * z)) * (NHP_INVSQRT2PI * q.y)) * qq;
+                    atomicAdd(&accH[p], g * h);
+                    atomicAdd(&acc1[p], g * h * (q.y * z));
+                    atomicAdd(&acc2[p], g * h * (1.0 - z * z));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const size_t Nn = (size_t)N, NN = Nn * Nn;
+    const size_t nimp = IMP == NHP_IMPULSE_EXPONENTIAL ? NN : 2 * NN;
+    for (int p = tid; p < N; p += NHP_BLOCK) {
+        const size_t k = (size_t)p + (size_t)c * N;
+        const double av = a.A ? a.A[k] : 1.0;
+        const double aw = av * a.W[k];
+        if (accH[p] != 0.0) atomicAdd(&grad[Nn + nimp + k], av * accH[p]);
+        if (IMP == NHP_IMPULSE_EXPONENTIAL) {
+            if (acc1[p] != 0.0) atomicAdd(&grad[Nn + k], aw * acc1[p]);
+        } else {
+            if (acc1[p] != 0.0) atomicAdd(&grad[Nn + k], aw * acc1[p]);
+            if (acc2[p] != 0.0) atomicAdd(&grad[Nn + NN + k], aw * (0.5 / a.p2[k]) * acc2[p]);
+        }
+    }
+    const double gs = nhp_block_sum(gsum, red);
+    if (tid == 0 && gs != 0.0) atomicAdd(&grad[c], gs);
+}
+
+// ---- recursive exponential: ll and gradient in one pass ---------------------------------------
+#define GR_RING 64
+__global__ __launch_bounds__(NHP_BLOCK) void k_grad_recursive(nhp_cont_args a, double *__restrict__ partials,
+                                                              double *__restrict__ grad)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *red = reinterpret_cast<double *>(smem);              // [4]
+    double *wpart = red + 4;                                     // [NHP_WAVES]
+    double *th = wpart + NHP_WAVES;                              // θ[p,c]
+    double *wth = th + a.N;                                      // (a·w)·θ
+    double *S = wth + a.N, *R = S + a.N;                         // state and derivative state at the last child
+    double *nS = R + a.N, *nR = nS + a.N;                        // segment accumulators referenced to t_k
+    double *GS = nR + a.N, *GR = GS + a.N;                       // Σ_k g_k S_p(t_k), Σ_k g_k R_p(t_k)
+
+    const int c = blockIdx.x, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double integ = 0.0;
+    for (int p = tid; p < N; p += NHP_BLOCK) {
+        const size_t k = (size_t)p + (size_t)c * N;
+        const double w = a.W[k], weff = a.A ? a.A[k] * w : w, t = a.p1[k];
+        th[p] = t; wth[p] = weff * t;
+        S[p] = R[p] = nS[p] = nR[p] = GS[p] = GR[p] = 0.0;
+        integ += a.cnt[p] * w;
+    }
+    __syncthreads();
+    const int kb = a.boff[c], ke = a.boff[c + 1];
+    const double lam0 = a.lambda0[c];                            // homogeneous baseline only
+    int prev_idx = 0;
+    double prev_t = 0.0, logsum = 0.0, gsum = 0.0;
+    for (int k = kb; k < ke; ++k) {
+        const nhp_child ch = a.child[k];
+        for (int j = prev_idx + tid; j < ch.idx; j += NHP_BLOCK) {
+            const double tj = a.times[j];
+            if (tj > 0.0) {
+                const int p = a.nodes[j];
+                const double d = ch.t - tj;
+                const double e = nhp_exp_neg(-(th[p] * d));
+                atomicAdd(&nS[p], e);
+                atomicAdd(&nR[p], d * e);
+            }
+        }
+        __syncthreads();
+        const double gap = ch.t - prev_t;
+        double part = 0.0;
+        for (int p = tid; p < N; p += NHP_BLOCK) {
+            double s = S[p], r = R[p];
+            if (k != kb) {
+                const double dec = nhp_exp_neg(-(th[p] * gap));
+                r = dec * (r + gap * s);
+                s = dec * s;
+            }
+            s += nS[p]; r += nR[p];
+            nS[p] = 0.0; nR[p] = 0.0;
+            S[p] = s; R[p] = r;
+            part += wth[p] * s;
+        }
+        part = nhp_wave_sum(part);
+        if (lane == 0) wpart[wave] = part;
+        __syncthreads();
+        double lam = lam0;
+        for (int w = 0; w < NHP_WAVES; ++w) lam += wpart[w];
+        const double g = 1.0 / lam;
+        for (int p = tid; p < N; p += NHP_BLOCK) { GS[p] += g * S[p]; GR[p] += g * R[p]; }
+        if (tid == 0) { logsum += nhp_log(lam); gsum += g; }
+        prev_idx = ch.idx;
+        prev_t = ch.t;
+    }
+    __syncthreads();
+    const size_t Nn = (size_t)N, NN = Nn * Nn;
+    for (int p = tid; p < N; p += NHP_BLOCK) {
+        const size_t k = (size_t)p + (size_t)c * N;
+        const double av = a.A ? a.A[k] : 1.0, w = a.W[k], t = th[p];
+        grad[Nn + NN + k] = -a.cnt[p] + av * t * GS[p];          // unmasked integral (D7)
+        grad[Nn + k] = av * w * (GS[p] - t * GR[p]);
+    }
+    const double blk = nhp_block_sum(logsum, red);
+    const double blk_int = nhp_block_sum(integ, red);
+    if (tid == 0) {
+        partials[2 * (size_t)c] = blk;
+        partials[2 * (size_t)c + 1] = blk_int;
+        grad[c] = -a.duration + gsum;
+    }
+}
+
+template <int IMP>
+static void launch_grad_group(int G, dim3 grid, size_t lds, hipStream_t st, const nhp_cont_args &a,
+                              const double *lambda, double *grad)
+{
+#define NHP_CASE(g)                                                                                      \
+    case g:                                                                                              \
+        hipLaunchKernelGGL((k_grad_windowed<IMP, g>), grid, dim3(NHP_BLOCK), lds, st, a, lambda, grad);  \
+        break;
+    switch (G) {
+        NHP_CASE(1) NHP_CASE(2) NHP_CASE(4) NHP_CASE(8) NHP_CASE(16) NHP_CASE(32)
+    default:
+        hipLaunchKernelGGL((k_grad_windowed<IMP, 64>), grid, dim3(NHP_BLOCK), lds, st, a, lambda, grad);
+    }
+#undef NHP_CASE
+}
+
+extern "C" nhp_status nhp_cont_loglik_grad(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m,
+                                           int32_t flags, double *ll, double *grad, int64_t grad_len)
+{
+    NHP_TRY(nhp_check_pair(ctx, ds, m));
+    if (!ll || !grad) return NHP_EINVAL;
+    if (m->baseline_kind != NHP_BASELINE_HOMOGENEOUS) { nhp_set_error(ctx, "gradient: homogeneous baseline only"); return NHP_ENOTIMPL; }
+    const size_t N = (size_t)ds->N, NN = N * N;
+    const bool exp_imp = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
+    const size_t P = N + (exp_imp ? 2 : 3) * NN;
+    if ((size_t)grad_len != P) { nhp_set_error(ctx, "Parameter vector length does not match model parameter length."); return NHP_ESHAPE; }
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t M = (size_t)(ds->M > 0 ? ds->M : 1);
+    NHP_TRY(nhp_ctx_reserve_scratch(ctx, 8 * (P + M)));
+    double *d_grad = (double *)ctx->d_scratch, *d_lambda = d_grad + P;
+    nhp_cont_args a = nhp_make_args(ds, m);
+    hipStream_t st = ctx->stream;
+    if ((flags & NHP_LL_RECURSIVE) && exp_imp) {
+        const size_t lds = 8 * (4 + NHP_WAVES + 8 * N);
+        if (lds > 160 * 1024) { nhp_set_error(ctx, "recursive gradient: n_nodes = %d exceeds the LDS budget", ds->N); return NHP_ENOTIMPL; }
+        if (lds > 64 * 1024)
+            NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_grad_recursive, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * N));
+        hipLaunchKernelGGL(k_grad_recursive, dim3((unsigned)N), dim3(NHP_BLOCK), lds, st, a, ctx->d_partials, d_grad);
+        NHP_HIP(ctx, hipGetLastError());
+        NHP_TRY(nhp_launch_finalize(ctx, a, (int)N, ctx->d_results));
+    } else {
+        hipLaunchKernelGGL(k_grad_init, dim3(1024), dim3(256), 0, st, a, 1, d_grad);
+        NHP_HIP(ctx, hipGetLastError());
+        NHP_TRY(nhp_launch_event_intensity(ctx, ds, m, d_lambda));          // pass A: partials + λ_i
+        NHP_TRY(nhp_launch_finalize(ctx, a, ds->n_items, ctx->d_results));
+        const size_t lds = 32 + 16 * N + 8 * N * (exp_imp ? 2 : 3);
+        if (lds > 64 * 1024) { nhp_set_error(ctx, "gradient: n_nodes = %d exceeds the 64 KiB LDS budget", ds->N); return NHP_ENOTIMPL; }
+        dim3 grid((unsigned)ds->n_items);
+        if (exp_imp) launch_grad_group<NHP_IMPULSE_EXPONENTIAL>(ds->group, grid, lds, st, a, d_lambda, d_grad);
+        else launch_grad_group<NHP_IMPULSE_LOGITNORMAL>(ds->group, grid, lds, st, a, d_lambda, d_grad);
+        NHP_HIP(ctx, hipGetLastError());
+    }
+    NHP_HIP(ctx, hipMemcpyAsync(grad, d_grad, 8 * P, hipMemcpyDeviceToHost, st));
+    return nhp_ctx_fetch(ctx, 0, 1, ll);
+}

@@ -1,0 +1,167 @@
+"""Inference drivers: host mirror of src/inference.jl and of the mle! / resample! bodies in
+src/continuous.jl:144-208,350-358.  Every O(M·K̄) or O(M·N) loop runs on the GPU; what stays
+on the host is O(N²) bookkeeping and the conjugate random draws (out of scope).
+
+Result containers keep the reference's field names (src/inference.jl:6-12,24-29,78-83).
+"""
+import time
+
+import numpy as np
+from scipy import optimize
+from scipy.special import gammaln
+
+from . import _lib
+from .components import (ExponentialImpulseResponse, HomogeneousProcess, LogitNormalImpulseResponse)
+from .continuous import (ContinuousNetworkHawkesProcess, ContinuousStandardHawkesProcess,
+                         device_dataset, loglikelihood, loglikelihood_gradient)
+from .parents import resample_parents
+
+
+class MaximumLikelihood:
+    """src/inference.jl:6-12"""
+
+    def __init__(self, maximizer, maximum, steps, elapsed, status):
+        self.maximizer, self.maximum, self.steps, self.elapsed, self.status = maximizer, maximum, steps, elapsed, status
+
+    def __repr__(self):
+        return f"\n* Status: {self.status}\n    steps: {self.steps}\n    elapsed: {self.elapsed}\n    loss: {self.maximum}"
+
+
+class MarkovChainMonteCarlo:
+    """src/inference.jl:24-37"""
+
+    def __init__(self):
+        self.samples, self.steps, self.elapsed, self.status = [], 0, 0.0, "incomplete"
+
+    def __repr__(self):
+        return f"\n* Status: complete\n    steps: {self.steps}\n    elapsed: {self.elapsed}"
+
+
+# ---- log priors and their gradients (host, O(N²)) ---------------------------------------------
+def _gamma_logpdf(x, shape, rate):
+    return shape * np.log(rate) - gammaln(shape) + (shape - 1.0) * np.log(x) - rate * x
+
+
+def logprior(process):
+    """logprior(process) -- src/continuous.jl:278-284: Gamma(α0, 1/β0) on λ (src/baselines.jl:120-122),
+    Gamma(κ, 1/ν) on W (src/weights.jl:66-68), Gamma(α, 1/β) on θ (src/impulses.jl:110-112) or
+    normal-gamma on (μ, τ) (src/impulses.jl:254-259)."""
+    b, w, imp = process.baseline, process.weights, process.impulses
+    lp = np.sum(_gamma_logpdf(b.λ, b.α0, b.β0)) + np.sum(_gamma_logpdf(w.W, w.κ, w.ν))
+    if isinstance(imp, ExponentialImpulseResponse):
+        lp += np.sum(_gamma_logpdf(imp.θ, imp.α, imp.β))
+    else:
+        lp += np.sum(_gamma_logpdf(imp.τ, imp.α0, imp.β0))
+        prec = imp.κμ * imp.τ
+        lp += np.sum(0.5 * np.log(prec / (2 * np.pi)) - 0.5 * prec * (imp.μ - imp.μμ) ** 2)
+    return float(lp)
+
+
+def _logprior_gradient(process):
+    b, w, imp = process.baseline, process.weights, process.impulses
+    g = [(b.α0 - 1.0) / b.λ - b.β0]
+    if isinstance(imp, ExponentialImpulseResponse):
+        g.append(((imp.α - 1.0) / imp.θ - imp.β).ravel(order="F"))
+    else:
+        g.append((-imp.κμ * imp.τ * (imp.μ - imp.μμ)).ravel(order="F"))
+        g.append(((imp.α0 - 1.0) / imp.τ - imp.β0 + 0.5 / imp.τ - 0.5 * imp.κμ * (imp.μ - imp.μμ) ** 2).ravel(order="F"))
+    g.append(((w.κ - 1.0) / w.W - w.ν).ravel(order="F"))
+    return np.concatenate(g)
+
+
+def _rand_init_(process, rng):
+    """src/continuous.jl:200: rand(length(params(process)))"""
+    return rng.uniform(size=len(process.params()))
+
+
+def mle_(process, data, optimizer="L-BFGS-B", verbose=False, f_abstol=1e-6, regularize=False, guess=None,
+         recursive=True, seed=None, max_steps=1000, ctx=None):
+    """mle!(process, data; optimizer, verbose, f_abstol, regularize, guess) -- src/continuous.jl:144-198.
+
+    Same objective (-loglikelihood [- logprior]), same box [1e-6, 10] on every coordinate, same
+    random start and the same |f - f_prev| < f_abstol stopping rule; `process` is overwritten with
+    the estimate.  The reference runs Optim's Fminbox(BFGS) on finite differences (2P objective
+    calls per gradient); here a box-constrained quasi-Newton method (scipy L-BFGS-B) is fed the
+    analytic gradient computed on the GPU, so iterates differ while the optimum is the same."""
+    if not isinstance(process, ContinuousStandardHawkesProcess):
+        raise TypeError("mle! is defined for ContinuousStandardHawkesProcess (src/continuous.jl:144)")
+    ctx = ctx or _lib.default_context()
+    ds = device_dataset(process, data, ctx)
+    rng = np.random.default_rng(seed)
+    x0 = _rand_init_(process, rng) if guess is None else np.array(guess, dtype=np.float64)
+    lower, upper = 1e-6, 1e1
+    state = {"minloss": np.inf, "steps": 0, "converged": False, "last": None}
+    start = time.time()
+
+    def fg(x):
+        process.params_(x)
+        ll, g = loglikelihood_gradient(process, ds, recursive=recursive, ctx=ctx)
+        if regularize:
+            ll += logprior(process)
+            g = g + _logprior_gradient(process)
+        state["last"] = -ll
+        return -ll, -g
+
+    def status_update(xk):
+        state["steps"] += 1
+        value = state["last"]
+        if verbose:
+            print(f" > step: {state['steps']}, loss: {value}, elapsed: {time.time() - start}")
+        if abs(value - state["minloss"]) < f_abstol:
+            state["converged"] = True
+            raise StopIteration
+        state["minloss"] = value
+
+    res = optimize.minimize(fg, np.clip(x0, lower, upper), jac=True, method=optimizer,
+                            bounds=[(lower, upper)] * len(x0), callback=status_update,
+                            options={"maxiter": max_steps})
+    process.params_(res.x)
+    return MaximumLikelihood(res.x.copy(), -float(res.fun), state["steps"], time.time() - start,
+                             "success" if (state["converged"] or res.success) else "failure")
+
+
+def resample_(process, data, rng, step=0, seed=0, ctx=None):
+    """resample!(process, data) -- src/continuous.jl:202-208,350-358: one Gibbs sweep.
+
+    Parents and every sufficient statistic come from one GPU call; the conjugate draws are host
+    numpy.  For the network process the adjacency matrix is held fixed (its Gibbs update,
+    src/continuous.jl:444-519, is the first "next" row of SURVEY.md 8f) and only ρ is redrawn."""
+    _, _, st = resample_parents(process, data, seed=seed, step=step, with_stats=True, want_parents=False, ctx=ctx)
+    duration = data.duration if hasattr(data, "duration") else data[2]
+    process.baseline.resample_(st["cnt0"], duration, rng)
+    process.weights.resample_(st["Mn"], st["Mnm"], rng)
+    if isinstance(process.impulses, ExponentialImpulseResponse):
+        process.impulses.resample_(st["Mnm"], st["Xnm"], rng)
+    else:
+        process.impulses.resample_(st["Mnm"], st["Xnm"], st["Vnm"], rng)
+    if isinstance(process, ContinuousNetworkHawkesProcess):
+        process.network.resample_(process.adjacency_matrix, rng)
+    return process.params()
+
+
+def mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, keep_samples=True, ctx=None):
+    """mcmc!(process, data; nsteps, log_freq, verbose) -- src/inference.jl:49-70.
+
+    `seed` keys both the device-side Philox stream of the parent sampler (counter = step, event)
+    and the host generator of the conjugate draws, so a chain is reproducible and chains with
+    different seeds are independent (one per GPU: chains.py)."""
+    if not isinstance(process.baseline, HomogeneousProcess):
+        raise NotImplementedError("mcmc!: LGCP baseline resampling (src/baselines.jl:212-326) is out of scope")
+    ctx = ctx or _lib.default_context()
+    ds = device_dataset(process, data, ctx)
+    rng = np.random.default_rng(seed)
+    res = MarkovChainMonteCarlo()
+    start = time.time()
+    while res.steps < nsteps:
+        x = resample_(process, ds, rng, step=res.steps, seed=seed, ctx=ctx)
+        if keep_samples:
+            res.samples.append(x)
+        res.steps += 1
+        if res.steps % log_freq == 0 and verbose:
+            res.elapsed = time.time() - start
+            print(f" > step: {res.steps}, elapsed: {res.elapsed}")
+    res.elapsed = time.time() - start
+    res.status = "complete"
+    if not keep_samples:
+        res.samples.append(process.params())
+    return res

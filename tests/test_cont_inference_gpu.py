@@ -1,0 +1,105 @@
+"""GPU tests for intensity(process, data, times), the analytic gradient, mle! and mcmc!
+(reference: src/continuous.jl:76-96,144-208,350-358; src/inference.jl:49-70)."""
+import numpy as np
+import pytest
+
+from helpers import random_case, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind,network,lgcp", [("exponential", False, False), ("logitnormal", True, False),
+                                               ("exponential", True, True)])
+def test_intensity_matches_oracle(nhp, orc, kind, network, lgcp):
+    c = random_case(7, 1500, 80.0, kind, 1.5, network=network, lgcp=lgcp, seed=3, nhp=nhp, orc=orc)
+    q = np.concatenate([[0.0, 80.0], np.random.default_rng(1).uniform(0, 80, 300), c["times"][[5, 100, 1499]]])
+    got = nhp.intensity(c["proc"], c["data"], q)
+    want = orc.intensity(c["om"], c["times"], c["nodes"], q)
+    assert got.shape == (len(q), 7)
+    assert np.max(np.abs(got - want) / want) < 1e-12
+    one = nhp.intensity(c["proc"], c["data"], float(q[7]))          # scalar time -> length-N vector
+    assert one.shape == (7,) and np.array_equal(one, got[7])
+    if not lgcp:
+        with pytest.raises(nhp.DomainError):
+            nhp.intensity(c["proc"], c["data"], np.array([-1.0]))   # src/baselines.jl:111
+    else:
+        with pytest.raises(nhp.DomainError):
+            nhp.intensity(c["proc"], c["data"], np.array([80.5]))   # outside the interpolation support
+
+
+@pytest.mark.parametrize("kind,recursive,network", [("exponential", False, False), ("exponential", True, False),
+                                                    ("exponential", False, True), ("exponential", True, True),
+                                                    ("logitnormal", False, False), ("logitnormal", False, True)])
+def test_gradient_matches_oracle(nhp, orc, kind, recursive, network):
+    dtm = np.inf if recursive else 1.5
+    c = random_case(6, 2500, 150.0, kind, dtm, network=network, seed=17, nhp=nhp, orc=orc)
+    ll, g = nhp.loglikelihood_gradient(c["proc"], c["data"], recursive=recursive) if not network else \
+        _grad_network(nhp, c, recursive)
+    wll, wg = orc.loglik_grad(c["om"], c["times"], c["nodes"], c["T"], recursive=recursive)
+    assert rel(ll, wll) < 1e-11
+    assert np.max(np.abs(g - wg) / np.maximum(1.0, np.abs(wg))) < 1e-9
+
+
+def _grad_network(nhp, c, recursive):
+    # the network process has no params!/mle! in the reference (src/continuous.jl:325-333), but the
+    # kernels differentiate it all the same; P is the standard process's [λ0; θ|μ;τ; W]
+    import ctypes as C
+    from nhp_amd import _lib
+    proc = c["proc"]
+    ctx = nhp.default_context()
+    ds = nhp.device_dataset(proc, c["data"], ctx)
+    model = proc.device_model(ctx)
+    N = proc.ndims()
+    P = N + N * N * (2 if isinstance(proc.impulses, nhp.ExponentialImpulseResponse) else 3)
+    g = np.empty(P)
+    ll = C.c_double()
+    flags = _lib.LL_RECURSIVE if recursive else 0
+    _lib.check(_lib.lib().nhp_cont_loglik_grad(ctx.h, ds.h, model.h, flags, C.byref(ll), _lib.dptr(g), P), ctx.h)
+    return ll.value, g
+
+
+def test_mle_recovers_the_maximum(nhp, orc):
+    # C1-sized problem: N=2 README model, simulated by the branching sampler
+    proc, data = nhp.synthetic.readme_case(seed=1)
+    truth = proc.params().copy()
+    ll_truth = nhp.loglikelihood(proc, data)
+    res = nhp.mle_(proc, data, seed=0)
+    assert res.status == "success"
+    assert res.maximum >= ll_truth - 1e-6                  # the optimum beats the generating parameters
+    assert np.array_equal(proc.params(), res.maximizer)    # process overwritten in place
+    assert np.all(res.maximizer >= 1e-6) and np.all(res.maximizer <= 10.0)
+    # gradient ~ 0 at interior coordinates of the maximiser
+    _, g = nhp.loglikelihood_gradient(proc, data)
+    interior = (res.maximizer > 1e-5) & (res.maximizer < 9.99)
+    assert np.max(np.abs(g[interior])) < 5e-2 * max(1.0, abs(res.maximum)) ** 0.5
+    lam_hat = res.maximizer[:2]
+    assert np.all(np.abs(lam_hat - truth[:2]) < 0.25)      # baseline rates ≈ 1.0 with T = 1000
+    # regularised objective runs and returns a finite optimum
+    res2 = nhp.mle_(proc, data, regularize=True, guess=res.maximizer)
+    assert np.isfinite(res2.maximum)
+
+
+def test_mcmc_runs_and_is_reproducible(nhp):
+    c = random_case(4, 3000, 300.0, "logitnormal", 1.0, network=True, seed=23, nhp=nhp)
+    c2 = random_case(4, 3000, 300.0, "logitnormal", 1.0, network=True, seed=23, nhp=nhp)
+    r1 = nhp.mcmc_(c["proc"], c["data"], nsteps=25, seed=7)
+    r2 = nhp.mcmc_(c2["proc"], c2["data"], nsteps=25, seed=7)
+    assert r1.steps == 25 and len(r1.samples) == 25 and r1.status == "complete"
+    assert all(np.array_equal(a, b) for a, b in zip(r1.samples, r2.samples))   # same seed -> same chain
+    r3 = nhp.mcmc_(c2["proc"], c2["data"], nsteps=5, seed=8)
+    assert not np.array_equal(r3.samples[0], r1.samples[0])
+    assert len(r1.samples[0]) == 1 + 4 + 16 + 32 + 16                           # [ρ; λ0; W; μ; τ; vec(A)]
+    assert all(np.all(np.isfinite(s)) for s in r1.samples)
+
+
+def test_mcmc_posterior_concentrates(nhp):
+    # exponential standard process, data simulated from known parameters: posterior means land near them
+    lam0, W, th = np.array([0.8, 1.2]), np.array([[0.3, 0.1], [0.05, 0.25]]), np.full((2, 2), 2.0)
+    data = nhp.synthetic.branching_sample(lam0, W, th, 3000.0, seed=3)
+    proc = nhp.ContinuousStandardHawkesProcess(nhp.HomogeneousProcess(np.ones(2)),
+                                               nhp.ExponentialImpulseResponse(np.ones((2, 2)), 1.0, 1.0, 10.0),
+                                               nhp.DenseWeightModel(0.5 * np.ones((2, 2))))
+    res = nhp.mcmc_(proc, data, nsteps=300, seed=1)
+    post = np.mean(res.samples[100:], axis=0)
+    assert np.all(np.abs(post[:2] - lam0) < 0.12)
+    assert np.all(np.abs(post[6:].reshape((2, 2), order="F") - W) < 0.08)
