@@ -9,10 +9,34 @@ from ._lib import Context, DomainError, NhpError, default_context  # noqa: F401
 from .components import (BernoulliNetworkModel, DenseNetworkModel, DenseWeightModel,  # noqa: F401
                          ExponentialImpulseResponse, HomogeneousProcess, LogGaussianCoxProcess,
                          LogitNormalImpulseResponse)
-from .continuous import (ContinuousNetworkHawkesProcess, ContinuousStandardHawkesProcess,  # noqa: F401
-                         DeviceDataset, device_dataset, intensity, loglikelihood,
+from .continuous import (ContinuousHawkesProcess, ContinuousNetworkHawkesProcess,  # noqa: F401
+                         ContinuousStandardHawkesProcess, DeviceDataset, HawkesProcess, device_dataset,
                          loglikelihood_gradient, total_intensity)
+from . import continuous as _cont
+from .discrete import (DiscreteDataset, DiscreteGaussianImpulseResponse, DiscreteHawkesProcess,  # noqa: F401
+                       DiscreteHomogeneousProcess, DiscreteNetworkHawkesProcess,
+                       DiscreteStandardHawkesProcess, VariationalInference, convolve, update_, vb_)
+from . import discrete as _disc
 from .parents import node_counts, parent_counts, resample_parents, uniform_stream  # noqa: F401
 from .inference import (MarkovChainMonteCarlo, MaximumLikelihood, logprior, mcmc_, mle_,  # noqa: F401
                         resample_)
 from . import synthetic  # noqa: F401
+
+
+def loglikelihood(process, data, *args, **kwargs):
+    """loglikelihood(process, data; recursive=true) for continuous processes (src/continuous.jl:210,360);
+    loglikelihood(process, data[, convolved]) for discrete ones (src/discrete.jl:86-102)."""
+    if isinstance(process, DiscreteHawkesProcess):
+        return _disc.disc_loglikelihood(process, data, *args, **kwargs)
+    return _cont.loglikelihood(process, data, *args, **kwargs)
+
+
+def intensity(process, data, *args, **kwargs):
+    """intensity(process, data, times) for continuous processes (src/continuous.jl:76-96);
+    intensity(process, convolved) / intensity(process, data::Matrix) for discrete ones
+    (src/discrete.jl:115-131)."""
+    if isinstance(process, DiscreteHawkesProcess):
+        if isinstance(data, DiscreteDataset) and data.B:
+            return _disc.disc_intensity(process, convolved=data, **kwargs)
+        return _disc.disc_intensity(process, data, **kwargs)
+    return _cont.intensity(process, data, *args, **kwargs)

@@ -1,0 +1,574 @@
+// Discrete-time path: basis convolution, intensity / Poisson log-likelihood and the
+// mean-field VB step (reference: convolve src/discrete.jl:146-151; basis
+// src/impulses.jl:321-335; intensity src/discrete.jl:115-129 with bump :381-385,:511-516;
+// loglikelihood :91-102; update! :369-375 = update_parents src/parents.jl:136-177 + the three
+// component updates src/baselines.jl:444-456, src/weights.jl:70-97, src/impulses.jl:355-375).
+//
+// The reference's 4-deep scalar loop for λ and its T x N x (1+NB) responsibility array are one
+// dense contraction:  with k = (p,b),  G = Ŝ viewed as T x (N·B)  and  E[k,c] the per-link
+// factor,   Z = base ⊕ G·E   (GEMM-1, T x NB x N).  VB needs a second one,
+// Γ = E ⊙ (Gᵀ·R) with R = data/Z (GEMM-2, NB x T x N); `u` (1.68 TB at N=512, B=8, T=1e5) is
+// never formed.  This IS a dense GEMM, so it runs on the fp64 matrix cores
+// (v_mfma_f64_16x16x4_f64): 128x128 block tile, 4 waves as 2x2, 64x64 per wave = 4x4 MFMA tiles
+// (64 fp64 accumulators per lane), BK = 16 staged through padded LDS images that make every
+// fragment read conflict-free, next tile prefetched into registers during the MFMAs.
+#include <math.h>
+
+#include <algorithm>
+
+#include "nhp_internal.h"
+#include "nhp_math.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+#define BM 128
+#define BN 128
+#define BK 16
+#define A_MC_LD (BM + 16)     // m-contiguous image: row stride ≡ 128 B (mod 256) -> kk rows hit disjoint banks
+#define KC_LD (BK + 1)        // k-contiguous image: 136-B rows -> 16 lanes x 2 kk conflict-free
+
+enum { EPI_INTENSITY = 0, EPI_LOGLIK = 1, EPI_VB_Z = 2, EPI_SLAB = 3 };
+
+struct gemm_args {
+    const double *A; size_t lda;
+    const double *B; size_t ldb;
+    int M, N;                 // output shape
+    int K;                    // reduction length
+    int k_chunk;              // reduction elements per grid.z slice
+    // epilogue operands
+    const double *base;       // [N]   additive per-column term (λ0·dt or e0)
+    const double *dataT;      // [M x N] counts as f64, t fastest
+    double *out;              // EPI_INTENSITY: λ [M x N]; EPI_VB_Z: R [M x N]; EPI_SLAB: slabs [z][M x N]
+    double *partials;         // EPI_LOGLIK: [2 * blocks]; EPI_VB_Z: column partials [rowBlocks][N]
+};
+
+// C[m,n] = Σ_k Aop[m,k]·B[k + n·ldb];  A_MCONTIG: Aop[m,k] = A[m + k·lda], else A[k + m·lda].
+template <bool A_MCONTIG, int EPI>
+__global__ __launch_bounds__(256) void k_gemm_f64(gemm_args g)
+{
+    __shared__ double As[A_MCONTIG ? BK * A_MC_LD : BM * KC_LD];
+    __shared__ double Bs[BN * KC_LD];
+    __shared__ double red[NHP_WAVES];
+    __shared__ double wcol[NHP_WAVES][64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, kk = lane >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;   // n-blocks fastest: tiles sharing an A panel are adjacent
+    const int kbeg = blockIdx.z * g.k_chunk;
+    const int kend = min(g.K, kbeg + g.k_chunk);
+
+    v4d acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    // per-thread staging coordinates: 8 consecutive elements along the contiguous dimension
+    const int a_k = A_MCONTIG ? tid >> 4 : (tid & 1) * 8;          // m-contig: k row;  k-contig: k offset
+    const int a_m = A_MCONTIG ? (tid & 15) * 8 : tid >> 1;         // m-contig: m offset; k-contig: m row
+    const int b_k = (tid & 1) * 8, b_n = tid >> 1;
+    double ra[8], rb[8];
+
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (A_MCONTIG) {
+                const int m = m0 + a_m + e, k = k0 + a_k;
+                ra[e] = (m < g.M && k < kend) ? g.A[(size_t)m + (size_t)k * g.lda] : 0.0;
+            } else {
+                const int m = m0 + a_m, k = k0 + a_k + e;
+                ra[e] = (m < g.M && k < kend) ? g.A[(size_t)k + (size_t)m * g.lda] : 0.0;
+            }
+            const int n = n0 + b_n, k = k0 + b_k + e;
+            rb[e] = (n < g.N && k < kend) ? g.B[(size_t)k + (size_t)n * g.ldb] : 0.0;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (A_MCONTIG) As[a_k * A_MC_LD + a_m + e] = ra[e];
+            else As[a_m * KC_LD + a_k + e] = ra[e];
+            Bs[b_n * KC_LD + b_k + e] = rb[e];
+        }
+    };
+
+    load_tiles(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();                       // previous tile fully consumed
+        store_tiles();
+        __syncthreads();
+        if (k0 + BK < kend) load_tiles(k0 + BK);   // prefetch under the MFMAs
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = wm * 64 + i * 16 + r16;
+                a[i] = A_MCONTIG ? As[(ks * 4 + kk) * A_MC_LD + m] : As[m * KC_LD + ks * 4 + kk];
+                const int n = wn * 64 + i * 16 + r16;
+                b[i] = Bs[n * KC_LD + ks * 4 + kk];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue.  acc[i][j][r] is C[row, col], row = wm*64 + i*16 + kk + 4r, col = wn*64 + j*16 + r16
+    double t_sum = 0.0, t_sum2 = 0.0;
+    double colp[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + r16;
+        const double base = (EPI != EPI_SLAB && col < g.N) ? g.base[col] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + i * 16 + kk + 4 * r;
+                if (row < g.M && col < g.N) {
+                    const size_t o = (size_t)row + (size_t)col * g.M;
+                    const double v = acc[i][j][r];
+                    if (EPI == EPI_INTENSITY) {
+                        g.out[o] = base + v;
+                    } else if (EPI == EPI_LOGLIK) {
+                        // log pdf(Poisson(λ), s) = xlogy(s, λ) - λ - loggamma(s+1); the data-only
+                        // Σ loggamma(s+1) is hoisted to the host
+                        const double lam = base + v, s = g.dataT[o];
+                        t_sum += (s == 0.0 ? 0.0 : s * nhp_log(lam));
+                        t_sum2 += lam;
+                    } else if (EPI == EPI_VB_Z) {
+                        const double rr = g.dataT[o] / (base + v);
+                        g.out[o] = rr;
+                        colp[j] += rr;
+                    } else {
+                        g.out[(size_t)blockIdx.z * (size_t)g.M * g.N + o] = v;
+                    }
+                }
+            }
+    }
+    if (EPI == EPI_LOGLIK) {
+        const double s1 = nhp_block_sum(t_sum, red);
+        const double s2 = nhp_block_sum(t_sum2, red);
+        if (tid == 0) {
+            const size_t b = (size_t)blockIdx.x + (size_t)blockIdx.y * gridDim.x;
+            g.partials[2 * b] = s1;
+            g.partials[2 * b + 1] = s2;
+        }
+    }
+    if (EPI == EPI_VB_Z) {
+        // deterministic column sums: lanes sharing r16 -> wave partial -> the two row-waves
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double v = colp[j];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (kk == 0) wcol[wave][j * 16 + r16] = v;
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int wn2 = tid >> 6, cl = tid & 63, col = n0 + tid;
+            if (col < g.N) g.partials[(size_t)blockIdx.y * g.N + col] = wcol[wn2][cl] + wcol[2 + wn2][cl];
+        }
+    }
+}
+
+// ---- small kernels ----------------------------------------------------------------------------
+
+// data (N x T, node fastest, Int64) -> dataT (T x N, t fastest, f64) + per-node event totals
+__global__ __launch_bounds__(256) void k_disc_transpose(const int64_t *__restrict__ data, int N, int64_t T,
+                                                        double *__restrict__ dataT)
+{
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t t0 = (int64_t)blockIdx.x * 32;
+    const int n0 = blockIdx.y * 32;
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + tx;
+        const int64_t t = t0 + r;
+        if (n < N && t < T) tile[r][tx] = (double)data[(size_t)n + (size_t)t * N];
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r;
+        const int64_t t = t0 + tx;
+        if (n < N && t < T) dataT[(size_t)t + (size_t)n * T] = tile[tx][r];
+    }
+}
+
+// per-node Σ_t data[n,t]  and  Σ_t loggamma(data[n,t] + 1)  -> out[n], out[N + n]
+__global__ __launch_bounds__(256) void k_disc_colstats(const double *__restrict__ dataT, int N, int64_t T,
+                                                       double *__restrict__ out)
+{
+    __shared__ double red[NHP_WAVES];
+    const int n = blockIdx.x;
+    double s = 0.0, lg = 0.0;
+    for (int64_t t = threadIdx.x; t < T; t += 256) {
+        const double v = dataT[(size_t)t + (size_t)n * T];
+        s += v;
+        if (v > 1.0) lg += lgamma(v + 1.0);
+    }
+    s = nhp_block_sum(s, red);
+    lg = nhp_block_sum(lg, red);
+    if (threadIdx.x == 0) { out[n] = s; out[N + n] = lg; }
+}
+
+// Ŝ[t,n,b] = max(0, Σ_{l=1..min(L,t)} data[n,t-l]·ϕ_b[l])   (0-based t; lag 0 excluded by the
+// prepended 0.0 of the reference's conv kernel; direct form = the exact value its FFT approximates)
+__global__ __launch_bounds__(256) void k_disc_convolve(const double *__restrict__ dataT, int N, int64_t T,
+                                                       const double *__restrict__ phi, int L,
+                                                       double *__restrict__ conv)
+{
+#pragma clang fp contract(off)
+    extern __shared__ double sphi[];
+    const int b = blockIdx.z, n = blockIdx.y;
+    for (int l = threadIdx.x; l < L; l += 256) sphi[l] = phi[l + (size_t)b * L];
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const double *d = dataT + (size_t)n * T;
+    const int lmax = (int)(t < L ? t : L);
+    double s = 0.0;
+    for (int l = 1; l <= lmax; ++l) s = s + d[t - l] * sphi[l - 1];
+    conv[(size_t)t + (size_t)n * T + (size_t)b * T * N] = s > 0.0 ? s : 0.0;
+}
+
+// E[k + c·K], k = p + b·N:  bump = ((a·)w·θ)·dt   (src/discrete.jl:381-385,511-516);  base[c] = λ0[c]·dt
+__global__ __launch_bounds__(256) void k_disc_bump(int N, int B, double dt, const double *__restrict__ lambda0,
+                                                   const double *__restrict__ W, const double *__restrict__ theta,
+                                                   const double *__restrict__ A, double *__restrict__ E,
+                                                   double *__restrict__ base)
+{
+#pragma clang fp contract(off)
+    const size_t NN = (size_t)N * N, K = (size_t)N * B;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < NN * B) {
+        const size_t b = i / NN, pc = i % NN, p = pc % N, c = pc / N;
+        const double w = A ? A[pc] * W[pc] : W[pc];
+        E[p + b * N + c * K] = (w * theta[i]) * dt;
+    }
+    if (i < (size_t)N) base[i] = lambda0[i] * dt;
+}
+
+// [3P] SpecialFunctions.digamma, x > 0: recurrence to x >= 10 then the asymptotic series
+__device__ __forceinline__ double nhp_digamma(double x)
+{
+    double r = 0.0;
+    while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+    const double f = 1.0 / (x * x);
+    const double t = f * (-1.0 / 12.0 + f * (1.0 / 120.0 + f * (-1.0 / 252.0 + f * (1.0 / 240.0 +
+                     f * (-1.0 / 132.0 + f * (691.0 / 32760.0 + f * (-1.0 / 12.0)))))));
+    return r + nhp_log(x) - 0.5 / x + t;
+}
+
+// VB factors from the OLD variational parameters (src/parents.jl:169-177):
+// E[k + c·K] = exp(ψ(γv[p,c,b]) - ψ(Σ_b γv[p,c,·]) + ψ(κv[p,c]) - log νv[p,c]);  e0[c] = exp(ψ(αv) - log βv)
+__global__ __launch_bounds__(256) void k_vb_factors(int N, int B, const double *__restrict__ alpha_v,
+                                                    const double *__restrict__ beta_v,
+                                                    const double *__restrict__ kappa_v,
+                                                    const double *__restrict__ nu_v,
+                                                    const double *__restrict__ gamma_v,
+                                                    double *__restrict__ E, double *__restrict__ e0)
+{
+    const size_t NN = (size_t)N * N, K = (size_t)N * B;
+    const size_t pc = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (pc < NN) {
+        const size_t p = pc % N, c = pc / N;
+        double gs = 0.0;
+        for (int b = 0; b < B; ++b) gs += gamma_v[pc + (size_t)b * NN];
+        const double elw = nhp_digamma(kappa_v[pc]) - nhp_log(nu_v[pc]);
+        const double dgs = nhp_digamma(gs);
+        for (int b = 0; b < B; ++b) {
+            const double elt = nhp_digamma(gamma_v[pc + (size_t)b * NN]) - dgs;
+            E[p + (size_t)b * N + c * K] = nhp_exp(elt + elw);
+        }
+    }
+    if (pc < (size_t)N) e0[pc] = nhp_exp(nhp_digamma(alpha_v[pc]) - nhp_log(beta_v[pc]));
+}
+
+// After GEMM-2: Γ = E ⊙ Σ_z slab_z;  γv = γ + Γ,  κv = κ + Σ_b Γ,  νv[p,c] = ν + Σ_t data[p,t]
+__global__ __launch_bounds__(256) void k_vb_finish(int N, int B, int n_slabs, const double *__restrict__ slabs,
+                                                   const double *__restrict__ E, const double *__restrict__ colsum,
+                                                   double kappa, double nu, double gamma,
+                                                   double *__restrict__ kappa_v, double *__restrict__ nu_v,
+                                                   double *__restrict__ gamma_v)
+{
+    const size_t NN = (size_t)N * N, K = (size_t)N * B;
+    const size_t pc = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (pc >= NN) return;
+    const size_t p = pc % N, c = pc / N;
+    double ksum = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const size_t o = p + (size_t)b * N + c * K;
+        double s = 0.0;
+        for (int z = 0; z < n_slabs; ++z) s += slabs[(size_t)z * K * N + o];
+        const double G = E[o] * s;
+        gamma_v[pc + (size_t)b * NN] = gamma + G;
+        ksum += G;
+    }
+    kappa_v[pc] = kappa + ksum;
+    nu_v[pc] = nu + colsum[p];
+}
+
+// αv[c] = α0 + e0[c]·Σ_t R[t,c];  βv[c] = 1/β0 + T·dt  (src/baselines.jl:444-452, D14 literal)
+__global__ __launch_bounds__(256) void k_vb_baseline(int N, int row_blocks, const double *__restrict__ colpart,
+                                                     const double *__restrict__ e0, double alpha0, double beta0,
+                                                     double Tdt, double *__restrict__ alpha_v, double *__restrict__ beta_v)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    double s = 0.0;
+    for (int r = 0; r < row_blocks; ++r) s += colpart[(size_t)r * N + c];
+    alpha_v[c] = alpha0 + e0[c] * s;
+    beta_v[c] = 1.0 / beta0 + Tdt;
+}
+
+__global__ __launch_bounds__(256) void k_sum_pairs(const double *__restrict__ partials, int n, double lg_const,
+                                                   double *__restrict__ out)
+{
+    __shared__ double red[NHP_WAVES];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { a += partials[2 * (size_t)i]; b += partials[2 * (size_t)i + 1]; }
+    a = nhp_block_sum(a, red);
+    b = nhp_block_sum(b, red);
+    if (threadIdx.x == 0) *out = a - b - lg_const;
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+
+extern "C" nhp_status nhp_disc_basis(int32_t L, int32_t B, double dt, double *phi)
+{
+    // basis(impulse): src/impulses.jl:321-335 (the exponent parses as -d²/(4σ))
+    if (L < 1 || B < 1 || !phi) return NHP_EINVAL;
+    const double sigma = (double)L / (double)(B - 1);
+    const double coef = ((-1.0 / 2.0) * (1.0 / sigma)) / 2.0;
+    for (int b = 0; b < B; ++b) {
+        const int len = (B < L) ? B + 2 : B, i = (B < L) ? b + 1 : b;
+        const double tt = (double)i / (double)(len > 1 ? len - 1 : 1);
+        const double mu = (1.0 - tt) * 1.0 + tt * (double)L;
+        double s = 0.0;
+        for (int l = 0; l < L; ++l) {
+            const double d = (double)(l + 1) - mu;
+            phi[l + (size_t)b * L] = exp(coef * (d * d));
+            s += phi[l + (size_t)b * L];
+        }
+        for (int l = 0; l < L; ++l) phi[l + (size_t)b * L] /= (s * dt);
+    }
+    return NHP_OK;
+}
+
+extern "C" nhp_status nhp_disc_dataset_create(nhp_ctx *ctx, const int64_t *data, int32_t N, int64_t T,
+                                              nhp_disc_dataset **out)
+{
+    if (!ctx || !out || !data || N < 1 || T < 1) return NHP_EINVAL;
+    *out = nullptr;
+    if (T >= ((int64_t)1 << 31) - BM) { nhp_set_error(ctx, "n_bins must be < 2^31"); return NHP_EINVAL; }
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    nhp_disc_dataset *ds = new nhp_disc_dataset();
+    ds->ctx = ctx; ds->N = N; ds->T = T;
+    const size_t NT = (size_t)N * (size_t)T;
+    int64_t *d_raw = nullptr;
+    hipStream_t st = ctx->stream;
+    hipError_t e;
+    if ((e = hipMalloc(&d_raw, 8 * NT)) != hipSuccess || (e = hipMalloc(&ds->d_dataT, 8 * NT)) != hipSuccess ||
+        (e = hipMalloc(&ds->d_colsum, 8 * 2 * (size_t)N)) != hipSuccess) {
+        nhp_set_error(ctx, "hipMalloc failed: %s", hipGetErrorString(e));
+        if (d_raw) (void)hipFree(d_raw);
+        nhp_disc_dataset_destroy(ds);
+        return NHP_ENOMEM;
+    }
+    NHP_HIP(ctx, hipMemcpyAsync(d_raw, data, 8 * NT, hipMemcpyHostToDevice, st));
+    dim3 tg((unsigned)((T + 31) / 32), (unsigned)((N + 31) / 32));
+    hipLaunchKernelGGL(k_disc_transpose, tg, dim3(256), 0, st, d_raw, N, T, ds->d_dataT);
+    hipLaunchKernelGGL(k_disc_colstats, dim3((unsigned)N), dim3(256), 0, st, ds->d_dataT, N, T, ds->d_colsum);
+    NHP_HIP(ctx, hipGetLastError());
+    std::vector<double> h(2 * (size_t)N);
+    NHP_HIP(ctx, hipMemcpyAsync(h.data(), ds->d_colsum, 8 * 2 * (size_t)N, hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipStreamSynchronize(st));
+    (void)hipFree(d_raw);
+    ds->lgamma_sum = 0.0;
+    for (int n = 0; n < N; ++n) {
+        ds->lgamma_sum += h[(size_t)N + n];
+        if (h[n] < 0.0) { nhp_set_error(ctx, "counts must be non-negative"); nhp_disc_dataset_destroy(ds); return NHP_EDOMAIN; }
+    }
+    *out = ds;
+    return NHP_OK;
+}
+
+extern "C" void nhp_disc_dataset_destroy(nhp_disc_dataset *ds)
+{
+    if (!ds) return;
+    (void)hipSetDevice(ds->ctx->device);
+    (void)hipStreamSynchronize(ds->ctx->stream);
+    (void)hipFree(ds->d_dataT); (void)hipFree(ds->d_conv); (void)hipFree(ds->d_colsum);
+    delete ds;
+}
+
+extern "C" nhp_status nhp_disc_convolve(nhp_ctx *ctx, nhp_disc_dataset *ds, const double *phi, int32_t L,
+                                        int32_t B, double *out)
+{
+    if (!ctx || !ds || !phi || L < 1 || B < 1) return NHP_EINVAL;
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t TNB = (size_t)ds->T * ds->N * B;
+    hipStream_t st = ctx->stream;
+    if (ds->B != B || !ds->d_conv) {
+        NHP_HIP(ctx, hipStreamSynchronize(st));
+        if (ds->d_conv) (void)hipFree(ds->d_conv);
+        ds->d_conv = nullptr;
+        if (hipMalloc(&ds->d_conv, 8 * TNB) != hipSuccess) { nhp_set_error(ctx, "out of device memory for the %zu-byte convolution", 8 * TNB); return NHP_ENOMEM; }
+    }
+    ds->B = B; ds->L = L;
+    NHP_TRY(nhp_ctx_reserve_scratch(ctx, 8 * (size_t)L * B));
+    double *d_phi = (double *)ctx->d_scratch;
+    NHP_HIP(ctx, hipMemcpyAsync(d_phi, phi, 8 * (size_t)L * B, hipMemcpyHostToDevice, st));
+    dim3 grid((unsigned)((ds->T + 255) / 256), (unsigned)ds->N, (unsigned)B);
+    hipLaunchKernelGGL(k_disc_convolve, grid, dim3(256), 8 * (size_t)L, st, ds->d_dataT, ds->N, ds->T, d_phi, L, ds->d_conv);
+    NHP_HIP(ctx, hipGetLastError());
+    if (out) NHP_HIP(ctx, hipMemcpyAsync(out, ds->d_conv, 8 * TNB, hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipStreamSynchronize(st));
+    return NHP_OK;
+}
+
+template <bool AMC, int EPI>
+static void launch_gemm(const gemm_args &g, int splits, hipStream_t st)
+{
+    dim3 grid((unsigned)((g.N + BN - 1) / BN), (unsigned)((g.M + BM - 1) / BM), (unsigned)splits);
+    hipLaunchKernelGGL((k_gemm_f64<AMC, EPI>), grid, dim3(256), 0, st, g);
+}
+
+// uploads the model pieces, builds E and base on the device; returns pointers into scratch
+static nhp_status stage_bump(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0, const double *W,
+                             const double *theta, const double *A, double dt, double **E, double **base, size_t extra,
+                             double **extra_ptr)
+{
+    if (!ds->d_conv) { nhp_set_error(ctx, "convolve(process, data) must run before intensity / loglikelihood"); return NHP_EINVAL; }
+    if (!lambda0 || !W || !theta) return NHP_EINVAL;
+    const size_t N = (size_t)ds->N, NN = N * N, B = (size_t)ds->B, K = N * B;
+    const size_t need = 8 * (K * N + N + N + NN + NN * B + NN + extra);
+    NHP_TRY(nhp_ctx_reserve_scratch(ctx, need));
+    double *p = (double *)ctx->d_scratch;
+    double *dE = p; p += K * N;
+    double *dbase = p; p += N;
+    double *dl0 = p; p += N;
+    double *dW = p; p += NN;
+    double *dth = p; p += NN * B;
+    double *dA = p; p += NN;
+    *extra_ptr = p;
+    hipStream_t st = ctx->stream;
+    NHP_HIP(ctx, hipMemcpyAsync(dl0, lambda0, 8 * N, hipMemcpyHostToDevice, st));
+    NHP_HIP(ctx, hipMemcpyAsync(dW, W, 8 * NN, hipMemcpyHostToDevice, st));
+    NHP_HIP(ctx, hipMemcpyAsync(dth, theta, 8 * NN * B, hipMemcpyHostToDevice, st));
+    if (A) NHP_HIP(ctx, hipMemcpyAsync(dA, A, 8 * NN, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_disc_bump, dim3((unsigned)((NN * B + 255) / 256)), dim3(256), 0, st, (int)N, (int)B, dt, dl0, dW,
+                       dth, A ? dA : nullptr, dE, dbase);
+    NHP_HIP(ctx, hipGetLastError());
+    *E = dE; *base = dbase;
+    return NHP_OK;
+}
+
+extern "C" nhp_status nhp_disc_intensity(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
+                                         const double *W, const double *theta, const double *A, double dt,
+                                         double *lam)
+{
+    if (!ctx || !ds || !lam) return NHP_EINVAL;
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t TN = (size_t)ds->T * ds->N;
+    double *E, *base, *dlam;
+    NHP_TRY(stage_bump(ctx, ds, lambda0, W, theta, A, dt, &E, &base, TN, &dlam));
+    gemm_args g{};
+    g.A = ds->d_conv; g.lda = (size_t)ds->T; g.B = E; g.ldb = (size_t)ds->N * ds->B;
+    g.M = (int)ds->T; g.N = ds->N; g.K = ds->N * ds->B; g.k_chunk = g.K;
+    g.base = base; g.out = dlam;
+    launch_gemm<true, EPI_INTENSITY>(g, 1, ctx->stream);
+    NHP_HIP(ctx, hipGetLastError());
+    NHP_HIP(ctx, hipMemcpyAsync(lam, dlam, 8 * TN, hipMemcpyDeviceToHost, ctx->stream));
+    NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NHP_OK;
+}
+
+extern "C" nhp_status nhp_disc_loglik(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
+                                      const double *W, const double *theta, const double *A, double dt, double *ll)
+{
+    if (!ctx || !ds || !ll) return NHP_EINVAL;
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    double *E, *base, *unused;
+    NHP_TRY(stage_bump(ctx, ds, lambda0, W, theta, A, dt, &E, &base, 0, &unused));
+    gemm_args g{};
+    g.A = ds->d_conv; g.lda = (size_t)ds->T; g.B = E; g.ldb = (size_t)ds->N * ds->B;
+    g.M = (int)ds->T; g.N = ds->N; g.K = ds->N * ds->B; g.k_chunk = g.K;
+    g.base = base; g.dataT = ds->d_dataT;
+    const int blocks = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)blocks));
+    g.partials = ctx->d_partials;
+    launch_gemm<true, EPI_LOGLIK>(g, 1, ctx->stream);
+    NHP_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_sum_pairs, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, blocks, ds->lgamma_sum, ctx->d_results);
+    NHP_HIP(ctx, hipGetLastError());
+    return nhp_ctx_fetch(ctx, 0, 1, ll);
+}
+
+extern "C" nhp_status nhp_disc_vb_step(nhp_ctx *ctx, const nhp_disc_dataset *ds, double dt,
+                                       double alpha0, double beta0, double kappa, double nu, double gamma,
+                                       double *alpha_v, double *beta_v, double *kappa_v, double *nu_v, double *gamma_v)
+{
+    if (!ctx || !ds || !alpha_v || !beta_v || !kappa_v || !nu_v || !gamma_v) return NHP_EINVAL;
+    if (!ds->d_conv) { nhp_set_error(ctx, "convolve(process, data) must run before update!"); return NHP_EINVAL; }
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t N = (size_t)ds->N, NN = N * N, B = (size_t)ds->B, K = N * B, T = (size_t)ds->T;
+    const int row_blocks = (int)((T + BM - 1) / BM);
+    // split the T-long reduction of GEMM-2 so that the grid fills the chip
+    const int tiles2 = (int)(((K + BM - 1) / BM) * ((N + BN - 1) / BN));
+    int splits = (2 * ctx->cu_count + tiles2 - 1) / tiles2;
+    splits = std::max(1, std::min(splits, (int)((T + 4 * BK - 1) / (4 * BK))));
+    int k_chunk = (int)((T + splits - 1) / splits);
+    k_chunk = ((k_chunk + BK - 1) / BK) * BK;
+    splits = (int)((T + k_chunk - 1) / k_chunk);
+    const size_t need = 8 * (K * N + N + N + N + NN + NN + NN * B + T * N + (size_t)row_blocks * N + (size_t)splits * K * N);
+    NHP_TRY(nhp_ctx_reserve_scratch(ctx, need));
+    double *p = (double *)ctx->d_scratch;
+    double *dE = p; p += K * N;
+    double *de0 = p; p += N;
+    double *dav = p; p += N;
+    double *dbv = p; p += N;
+    double *dkv = p; p += NN;
+    double *dnv = p; p += NN;
+    double *dgv = p; p += NN * B;
+    double *dR = p; p += T * N;
+    double *dcolp = p; p += (size_t)row_blocks * N;
+    double *dslab = p;
+    hipStream_t st = ctx->stream;
+    NHP_HIP(ctx, hipMemcpyAsync(dav, alpha_v, 8 * N, hipMemcpyHostToDevice, st));
+    NHP_HIP(ctx, hipMemcpyAsync(dbv, beta_v, 8 * N, hipMemcpyHostToDevice, st));
+    NHP_HIP(ctx, hipMemcpyAsync(dkv, kappa_v, 8 * NN, hipMemcpyHostToDevice, st));
+    NHP_HIP(ctx, hipMemcpyAsync(dnv, nu_v, 8 * NN, hipMemcpyHostToDevice, st));
+    NHP_HIP(ctx, hipMemcpyAsync(dgv, gamma_v, 8 * NN * B, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_vb_factors, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, st, (int)N, (int)B, dav, dbv, dkv, dnv, dgv, dE, de0);
+    NHP_HIP(ctx, hipGetLastError());
+    // GEMM-1: Z = e0 ⊕ G·E, R = data / Z, column sums of R
+    gemm_args g1{};
+    g1.A = ds->d_conv; g1.lda = T; g1.B = dE; g1.ldb = K; g1.M = (int)T; g1.N = (int)N; g1.K = (int)K; g1.k_chunk = (int)K;
+    g1.base = de0; g1.dataT = ds->d_dataT; g1.out = dR; g1.partials = dcolp;
+    launch_gemm<true, EPI_VB_Z>(g1, 1, st);
+    NHP_HIP(ctx, hipGetLastError());
+    // GEMM-2: slabs_z = Gᵀ·R over T-chunk z
+    gemm_args g2{};
+    g2.A = ds->d_conv; g2.lda = T; g2.B = dR; g2.ldb = T; g2.M = (int)K; g2.N = (int)N; g2.K = (int)T; g2.k_chunk = k_chunk;
+    g2.out = dslab;
+    launch_gemm<false, EPI_SLAB>(g2, splits, st);
+    NHP_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_vb_baseline, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, (int)N, row_blocks, dcolp, de0,
+                       alpha0, beta0, (double)T * dt, dav, dbv);
+    hipLaunchKernelGGL(k_vb_finish, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, st, (int)N, (int)B, splits, dslab, dE,
+                       ds->d_colsum, kappa, nu, gamma, dkv, dnv, dgv);
+    NHP_HIP(ctx, hipGetLastError());
+    NHP_HIP(ctx, hipMemcpyAsync(alpha_v, dav, 8 * N, hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipMemcpyAsync(beta_v, dbv, 8 * N, hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipMemcpyAsync(kappa_v, dkv, 8 * NN, hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipMemcpyAsync(nu_v, dnv, 8 * NN, hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipMemcpyAsync(gamma_v, dgv, 8 * NN * B, hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipStreamSynchronize(st));
+    return NHP_OK;
+}

@@ -89,10 +89,10 @@ struct nhp_disc_dataset {
     nhp_ctx *ctx = nullptr;
     int32_t N = 0, B = 0, L = 0;
     int64_t T = 0;
-    int32_t *d_data = nullptr;          // [N*T] counts narrowed to i32, node fastest
     double *d_dataT = nullptr;          // [T*N] counts as f64, t fastest (GEMM operand)
     double *d_conv = nullptr;           // [T*N*B] t fastest
-    double *d_colsum = nullptr;         // [N] Σ_t data[n,t]
+    double *d_colsum = nullptr;         // [2N] Σ_t data[n,t], then Σ_t loggamma(data[n,t]+1)
+    double lgamma_sum = 0.0;            // Σ_{n,t} loggamma(data[n,t]+1): the data-only term of the Poisson ll
 };
 
 // ---- error plumbing -------------------------------------------------------------------

@@ -1,0 +1,296 @@
+"""Discrete-time process models: host mirror of src/discrete.jl (+ the discrete components of
+src/baselines.jl:358-456 and src/impulses.jl:272-375) on top of libnhp.so.
+
+`data` is the reference's N x T Int64 count matrix (src/discrete.jl:18,80); `convolved` is the
+T x N x B array of basis-filtered counts, kept on the device inside a DiscreteDataset handle.
+"""
+import ctypes as C
+import time
+import weakref
+
+import numpy as np
+
+from . import _lib
+from ._lib import DomainError
+from .components import DenseWeightModel
+from .continuous import HawkesProcess
+
+
+class DiscreteBaseline:
+    pass
+
+
+class DiscreteHomogeneousProcess(DiscreteBaseline):
+    """DiscreteHomogeneousProcess(λ[, dt]) or (λ, α0, β0, αv, βv, dt) -- src/baselines.jl:358-382."""
+
+    def __init__(self, λ, *args):
+        λ = np.array(λ, dtype=np.float64)
+        if len(args) <= 1:
+            α0, β0, αv, βv, dt = 1.0, 1.0, np.ones_like(λ), np.ones_like(λ), (args[0] if args else 1.0)
+        elif len(args) == 5:
+            α0, β0, αv, βv, dt = args
+        else:
+            raise TypeError("DiscreteHomogeneousProcess(λ[, dt]) or (λ, α0, β0, αv, βv, dt)")
+        αv, βv = np.array(αv, dtype=np.float64), np.array(βv, dtype=np.float64)
+        if np.any(λ < 0):
+            raise DomainError("DiscreteHomogeneousProcess: intensity parameter λ must be non-negative")
+        if not α0 > 0:
+            raise DomainError("DiscreteHomogeneousProcess: shape parameter α0 must be positive")
+        if not β0 > 0:
+            raise DomainError("DiscreteHomogeneousProcess: rate parameter β0 must be positive")
+        if not np.all(αv > 0):
+            raise DomainError("DiscreteHomogeneousProcess: shape parameter αv must be positive")
+        if not np.all(βv > 0):
+            raise DomainError("DiscreteHomogeneousProcess: rate parameter βv must be positive")
+        if not dt > 0.0:
+            raise DomainError("DiscreteHomogeneousProcess: time step dt must be non-negative")
+        self.λ, self.α0, self.β0, self.αv, self.βv, self.dt = λ, float(α0), float(β0), αv, βv, float(dt)
+
+    def ndims(self):
+        return len(self.λ)
+
+    def params(self):
+        return self.λ.copy()
+
+    def variational_params(self):
+        return np.concatenate([self.αv, self.βv])
+
+    def intensity(self, *args):
+        """intensity(p, ts) -> len(ts) x N, or intensity(p, node, time) -- src/baselines.jl:402-411"""
+        if len(args) == 1:
+            ts = np.atleast_1d(np.asarray(args[0], dtype=np.float64))
+            if np.any(ts < 0.0):
+                raise DomainError("intensity: times ts must be non-negative")
+            return np.tile(self.λ, (len(ts), 1)) * self.dt
+        node, t = args
+        if node < 1 or node > self.ndims():
+            raise DomainError("intensity: node must be between one and ndims")
+        if t < 0.0:
+            raise DomainError("intensity: time must be non-negative")
+        return self.λ[node - 1] * self.dt
+
+    def sufficient_statistics(self, data):
+        """src/baselines.jl:421-425 (pinned by test/baselines.jl:77-78)"""
+        data = np.asarray(data)
+        return data.sum(axis=1), data.shape[1]
+
+    def integrated_intensity(self, *args):
+        """src/baselines.jl:427-439"""
+        if len(args) == 1:
+            (duration,) = args
+            if duration < 0.0:
+                raise DomainError("intensity: duration must be non-negative")
+            return self.λ * self.dt * duration
+        node, duration = args
+        if node < 1 or node > self.ndims():
+            raise DomainError("intensity: node must be between one and ndims")
+        if duration < 0.0:
+            raise DomainError("intensity: duration must be non-negative")
+        return self.λ[node - 1] * self.dt * duration
+
+    def update_(self, data, parents):
+        """The reference's argument check (src/baselines.jl:447, test/baselines.jl:88); the update
+        itself is fused into the GPU VB step."""
+        data, parents = np.asarray(data), np.asarray(parents)
+        if data.shape != (parents.shape[1], parents.shape[0]):
+            raise ValueError("update!: data and parent dimensions do not conform")
+        N, T = data.shape
+        self.αv = self.α0 + np.sum(parents[:, :, 0] * data.T, axis=0)
+        self.βv = 1.0 / self.β0 + T * self.dt * np.ones(N)
+        return self.αv.copy(), self.βv.copy()
+
+
+class DiscreteImpulseResponse:
+    pass
+
+
+class DiscreteGaussianImpulseResponse(DiscreteImpulseResponse):
+    """DiscreteGaussianImpulseResponse(θ, nlags[, dt]) -- src/impulses.jl:272-288; θ is N x N x B
+    with Σ_b θ[p,c,·] = 1."""
+
+    def __init__(self, θ, nlags, dt=1.0):
+        θ = np.array(θ, dtype=np.float64)
+        if not np.all(θ.sum(axis=2) == 1.0):
+            raise ValueError("Invalid discrete basis parameter.")
+        self.θ, self.γ, self.γv, self.nlags, self.dt = θ, 1.0, np.ones_like(θ), int(nlags), float(dt)
+        self.ϕ = None
+
+    def ndims(self):
+        return self.θ.shape[0]
+
+    def nbasis(self):
+        return self.θ.shape[2]
+
+    def params(self):
+        return self.θ.ravel(order="F").copy()
+
+    def variational_params(self):
+        return self.γv.ravel(order="F").copy()
+
+    def basis(self):
+        """basis(impulse) -> L x B matrix (column b = ϕ_b) -- src/impulses.jl:321-335"""
+        L, B = self.nlags, self.nbasis()
+        phi = np.empty((B, L))
+        _lib.check(_lib.lib().nhp_disc_basis(L, B, self.dt, _lib.dptr(phi)))
+        return phi.T.copy()
+
+
+class DiscreteDataset:
+    """nhp_disc_dataset handle: the count matrix (uploaded once, transposed on the device) and,
+    after convolve(), the T x N x B basis-filtered counts."""
+
+    def __init__(self, ctx, data):
+        data = np.asarray(data)
+        if data.ndim != 2:
+            raise ValueError("data must be an N x T matrix")
+        self.N, self.T = data.shape
+        self.ctx = ctx
+        d = np.asfortranarray(data.astype(np.int64, copy=False)).ravel(order="K")
+        h = C.c_void_p()
+        _lib.check(_lib.lib().nhp_disc_dataset_create(ctx.h, _lib.iptr(d), self.N, self.T, C.byref(h)), ctx.h)
+        self.h = h
+        self.B = 0
+        self._fin = weakref.finalize(self, _lib.lib().nhp_disc_dataset_destroy, h)
+
+
+class DiscreteHawkesProcess(HawkesProcess):
+    def ndims(self):
+        return self.baseline.ndims()
+
+    def nlags(self):
+        return self.impulses.nlags
+
+    def _lowered(self):
+        A = getattr(self, "adjacency_matrix", None)
+        return (_lib.f64(self.baseline.λ), _lib.colmajor(self.weights.W), _lib.colmajor(self.impulses.θ),
+                None if A is None else _lib.colmajor(A))
+
+
+class DiscreteStandardHawkesProcess(DiscreteHawkesProcess):
+    """DiscreteStandardHawkesProcess(baseline, impulses, weights, dt) -- src/discrete.jl:161-170."""
+
+    def __init__(self, baseline, impulses, weights, dt):
+        if baseline.dt != dt or impulses.dt != dt:
+            raise ValueError("Baseline and impulse response time step must match process time step.")
+        self.baseline, self.impulses, self.weights, self.dt = baseline, impulses, weights, float(dt)
+
+    def isstable(self):
+        return np.max(np.abs(np.linalg.eigvals(self.weights.W))) < 1.0
+
+    def params(self):
+        """[λ0; vec(W .* θ)] -- src/discrete.jl:174-182"""
+        return np.concatenate([self.baseline.params(), (self.weights.W[:, :, None] * self.impulses.θ).ravel(order="F")])
+
+    def variational_params(self):
+        """src/discrete.jl:204-209"""
+        return np.concatenate([self.baseline.variational_params(), self.impulses.variational_params(),
+                               self.weights.variational_params()])
+
+
+class DiscreteNetworkHawkesProcess(DiscreteHawkesProcess):
+    """DiscreteNetworkHawkesProcess(baseline, impulses, weights, adjacency_matrix, network, dt)
+    -- src/discrete.jl:395-402."""
+
+    def __init__(self, baseline, impulses, weights, adjacency_matrix, network, dt):
+        self.baseline, self.impulses, self.weights = baseline, impulses, weights
+        self.adjacency_matrix, self.network, self.dt = np.array(adjacency_matrix, dtype=np.float64), network, float(dt)
+
+    def isstable(self):
+        return np.max(np.abs(np.linalg.eigvals(self.adjacency_matrix * self.weights.W))) < 1.0
+
+    def params(self):
+        """[ρ; λ0; W; θ; vec(A)] -- src/discrete.jl:406-414"""
+        return np.concatenate([self.network.params(), self.baseline.params(), self.weights.params(),
+                               self.impulses.params(), self.adjacency_matrix.ravel(order="F")])
+
+
+def convolve(process, data, ctx=None, fetch=False):
+    """convolve(process, data) -- src/discrete.jl:146-151.  Returns a DiscreteDataset whose device
+    copy holds Ŝ (T x N x B); with fetch=True also returns the array itself."""
+    ctx = ctx or _lib.default_context()
+    ds = data if isinstance(data, DiscreteDataset) else DiscreteDataset(ctx, data)
+    phi = process.impulses.basis()
+    L, B = phi.shape
+    ph = np.asfortranarray(phi).ravel(order="K")
+    out = np.empty(ds.T * ds.N * B) if fetch else None
+    _lib.check(_lib.lib().nhp_disc_convolve(ctx.h, ds.h, _lib.dptr(ph), L, B, _lib.dptr(out)), ctx.h)
+    ds.B = B
+    if fetch:
+        return ds, out.reshape((ds.T, ds.N, B), order="F")
+    return ds
+
+
+def _convolved(process, data, convolved, ctx):
+    if convolved is not None:
+        return convolved
+    return convolve(process, data, ctx)
+
+
+def disc_intensity(process, data=None, convolved=None, ctx=None):
+    """intensity(process, convolved) / intensity(process, data) -> T x N -- src/discrete.jl:115-131"""
+    ctx = ctx or _lib.default_context()
+    ds = _convolved(process, data, convolved, ctx)
+    l0, W, th, A = process._lowered()
+    out = np.empty(ds.T * ds.N)
+    _lib.check(_lib.lib().nhp_disc_intensity(ctx.h, ds.h, _lib.dptr(l0), _lib.dptr(W), _lib.dptr(th), _lib.dptr(A),
+                                             process.dt, _lib.dptr(out)), ctx.h)
+    return out.reshape((ds.T, ds.N), order="F")
+
+
+def disc_loglikelihood(process, data=None, convolved=None, ctx=None):
+    """loglikelihood(process, data[, convolved]) -- src/discrete.jl:86-102"""
+    ctx = ctx or _lib.default_context()
+    ds = _convolved(process, data, convolved, ctx)
+    l0, W, th, A = process._lowered()
+    ll = C.c_double()
+    _lib.check(_lib.lib().nhp_disc_loglik(ctx.h, ds.h, _lib.dptr(l0), _lib.dptr(W), _lib.dptr(th), _lib.dptr(A),
+                                          process.dt, C.byref(ll)), ctx.h)
+    return ll.value
+
+
+def update_(process, data, convolved, ctx=None):
+    """update!(process, data, convolved) -- src/discrete.jl:369-375: one mean-field step; the
+    variational parameters of baseline, weights and impulses are overwritten in place."""
+    if not isinstance(process, DiscreteStandardHawkesProcess) or not isinstance(process.weights, DenseWeightModel):
+        raise NotImplementedError("VB exists only for DiscreteStandardHawkesProcess + DenseWeightModel "
+                                  "(the reference's network / sparse variants are broken: SURVEY D6)")
+    ctx = ctx or _lib.default_context()
+    ds = _convolved(process, data, convolved, ctx)
+    b, w, imp = process.baseline, process.weights, process.impulses
+    N, B = process.ndims(), imp.nbasis()
+    av, bv = _lib.f64(b.αv).copy(), _lib.f64(b.βv).copy()
+    kv, nv, gv = _lib.colmajor(w.κv).copy(), _lib.colmajor(w.νv).copy(), _lib.colmajor(imp.γv).copy()
+    _lib.check(_lib.lib().nhp_disc_vb_step(ctx.h, ds.h, process.dt, b.α0, b.β0, w.κ, w.ν, imp.γ,
+                                           _lib.dptr(av), _lib.dptr(bv), _lib.dptr(kv), _lib.dptr(nv), _lib.dptr(gv)),
+               ctx.h)
+    b.αv, b.βv = av, bv
+    w.κv, w.νv = kv.reshape((N, N), order="F"), nv.reshape((N, N), order="F")
+    imp.γv = gv.reshape((N, N, B), order="F")
+    return process.variational_params()
+
+
+class VariationalInference:
+    """src/inference.jl:78-92"""
+
+    def __init__(self):
+        self.trace, self.step, self.elapsed, self.status = [], 0, 0.0, "incomplete"
+
+    def __repr__(self):
+        return f"\n* Status: {self.status}\n    step: {self.step}\n    elapsed: {self.elapsed}"
+
+
+def vb_(process, data, max_steps=1000, Δx_thresh=1e-6, Δq_thresh=1e-2, verbose=False, ctx=None):
+    """vb!(process, data; max_steps, Δx_thresh, Δq_thresh, verbose) -- src/inference.jl:153-181.
+    Like the reference (whose convergence test is commented out, :163-176) it runs max_steps updates."""
+    ctx = ctx or _lib.default_context()
+    start = time.time()
+    convolved = convolve(process, data, ctx)
+    res = VariationalInference()
+    while res.step < max_steps:
+        update_(process, data, convolved, ctx)
+        res.trace.append(process.variational_params())
+        res.step += 1
+    res.elapsed = time.time() - start
+    if verbose:
+        print(" ** maximum steps reached **")
+    return res

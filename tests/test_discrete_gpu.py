@@ -1,0 +1,107 @@
+"""GPU parity for the discrete path: convolve, intensity (fp64-MFMA GEMM-1), Poisson
+log-likelihood and the fused VB step (GEMM-1 + GEMM-2), reference src/discrete.jl:86-151,369-385,
+src/parents.jl:136-177."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make(nhp, N, T, B, L, seed=0, dt=1.0, network=False, rate=0.3):
+    rng = np.random.default_rng(seed)
+    data = rng.poisson(rate, (N, T)).astype(np.int64)
+    W = rng.uniform(0.05, 0.3, (N, N)) / max(1, N // 4)
+    th = rng.dirichlet(np.ones(B), (N, N))
+    th[:, :, -1] = 1.0 - th[:, :, :-1].sum(axis=2)
+    th = np.where(th.sum(axis=2, keepdims=True) == 1.0, th, th)   # constructor demands exact unit sums
+    lam0 = rng.uniform(0.2, 1.0, N)
+    A = (rng.uniform(size=(N, N)) < 0.6).astype(float)
+    base = nhp.DiscreteHomogeneousProcess(lam0, dt)
+    imp = nhp.DiscreteGaussianImpulseResponse.__new__(nhp.DiscreteGaussianImpulseResponse)
+    imp.θ, imp.γ, imp.γv, imp.nlags, imp.dt, imp.ϕ = th, 1.0, np.ones_like(th), L, dt, None
+    wts = nhp.DenseWeightModel(W)
+    if network:
+        proc = nhp.DiscreteNetworkHawkesProcess(base, imp, wts, A, nhp.BernoulliNetworkModel(0.6, N), dt)
+    else:
+        proc = nhp.DiscreteStandardHawkesProcess(base, imp, wts, dt)
+    return proc, data, lam0, W, th, (A if network else None)
+
+
+@pytest.mark.parametrize("N,T,B,L", [(3, 50, 2, 4), (5, 300, 3, 7), (16, 1000, 8, 32), (130, 257, 2, 3)])
+def test_convolve_bit_exact(nhp, orc, N, T, B, L):
+    proc, data, *_ = make(nhp, N, T, B, L, seed=N)
+    phi = proc.impulses.basis()
+    assert np.array_equal(phi, orc.disc_basis(L, B, 1.0))
+    ds, conv = nhp.convolve(proc, data, fetch=True)
+    assert conv.shape == (T, N, B)
+    assert np.array_equal(conv, orc.disc_convolve(data, phi))      # same summation order, no contraction
+
+
+@pytest.mark.parametrize("N,T,B,L,network", [(3, 50, 2, 4, False), (5, 300, 3, 7, True), (16, 1000, 8, 32, False),
+                                             (130, 257, 2, 3, True), (64, 2000, 4, 8, False)])
+def test_intensity_and_loglik(nhp, orc, N, T, B, L, network):
+    dt = 0.5
+    proc, data, lam0, W, th, A = make(nhp, N, T, B, L, seed=N + 1, dt=dt, network=network)
+    conv = orc.disc_convolve(data, orc.disc_basis(L, B, dt))
+    want = orc.disc_intensity(conv, lam0, W, th, dt=dt, A=A)
+    ds = nhp.convolve(proc, data)
+    got = nhp.intensity(proc, ds)
+    assert got.shape == (T, N)
+    assert np.max(np.abs(got - want) / want) < 1e-12
+    ll = nhp.loglikelihood(proc, data)                 # loglikelihood(process, data) convolves itself
+    ll2 = nhp.loglikelihood(proc, data, convolved=ds)  # loglikelihood(process, data, convolved)
+    wll = orc.disc_loglik(data, want)
+    assert abs(ll - wll) < 1e-11 * abs(wll) and ll == ll2
+
+
+@pytest.mark.parametrize("N,T,B,L", [(3, 40, 2, 4), (6, 500, 3, 5), (20, 3000, 4, 8), (130, 300, 2, 3)])
+def test_vb_step(nhp, orc, N, T, B, L):
+    proc, data, lam0, W, th, _ = make(nhp, N, T, B, L, seed=7 * N)
+    rng = np.random.default_rng(5)
+    proc.baseline.αv, proc.baseline.βv = rng.uniform(0.5, 3, N), rng.uniform(0.5, 3, N)
+    proc.weights.κv, proc.weights.νv = rng.uniform(0.5, 3, (N, N)), rng.uniform(0.5, 3, (N, N))
+    proc.impulses.γv = rng.uniform(0.5, 3, (N, N, B))
+    conv = orc.disc_convolve(data, orc.disc_basis(L, B, 1.0))
+    want = orc.disc_vb_step(data, conv, 1.0, proc.baseline.α0, proc.baseline.β0, proc.weights.κ, proc.weights.ν,
+                            proc.impulses.γ, proc.baseline.αv, proc.baseline.βv, proc.weights.κv, proc.weights.νv,
+                            proc.impulses.γv)
+    ds = nhp.convolve(proc, data)
+    vp = nhp.update_(proc, data, ds)
+    got = (proc.baseline.αv, proc.baseline.βv, proc.weights.κv, proc.weights.νv, proc.impulses.γv)
+    for g, w in zip(got, want):
+        assert np.allclose(g, w, rtol=1e-10, atol=1e-12)
+    assert len(vp) == 2 * N + N * N * B + 2 * N * N
+    # a second step starts from the updated parameters (update order: u from the OLD parameters)
+    want2 = orc.disc_vb_step(data, conv, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, *want)
+    nhp.update_(proc, data, ds)
+    assert np.allclose(proc.impulses.γv, want2[4], rtol=1e-9)
+
+
+def test_vb_driver_and_errors(nhp):
+    proc, data, *_ = make(nhp, 4, 200, 2, 4, seed=2)
+    res = nhp.vb_(proc, data, max_steps=5)
+    assert res.step == 5 and len(res.trace) == 5
+    assert np.all(proc.weights.νv == 1.0 + data.sum(axis=1)[:, None])
+    netproc, *_ = make(nhp, 4, 200, 2, 4, seed=2, network=True)
+    with pytest.raises(NotImplementedError):
+        nhp.update_(netproc, data, None)               # network VB is broken in the reference (D6)
+    with pytest.raises(nhp.DomainError):
+        nhp.DiscreteHomogeneousProcess([1.0, -1.0])    # test/baselines.jl:62
+    with pytest.raises(ValueError):
+        nhp.DiscreteHomogeneousProcess(np.ones(2), 0.5).update_(np.zeros((2, 10)), np.zeros((2, 10, 1)))
+
+
+def test_config4_shape_properties(nhp):
+    # BASELINE configs[3] scaled to fit a test (N=512, B=8, L=32, T=4096): GEMM linearity and
+    # the closed form for W = 0
+    N, T, B, L = 512, 4096, 8, 32
+    proc, data, lam0, W, th, _ = make(nhp, N, T, B, L, seed=1, rate=0.05)
+    ds = nhp.convolve(proc, data)
+    lam = nhp.intensity(proc, ds)
+    proc.weights.W = 2.0 * W
+    lam2 = nhp.intensity(proc, ds)
+    assert np.allclose(lam2 - lam0[None, :], 2.0 * (lam - lam0[None, :]), rtol=1e-12, atol=1e-15)
+    proc.weights.W = np.zeros((N, N))
+    from scipy.special import gammaln
+    closed = (data.T * np.log(lam0)[None, :]).sum() - T * lam0.sum() - gammaln(data + 1.0).sum()
+    assert abs(nhp.loglikelihood(proc, data, convolved=ds) - closed) < 1e-10 * abs(closed)

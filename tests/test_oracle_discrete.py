@@ -1,0 +1,96 @@
+"""Pins the CPU oracle for the discrete path (CPU only): reference fixtures
+(test/baselines.jl:60-88), scipy cross-checks of the third-party pieces, and a brute-force
+numpy evaluation of the VB step straight from the reference's formulas."""
+import numpy as np
+import pytest
+from scipy import signal, special, stats
+
+
+def case(N=3, T=60, B=3, L=5, seed=0, dt=1.0):
+    rng = np.random.default_rng(seed)
+    data = rng.poisson(0.4, (N, T)).astype(np.int64)
+    W = rng.uniform(0.05, 0.3, (N, N))
+    th = rng.dirichlet(np.ones(B), (N, N))
+    lam0 = rng.uniform(0.2, 1.0, N)
+    A = (rng.uniform(size=(N, N)) < 0.6).astype(float)
+    return data, lam0, W, th, A, L, B, dt
+
+
+def test_reference_discrete_baseline_fixture(orc):
+    # test/baselines.jl:69-81: λ = ones(2), dt = 0.5 -> intensity 0.5; integrated_intensity(2.0) == [1, 1]
+    conv = np.zeros((11, 2, 1))
+    lam = orc.disc_intensity(conv, np.ones(2), np.zeros((2, 2)), np.ones((2, 2, 1)), dt=0.5)
+    assert np.array_equal(lam, 0.5 * np.ones((11, 2)))
+
+
+def test_basis_matches_formula(orc):
+    for L, B in ((4, 3), (5, 5), (32, 8), (3, 4)):
+        phi = orc.disc_basis(L, B, 0.5)
+        sigma = L / (B - 1)
+        mu = np.linspace(1, L, B + 2)[1:-1] if B < L else np.linspace(1, L, B)
+        raw = np.exp(-(np.arange(1, L + 1)[:, None] - mu[None, :]) ** 2 / (4 * sigma))
+        want = raw / (raw.sum(axis=0) * 0.5)
+        assert np.allclose(phi, want, rtol=1e-13, atol=0)
+        assert np.allclose(phi.sum(axis=0) * 0.5, 1.0)
+
+
+def test_convolve_vs_scipy(orc):
+    data, *_rest, L, B, dt = case(T=200, L=7)
+    phi = orc.disc_basis(L, B, dt)
+    conv = orc.disc_convolve(data, phi)
+    T = data.shape[1]
+    for b in range(B):
+        full = signal.convolve(data.T.astype(float), np.concatenate([[0.0], phi[:, b]])[:, None])[:T]
+        assert np.allclose(conv[:, :, b], np.maximum(full, 0.0), atol=1e-12)
+    assert np.all(conv[0] == 0.0)                       # lag 0 excluded, nothing before the first bin
+
+
+def test_intensity_and_loglik_vs_numpy_scipy(orc):
+    data, lam0, W, th, A, L, B, dt = case(dt=0.5)
+    phi = orc.disc_basis(L, B, dt)
+    conv = orc.disc_convolve(data, phi)
+    for adj in (None, A):
+        lam = orc.disc_intensity(conv, lam0, W, th, dt=dt, A=adj)
+        Weff = W if adj is None else adj * W
+        want = lam0[None, :] * dt + np.einsum("tpb,pcb->tc", conv, Weff[:, :, None] * th * dt)
+        assert np.allclose(lam, want, rtol=1e-13)
+        ll = orc.disc_loglik(data, lam)
+        assert abs(ll - stats.poisson.logpmf(data.T, lam).sum()) < 1e-9 * abs(ll)
+
+
+def test_digamma_vs_scipy(orc):
+    xs = np.concatenate([np.linspace(1e-3, 12, 500), np.exp(np.linspace(0, 15, 100))])
+    got = np.array([orc.digamma(x) for x in xs])
+    assert np.max(np.abs(got - special.digamma(xs)) / np.maximum(1.0, np.abs(special.digamma(xs)))) < 1e-14
+
+
+def test_vb_step_vs_bruteforce(orc):
+    data, lam0, W, th, A, L, B, dt = case(N=3, T=40, B=2, L=4, seed=3)
+    N, T = data.shape
+    phi = orc.disc_basis(L, B, dt)
+    conv = orc.disc_convolve(data, phi)
+    rng = np.random.default_rng(1)
+    av, bv = rng.uniform(0.5, 3, N), rng.uniform(0.5, 3, N)
+    kv, nv, gv = rng.uniform(0.5, 3, (N, N)), rng.uniform(0.5, 3, (N, N)), rng.uniform(0.5, 3, (N, N, B))
+    a0, b0, kap, nu, gam = 1.5, 2.0, 1.2, 0.7, 1.1
+    got = orc.disc_vb_step(data, conv, dt, a0, b0, kap, nu, gam, av, bv, kv, nv, gv)
+    # brute force from src/parents.jl:136-177 and the component update!s
+    u = np.zeros((T, N, 1 + N * B))
+    for c in range(N):
+        u[:, c, 0] = np.exp(special.digamma(av[c]) - np.log(bv[c]))
+        for p in range(N):
+            elt = special.digamma(gv[p, c]) - special.digamma(gv[p, c].sum())
+            elw = special.digamma(kv[p, c]) - np.log(nv[p, c])
+            u[:, c, 1 + p * B:1 + (p + 1) * B] = conv[:, p, :] * np.exp(elt + elw)
+    u /= u.sum(axis=2, keepdims=True)
+    want_av = a0 + (u[:, :, 0] * data.T).sum(axis=0)
+    want_bv = 1 / b0 + T * dt * np.ones(N)
+    want_g = np.zeros((N, N, B))
+    for p in range(N):
+        for c in range(N):
+            want_g[p, c] = (data[c][:, None] * u[:, c, 1 + p * B:1 + (p + 1) * B]).sum(axis=0)
+    assert np.allclose(got[0], want_av, rtol=1e-12)
+    assert np.allclose(got[1], want_bv, rtol=1e-15)
+    assert np.allclose(got[2], kap + want_g.sum(axis=2), rtol=1e-12)
+    assert np.allclose(got[3], nu + data.sum(axis=1)[:, None] * np.ones((N, N)), rtol=1e-15)
+    assert np.allclose(got[4], gam + want_g, rtol=1e-12)
