@@ -161,6 +161,9 @@ void nhp_uniform_stream(uint64_t seed, uint64_t step, int64_t n, double *u);
  * 4 exp for x<=0, 5 exponential pdf(θ=x, Δt=y), 6 logit-normal pdf(τ=x, Δt=y; μ=.25, Δtmax=2));
  * lets tests hold the kernels' fixed operation sequences to a bitwise contract */
 nhp_status nhp_probe_math(nhp_ctx *ctx, int32_t op, const double *x, const double *y, int64_t n, double *out);
+/* throughput calibration on register operands: mode 0 = exponential pair terms per second (the
+ * fp64-VALU ceiling of the windowed kernels), mode 1 = fp64 fma per second */
+nhp_status nhp_probe_rate(nhp_ctx *ctx, int32_t mode, int32_t iters, int32_t blocks, double *ops_per_s);
 
 /* ---- discrete data: N x T counts  src/discrete.jl:18,80 -------------------------------- */
 nhp_status nhp_disc_dataset_create(nhp_ctx *ctx, const int64_t *data, int32_t n_nodes, int64_t n_bins,

@@ -71,6 +71,7 @@ def _declare(lib):
     f("nhp_ctx_fetch", i32, _vp, i32, i32, _dp)
     f("nhp_cont_event_intensity", i32, _vp, _vp, _vp, _dp)
     f("nhp_probe_math", i32, _vp, i32, _dp, _dp, i64, _dp)
+    f("nhp_probe_rate", i32, _vp, i32, i32, i32, _dp)
     for name, args in (
         ("nhp_cont_loglik_grad", (_vp, _vp, _vp, i32, _dp, _dp, i64)),
         ("nhp_cont_intensity", (_vp, _vp, _vp, _dp, i64, _dp)),

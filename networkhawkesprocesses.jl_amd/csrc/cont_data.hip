@@ -30,8 +30,11 @@ static int pick_group(double kbar)
         int g = atoi(env);
         if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64) return g;
     }
+    // measured on MI355X (tools/sweep3.sh): best width ~ 3*sqrt(mean window), at most 32:
+    // 8 at K=8, 16 at K=64, 16-32 at K=512
+    const double target = 3.0 * sqrt(kbar > 0.0 ? kbar : 0.0);
     int g = 1;
-    while (g < 64 && (double)g * 2.0 <= kbar) g *= 2;   // largest power of two <= kbar
+    while (g < 32 && (double)g * 2.0 <= target) g *= 2;
     return g;
 }
 
@@ -85,10 +88,12 @@ extern "C" nhp_status nhp_cont_dataset_create(nhp_ctx *ctx, const double *events
         }
     }
     // partition buckets into items of at most `chunk` children; every node gets >= 1 item
-    int64_t chunk = (M + 2047) / 2048;
-    chunk = std::max<int64_t>(32, std::min<int64_t>(1024, chunk));
+    // ~1024 items (4 per CU): one item per node when there are that many nodes (a node's column is
+    // then staged exactly once), otherwise nodes are cut into runs of M/1024 children
+    int64_t chunk = N >= 1024 ? (int64_t)(1.3 * (double)M / (double)N) + 1 : (M + 1023) / 1024;
+    chunk = std::max<int64_t>(32, std::min<int64_t>(4096, chunk));
     const char *env = getenv("NHP_CHUNK");
-    if (env && atoi(env) > 0) chunk = atoi(env);
+    if (env && atoi(env) > 0) chunk = std::min(atoi(env), 4096);
     std::vector<nhp_item> items;
     for (int32_t c = 0; c < N; ++c) {
         int32_t b = ds->h_boff[c], e = ds->h_boff[c + 1];
@@ -104,11 +109,23 @@ extern "C" nhp_status nhp_cont_dataset_create(nhp_ctx *ctx, const double *events
         }
     }
     ds->n_items = (int32_t)items.size();
+    // Windowed kernels: inside an item, order children by window length so that the lanes of a wave
+    // run the same number of pair iterations (the sum does not depend on the order; it stays fixed).
+    std::vector<nhp_child> child_w(child);
+    for (const nhp_item &it : items)
+        std::stable_sort(child_w.begin() + it.kbeg, child_w.begin() + it.kend, [](const nhp_child &x, const nhp_child &y) {
+            return (x.idx - x.first) > (y.idx - y.first);
+        });
+    for (const nhp_item &it : items) ds->max_item = std::max(ds->max_item, it.kend - it.kbeg);
+    std::vector<nhp_event> ev((size_t)M);
+    for (int64_t i = 0; i < M; ++i) { ev[i].t = events[i]; ev[i].node = node32[i]; ev[i].pad = 0; }
 
     nhp_status s;
     if ((s = upload(ctx, &ds->d_times, events, (size_t)M)) != NHP_OK ||
         (s = upload(ctx, &ds->d_nodes, node32.data(), (size_t)M)) != NHP_OK ||
+        (s = upload(ctx, &ds->d_ev, ev.data(), (size_t)M)) != NHP_OK ||
         (s = upload(ctx, &ds->d_child, child.data(), (size_t)M)) != NHP_OK ||
+        (s = upload(ctx, &ds->d_child_w, child_w.data(), (size_t)M)) != NHP_OK ||
         (s = upload(ctx, &ds->d_boff, ds->h_boff.data(), (size_t)N + 1)) != NHP_OK ||
         (s = upload(ctx, &ds->d_items, items.data(), items.size())) != NHP_OK ||
         (s = upload(ctx, &ds->d_cnt, ds->h_cnt.data(), (size_t)N)) != NHP_OK) {
@@ -126,7 +143,7 @@ extern "C" void nhp_cont_dataset_destroy(nhp_cont_dataset *ds)
     if (!ds) return;
     (void)hipSetDevice(ds->ctx->device);
     (void)hipStreamSynchronize(ds->ctx->stream);
-    (void)hipFree(ds->d_times); (void)hipFree(ds->d_nodes); (void)hipFree(ds->d_child);
+    (void)hipFree(ds->d_times); (void)hipFree(ds->d_nodes); (void)hipFree(ds->d_child); (void)hipFree(ds->d_child_w); (void)hipFree(ds->d_ev);
     (void)hipFree(ds->d_boff); (void)hipFree(ds->d_items); (void)hipFree(ds->d_cnt);
     delete ds;
 }
@@ -255,13 +272,15 @@ extern "C" void nhp_cont_model_destroy(nhp_cont_model *m)
 nhp_cont_args nhp_make_args(const nhp_cont_dataset *ds, const nhp_cont_model *m)
 {
     nhp_cont_args a;
-    a.times = ds->d_times; a.nodes = ds->d_nodes; a.child = ds->d_child; a.boff = ds->d_boff;
+    a.times = ds->d_times; a.nodes = ds->d_nodes; a.ev = ds->d_ev; a.child = ds->d_child; a.child_w = ds->d_child_w; a.boff = ds->d_boff;
     a.items = ds->d_items; a.cnt = ds->d_cnt;
     a.lambda0 = m->d_lambda0; a.grid = m->d_grid; a.p1 = m->d_p1; a.p2 = m->d_p2; a.W = m->d_W;
     a.A = m->has_A ? m->d_A : nullptr;
     a.M = ds->M; a.N = ds->N; a.grid_n = m->grid_n; a.baseline_kind = m->baseline_kind;
     a.impulse_kind = m->impulse_kind; a.dt_max = ds->dt_max; a.inv_dtmax = 1.0 / ds->dt_max;
     a.duration = ds->duration;
+    const char *dbg = getenv("NHP_DBG");
+    a.dbg = dbg ? atoi(dbg) : 0;
     return a;
 }
 

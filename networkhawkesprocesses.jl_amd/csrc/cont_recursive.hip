@@ -37,73 +37,102 @@ __device__ __forceinline__ double rec_baseline(const nhp_cont_args &a, int c, do
     return (y[lo + 1] * (t - x[lo]) + y[lo] * (x[lo + 1] - t)) / (x[lo + 1] - x[lo]);
 }
 
+// Layout of one workgroup (column c): thread `tid` owns parent nodes p = tid + 256 q; their state
+// S_pc, θ_pc and (a·w·θ)_pc live in registers.  LDS holds θ[·,c] (gathered by node in the segment
+// pass) and TWO segment accumulators, so that folding segment k+1 and consuming segment k share
+// one barrier interval: one barrier per child instead of two, and two independent instruction
+// streams for the scheduler to interleave.
+#define REC_PQ 8     // parent nodes per thread (N <= 2048)
+
 __global__ __launch_bounds__(NHP_BLOCK) void k_recursive(nhp_cont_args a, double *__restrict__ partials)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     double *red = reinterpret_cast<double *>(smem);              // [4]
-    double *ring = red + 4;                                      // [NHP_RING * NHP_WAVES]
-    double *th = ring + NHP_RING * NHP_WAVES;                    // [N] θ[p,c]
-    double *wth = th + a.N;                                      // [N] (a*w)*θ
-    double *S = wth + a.N;                                       // [N] state, as of the last child
-    double *acc_new = S + a.N;                                   // [N] segment accumulator, as of t_k
+    double *ring = red + 4;                                      // [2][NHP_RING * NHP_WAVES]
+    double *th = ring + 2 * NHP_RING * NHP_WAVES;                // [N] θ[p,c]
+    double *acc0 = th + a.N;                                     // [N] segment accumulators (double-buffered)
+    double *acc1 = acc0 + a.N;
 
     const int c = blockIdx.x, N = a.N, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
 
+    double S[REC_PQ], thr[REC_PQ], wthr[REC_PQ];
     double integ = 0.0;
-    for (int p = tid; p < N; p += NHP_BLOCK) {
-        const size_t k = (size_t)p + (size_t)c * N;
-        const double w = a.W[k];
-        const double weff = a.A ? a.A[k] * w : w;
-        const double t = a.p1[k];
-        th[p] = t;
-        wth[p] = weff * t;
-        S[p] = 0.0;
-        acc_new[p] = 0.0;
-        integ += a.cnt[p] * w;                                   // unmasked: src/continuous.jl:247,413
+#pragma unroll
+    for (int q = 0; q < REC_PQ; ++q) {
+        const int p = tid + q * NHP_BLOCK;
+        S[q] = 0.0; thr[q] = 0.0; wthr[q] = 0.0;
+        if (p < N) {
+            const size_t k = (size_t)p + (size_t)c * N;
+            const double w = a.W[k];
+            const double weff = a.A ? a.A[k] * w : w;
+            const double t = a.p1[k];
+            thr[q] = t; wthr[q] = weff * t;
+            th[p] = t; acc0[p] = 0.0; acc1[p] = 0.0;
+            integ += a.cnt[p] * w;                               // unmasked: src/continuous.jl:247,413
+        }
     }
     __syncthreads();
 
     const int kb = a.boff[c], ke = a.boff[c + 1];
-    int prev_idx = 0;
-    double prev_t = 0.0, logsum = 0.0;
-    for (int k = kb; k < ke; ++k) {
-        const nhp_child ch = a.child[k];
-        // fold the segment's events into the accumulator, referenced to t_k
-        for (int j = prev_idx + tid; j < ch.idx; j += NHP_BLOCK) {
-            const double tj = a.times[j];
-            if (tj > 0.0) {
-                const int p = a.nodes[j];
-                const double e = nhp_exp_neg(-(th[p] * (ch.t - tj)));
-                atomicAdd(&acc_new[p], e);
-            }
+    double logsum = 0.0;
+
+    // fold the events of [jb, je) into acc, referenced to time tk  (t_j > 0: the D9 seen-flag)
+    auto fold = [&](double *acc, int jb, int je, double tk) {
+        for (int j = jb + tid; j < je; j += NHP_BLOCK) {
+            const nhp_event e = a.ev[j];
+            if (e.t > 0.0) atomicAdd(&acc[e.node], nhp_exp_neg(-(th[e.node] * (tk - e.t))));
         }
-        __syncthreads();
-        // decay the state to t_k, merge, dot with the weights
-        const double gap = ch.t - prev_t;
+    };
+
+    // child records (time, index) are kept in scalars and fetched two ahead, so their latency never
+    // sits on the loop (a struct copy here makes hipcc spill the records to scratch)
+    double ch_t = 0.0, nx_t = 0.0;
+    int ch_idx = 0, nx_idx = 0;
+    if (kb < ke) { ch_t = a.child[kb].t; ch_idx = a.child[kb].idx; nx_t = ch_t; nx_idx = ch_idx; }
+    if (kb + 1 < ke) { nx_t = a.child[kb + 1].t; nx_idx = a.child[kb + 1].idx; }
+    if (kb < ke) fold(acc0, 0, ch_idx, ch_t);
+    __syncthreads();
+    double prev_t = ch_t;
+    for (int k = kb; k < ke; ++k) {
+        const int par = (k - kb) & 1;
+        double *accA = par ? acc0 : acc1;                        // filled now, consumed next iteration
+        double *accB = par ? acc1 : acc0;                        // filled last iteration, consumed now
+        const int kn = k + 2 < ke ? k + 2 : ke - 1;
+        const double nn_t = a.child[kn].t;
+        const int nn_idx = a.child[kn].idx;
+        if (k + 1 < ke) fold(accA, ch_idx, nx_idx, nx_t);
+        // decay the state to t_k, merge segment k, dot with the weights
+        const double gap = ch_t - prev_t;
         double part = 0.0;
-        for (int p = tid; p < N; p += NHP_BLOCK) {
-            double s = S[p];
-            if (k != kb) s *= nhp_exp_neg(-(th[p] * gap));
-            s += acc_new[p];
-            acc_new[p] = 0.0;
-            S[p] = s;
-            part += wth[p] * s;
+#pragma unroll
+        for (int q = 0; q < REC_PQ; ++q) {
+            const int p = tid + q * NHP_BLOCK;
+            if (p < N) {
+                double s = S[q];
+                if (k != kb) s *= nhp_exp_neg(-(thr[q] * gap));
+                s += accB[p];
+                accB[p] = 0.0;
+                S[q] = s;
+                part += wthr[q] * s;
+            }
         }
         part = nhp_wave_sum(part);
         const int slot = (k - kb) & (NHP_RING - 1);
-        if (lane == 0) ring[slot * NHP_WAVES + wave] = part;
+        const int half = ((k - kb) / NHP_RING) & 1;
+        if (lane == 0) ring[(half * NHP_RING + slot) * NHP_WAVES + wave] = part;
         __syncthreads();
         if (slot == NHP_RING - 1 || k == ke - 1) {
             if (tid <= slot) {
                 const double tk = a.child[k - slot + tid].t;
                 double lam = rec_baseline(a, c, tk);
-                for (int w = 0; w < NHP_WAVES; ++w) lam += ring[tid * NHP_WAVES + w];
+                for (int w = 0; w < NHP_WAVES; ++w) lam += ring[(half * NHP_RING + tid) * NHP_WAVES + w];
                 logsum += nhp_log(lam);
             }
         }
-        prev_idx = ch.idx;
-        prev_t = ch.t;
+        prev_t = ch_t;
+        ch_t = nx_t; ch_idx = nx_idx;
+        nx_t = nn_t; nx_idx = nn_idx;
     }
     const double blk = nhp_block_sum(logsum, red);
     const double blk_int = nhp_block_sum(integ, red);
@@ -117,7 +146,8 @@ nhp_status nhp_launch_recursive(nhp_ctx *ctx, const nhp_cont_dataset *ds, const 
 {
     if (m->impulse_kind != NHP_IMPULSE_EXPONENTIAL) return NHP_EINVAL;
     NHP_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t lds = sizeof(double) * (4 + NHP_RING * NHP_WAVES + 4 * (size_t)ds->N);
+    if (ds->N > REC_PQ * NHP_BLOCK) { nhp_set_error(ctx, "recursive ll: n_nodes = %d > %d not supported", ds->N, REC_PQ * NHP_BLOCK); return NHP_ENOTIMPL; }
+    const size_t lds = sizeof(double) * (4 + 2 * NHP_RING * NHP_WAVES + 3 * (size_t)ds->N);
     if (lds > 64 * 1024) { nhp_set_error(ctx, "recursive ll: n_nodes = %d exceeds the 64 KiB LDS state budget", ds->N); return NHP_ENOTIMPL; }
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)ds->N));
     nhp_cont_args a = nhp_make_args(ds, m);

@@ -50,6 +50,8 @@ extern "C" nhp_status nhp_ctx_create(int32_t device, nhp_ctx **out)
     NHP_HIP(ctx, hipEventCreate(&ctx->ev1));
     NHP_HIP(ctx, hipMalloc(&ctx->d_results, sizeof(double) * NHP_MAX_SLOTS));
     NHP_HIP(ctx, hipHostMalloc(&ctx->h_results, sizeof(double) * NHP_MAX_SLOTS));
+    NHP_HIP(ctx, hipMalloc(&ctx->d_counter, 128 * 80));
+    NHP_HIP(ctx, hipMemsetAsync(ctx->d_counter, 0, 128 * 80, ctx->stream));
     NHP_HIP(ctx, hipMemsetAsync(ctx->d_results, 0, sizeof(double) * NHP_MAX_SLOTS, ctx->stream));
     NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = ctx;
@@ -65,6 +67,7 @@ extern "C" void nhp_ctx_destroy(nhp_ctx *ctx)
     if (ctx->h_results) (void)hipHostFree(ctx->h_results);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -21,6 +21,7 @@ struct nhp_ctx {
     size_t partials_cap = 0;            // in doubles
     void *d_scratch = nullptr;          // general scratch (gradients, sampler output)
     size_t scratch_cap = 0;             // bytes
+    unsigned int *d_counter = nullptr;  // arrival ticket of the fused last-block reduction (kept at 0 between launches)
     int cu_count = 256;
     std::string err;
 };
@@ -40,6 +41,13 @@ struct __attribute__((aligned(16))) nhp_child {
     int32_t idx;       // original (time-ordered) index of this event; window = [first, idx)
 };
 
+// An event in time order, packed so that one 16-byte load fetches a parent.
+struct __attribute__((aligned(16))) nhp_event {
+    double t;
+    int32_t node;      // 0-based
+    int32_t pad;
+};
+
 struct nhp_cont_dataset {
     nhp_ctx *ctx = nullptr;
     int64_t M = 0;
@@ -48,10 +56,13 @@ struct nhp_cont_dataset {
     int64_t pairs = 0;
     int32_t group = 8;                  // lanes cooperating on one child in the windowed kernels
     int32_t n_items = 0;
+    int32_t max_item = 0;               // most children in one item (sizes the deferred-log LDS buffer)
+    nhp_event *d_ev = nullptr;          // [M] time order, packed (t, node)
     // device arrays
     double *d_times = nullptr;          // [M] time order
     int32_t *d_nodes = nullptr;         // [M] 0-based
-    nhp_child *d_child = nullptr;       // [M] bucket order
+    nhp_child *d_child = nullptr;       // [M] bucket order (time order inside a node)
+    nhp_child *d_child_w = nullptr;     // [M] same, but inside each item sorted by window length (windowed kernels)
     int32_t *d_boff = nullptr;          // [N+1] bucket offsets
     nhp_item *d_items = nullptr;        // [n_items]
     double *d_cnt = nullptr;            // [N] events per node
@@ -74,7 +85,9 @@ struct nhp_cont_model {
 struct nhp_cont_args {
     const double *times;
     const int32_t *nodes;
+    const nhp_event *ev;
     const nhp_child *child;
+    const nhp_child *child_w;
     const int32_t *boff;
     const nhp_item *items;
     const double *cnt;
@@ -83,6 +96,7 @@ struct nhp_cont_args {
     int64_t M;
     int32_t N, grid_n, baseline_kind, impulse_kind;
     double dt_max, inv_dtmax, duration;
+    int32_t dbg;        // NHP_DBG ablation bits (timing experiments only; results are wrong when set)
 };
 
 struct nhp_disc_dataset {
@@ -123,7 +137,36 @@ nhp_status nhp_launch_finalize(nhp_ctx *ctx, const nhp_cont_args &a, int n_parti
 nhp_status nhp_launch_event_intensity(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_lambda);
 
 // ---- device helpers --------------------------------------------------------------------
+__device__ __forceinline__ double nhp_dpp_add(double v, const int sel)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    int plo, phi;
+    switch (sel) {
+    case 0: plo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+    case 1: plo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+    case 2: plo = __builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true); break; // row_half_mirror
+    default: plo = __builtin_amdgcn_mov_dpp(lo, 0x140, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0x140, 0xF, 0xF, true); break; // row_mirror
+    }
+    return v + __hiloint2double(phi, plo);
+}
+
+// Sum over the 64 lanes of a wave; every lane returns the total.  Rows of 16 are reduced in the
+// VALU with DPP, the four row sums are combined through scalar lane reads (no LDS round trips).
 __device__ __forceinline__ double nhp_wave_sum(double v)
+{
+    v = nhp_dpp_add(v, 0);
+    v = nhp_dpp_add(v, 1);
+    v = nhp_dpp_add(v, 2);
+    v = nhp_dpp_add(v, 3);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double r = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    r += __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    r += __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    r += __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return r;
+}
+
+__device__ __forceinline__ double nhp_wave_sum_shfl(double v)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;

@@ -36,3 +36,47 @@ extern "C" nhp_status nhp_probe_math(nhp_ctx *ctx, int32_t op, const double *x, 
     NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NHP_OK;
 }
+
+// Throughput calibration ("c_pair measured by an exp-only microkernel"): every lane
+// evaluates `iters` exponential pair terms on register operands, no memory traffic in the loop.
+// mode 0: the pair term w*θ*exp(-θΔ);  mode 1: bare fp64 fma chain (peak fp64 VALU check).
+__global__ __launch_bounds__(256) void k_probe_rate(int mode, int iters, double *__restrict__ sink)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    double th = 1.0 + 1e-3 * (gid & 1023), dt = 1e-2 * (1 + (gid & 63)), acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    if (mode == 0) {
+        for (int i = 0; i < iters; i += 4) {
+            acc0 += 0.5 * nhp_pdf_exponential(th, dt);
+            acc1 += 0.5 * nhp_pdf_exponential(th, dt + 0.25);
+            acc2 += 0.5 * nhp_pdf_exponential(th, dt + 0.5);
+            acc3 += 0.5 * nhp_pdf_exponential(th, dt + 0.75);
+            dt += 1e-6;
+        }
+    } else {
+        double a = th, b = dt;
+        for (int i = 0; i < iters; i += 4) {
+            acc0 = __builtin_fma(acc0, a, b);
+            acc1 = __builtin_fma(acc1, a, b);
+            acc2 = __builtin_fma(acc2, a, b);
+            acc3 = __builtin_fma(acc3, a, b);
+        }
+    }
+    if (acc0 + acc1 + acc2 + acc3 == 12345.678) sink[gid] = acc0;
+}
+
+extern "C" nhp_status nhp_probe_rate(nhp_ctx *ctx, int32_t mode, int32_t iters, int32_t blocks, double *ops_per_s)
+{
+    if (!ctx || !ops_per_s || iters < 4 || blocks < 1) return NHP_EINVAL;
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    NHP_TRY(nhp_ctx_reserve_scratch(ctx, 8 * (size_t)blocks * 256));
+    double *sink = (double *)ctx->d_scratch;
+    hipLaunchKernelGGL(k_probe_rate, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, mode, iters, sink);   // warm-up
+    NHP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_probe_rate, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, mode, iters, sink);
+    NHP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    NHP_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    NHP_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *ops_per_s = (double)blocks * 256.0 * (double)iters / ((double)ms * 1e-3);
+    return NHP_OK;
+}
