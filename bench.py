@@ -98,6 +98,72 @@ def cpu_baseline(r, budget_s=12.0):
                        f"({ts:.3f} s each), scaled linearly to M; row sums of W hoisted (stronger baseline)")
 
 
+def config_workloads(nhp, ctx, which):
+    """BASELINE.json configs[1..3] as secondary measurements (one GPU): wall time per call through
+    the host mirror, i.e. including parameter upload and result download."""
+    import numpy as np
+    out = []
+
+    def timed(fn, reps):
+        fn()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    if "c2" in which:      # continuous exponential standard Hawkes, N=128, ~1e5 events: ll + mle! gradient
+        N, M = 128, 100_000
+        times, nodes, T = nhp.synthetic.s_metric_data(N, M, kbar=16.0)
+        proc = nhp.synthetic.s_metric_process(N, M, T, "exponential", 1.0)
+        ds = nhp.device_dataset(proc, (times, nodes, T), ctx)
+        P = len(proc.params())
+        for rec in (True, False):
+            t_ll = timed(lambda: nhp.loglikelihood(proc, ds, recursive=rec, ctx=ctx), 20)
+            t_g = timed(lambda: nhp.loglikelihood_gradient(proc, ds, recursive=rec, ctx=ctx), 20)
+            out.append({"workload": f"c2 N=128 M=1e5 exponential, recursive={rec}", "loglik_ms": 1e3 * t_ll,
+                        "loglik_plus_gradient_ms": 1e3 * t_g, "params": P,
+                        "reference_gradient_cost_in_loglik_calls": 2 * P})
+    if "c3" in which:      # continuous logit-normal network Hawkes, N=1024, ~1e6 events: mcmc! step
+        N, M = 1024, 1_000_000
+        times, nodes, T = nhp.synthetic.s_metric_data(N, M, kbar=8.0)
+        proc = nhp.synthetic.s_metric_process(N, M, T, "logitnormal", 1.0, network=True)
+        ds = nhp.device_dataset(proc, (times, nodes, T), ctx)
+        step = [0]
+
+        def sampler():
+            nhp.resample_parents(proc, ds, seed=1, step=step[0], with_stats=True, want_parents=False, ctx=ctx)
+            step[0] += 1
+        t_s = timed(sampler, 5)
+        rng = np.random.default_rng(0)
+
+        def gibbs():
+            nhp.resample_(proc, ds, rng, step=step[0], seed=1, ctx=ctx)
+            step[0] += 1
+        t_g = timed(gibbs, 3)
+        out.append({"workload": "c3 N=1024 M=1e6 logit-normal network, mcmc! step (A fixed)",
+                    "parent_sampler_plus_stats_ms": 1e3 * t_s, "full_gibbs_step_ms": 1e3 * t_g,
+                    "pairs": int(ds.pairs)})
+    if "c4" in which:      # discrete Gaussian-basis standard Hawkes, N=512, K=8, T=1e5
+        N, B, L, T = 512, 8, 32, 100_000
+        rng = np.random.default_rng(7)
+        data = rng.poisson(0.05, (N, T)).astype(np.int64)
+        th = np.full((N, N, B), 1.0 / B)
+        imp = nhp.DiscreteGaussianImpulseResponse(th, L, 1.0)
+        proc = nhp.DiscreteStandardHawkesProcess(nhp.DiscreteHomogeneousProcess(rng.uniform(0.02, 0.08, N), 1.0), imp,
+                                                 nhp.DenseWeightModel(rng.uniform(0, 1, (N, N)) / N), 1.0)
+        dsd = nhp.DiscreteDataset(ctx, data)
+        t_c = timed(lambda: nhp.convolve(proc, dsd, ctx=ctx), 3)
+        t_ll = timed(lambda: nhp.loglikelihood(proc, data, convolved=dsd, ctx=ctx), 5)
+        t_vb = timed(lambda: nhp.update_(proc, data, dsd, ctx=ctx), 3)
+        flop = 2.0 * T * N * N * B
+        out.append({"workload": "c4 discrete N=512 B=8 L=32 T=1e5", "convolve_ms": 1e3 * t_c, "loglik_ms": 1e3 * t_ll,
+                    "loglik_tflops_fp64": flop / t_ll / 1e12, "vb_step_ms": 1e3 * t_vb,
+                    "vb_tflops_fp64": 2 * flop / t_vb / 1e12, "mfma_fp64_peak_tflops": 78.6})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +174,8 @@ def main():
     ap.add_argument("--events", type=int, default=1_000_000)
     ap.add_argument("--extra", default=os.environ.get("NHP_BENCH_EXTRA", "windowed_k64,windowed_k512,recursive"),
                     help="comma list of secondary workloads reported under 'other_workloads' (N=1 only)")
+    ap.add_argument("--configs", default=os.environ.get("NHP_BENCH_CONFIGS", "c2,c3,c4"),
+                    help="comma list of BASELINE configs measured as secondary workloads (N=1 only); '' to skip")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -178,6 +246,8 @@ def main():
                                "pairs_per_eval": o["pairs"], "hbm_frac": Bo / (mk * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "loglik": o["ll"]})
             out["other_workloads"] = others
+        if world == 1 and args.configs:
+            out["configs"] = config_workloads(nhp, ctx, args.configs.split(","))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

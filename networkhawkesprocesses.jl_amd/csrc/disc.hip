@@ -44,7 +44,7 @@ struct gemm_args {
 
 // C[m,n] = Σ_k Aop[m,k]·B[k + n·ldb];  A_MCONTIG: Aop[m,k] = A[m + k·lda], else A[k + m·lda].
 template <bool A_MCONTIG, int EPI>
-__global__ __launch_bounds__(256) void k_gemm_f64(gemm_args g)
+__global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 waves/SIMD: <= 256 VGPR+AGPR
 {
     __shared__ double As[A_MCONTIG ? BK * A_MC_LD : BM * KC_LD];
     __shared__ double Bs[BN * KC_LD];
@@ -54,7 +54,14 @@ __global__ __launch_bounds__(256) void k_gemm_f64(gemm_args g)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r16 = lane & 15, kk = lane >> 4;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;   // n-blocks fastest: tiles sharing an A panel are adjacent
+    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Remap the linear id
+    // so that every XCD owns a CONTIGUOUS run of logical tiles: the n-tiles that share an A panel
+    // then hit the same L2 instead of fetching the panel once per XCD (bijective for any grid).
+    const unsigned nbk = gridDim.x * gridDim.y, lin = blockIdx.x + blockIdx.y * gridDim.x;
+    const unsigned xq = nbk / 8, xr = nbk % 8, xcd = lin % 8, pos = lin / 8;
+    const unsigned logical = xcd * xq + (xcd < xr ? xcd : xr) + pos;
+    const int bx = (int)(logical % gridDim.x), by = (int)(logical / gridDim.x);
+    const int m0 = by * BM, n0 = bx * BN;                    // n-tiles fastest: tiles sharing an A panel are adjacent
     const int kbeg = blockIdx.z * g.k_chunk;
     const int kend = min(g.K, kbeg + g.k_chunk);
 
@@ -65,29 +72,41 @@ __global__ __launch_bounds__(256) void k_gemm_f64(gemm_args g)
         for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
     // per-thread staging coordinates: 8 consecutive elements along the contiguous dimension
+    // m-contig A: thread (k = tid/16, m = tid%16 + 16 e): at fixed e a wave covers 4 k-rows x 128 B,
+    // coalesced in HBM and conflict-free as ds_write_b64 (consecutive lanes -> consecutive doubles)
     const int a_k = A_MCONTIG ? tid >> 4 : (tid & 1) * 8;          // m-contig: k row;  k-contig: k offset
-    const int a_m = A_MCONTIG ? (tid & 15) * 8 : tid >> 1;         // m-contig: m offset; k-contig: m row
+    const int a_m = A_MCONTIG ? (tid & 15) : tid >> 1;             // m-contig: m offset; k-contig: m row
     const int b_k = (tid & 1) * 8, b_n = tid >> 1;
     double ra[8], rb[8];
 
+    // Per-thread operand pointers advance by one tile per iteration; the 8 elements of a thread sit
+    // at compile-time offsets from them, so the loop carries no 64-bit index arithmetic (with one
+    // wave per SIMD every VALU instruction is time taken from the MFMA stream).
+    const double *pa = A_MCONTIG ? g.A + ((size_t)(m0 + a_m) + (size_t)(kbeg + a_k) * g.lda)
+                                 : g.A + ((size_t)(kbeg + a_k) + (size_t)(m0 + a_m) * g.lda);
+    const double *pb = g.B + ((size_t)(kbeg + b_k) + (size_t)(n0 + b_n) * g.ldb);
+    const size_t a_step = A_MCONTIG ? (size_t)BK * g.lda : (size_t)BK;
+    unsigned a_ok = 0;                       // bit e: row of element e is inside the matrix
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a_ok |= ((A_MCONTIG ? m0 + a_m + 16 * e : m0 + a_m) < g.M ? 1u : 0u) << e;
+    const bool b_ok = n0 + b_n < g.N;
+
     auto load_tiles = [&](int k0) {
+        const bool full = k0 + BK <= kend;   // only the last tile of a ragged K needs per-element checks
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            if (A_MCONTIG) {
-                const int m = m0 + a_m + e, k = k0 + a_k;
-                ra[e] = (m < g.M && k < kend) ? g.A[(size_t)m + (size_t)k * g.lda] : 0.0;
-            } else {
-                const int m = m0 + a_m, k = k0 + a_k + e;
-                ra[e] = (m < g.M && k < kend) ? g.A[(size_t)k + (size_t)m * g.lda] : 0.0;
-            }
-            const int n = n0 + b_n, k = k0 + b_k + e;
-            rb[e] = (n < g.N && k < kend) ? g.B[(size_t)k + (size_t)n * g.ldb] : 0.0;
+            const bool ka = full || (A_MCONTIG ? k0 + a_k : k0 + a_k + e) < kend;
+            ra[e] = ((a_ok >> e) & 1u) && ka ? (A_MCONTIG ? pa[16 * e] : pa[e]) : 0.0;
+            const bool kb = full || k0 + b_k + e < kend;
+            rb[e] = b_ok && kb ? pb[e] : 0.0;
         }
+        pa += a_step;
+        pb += BK;
     };
     auto store_tiles = [&]() {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            if (A_MCONTIG) As[a_k * A_MC_LD + a_m + e] = ra[e];
+            if (A_MCONTIG) As[a_k * A_MC_LD + a_m + 16 * e] = ra[e];
             else As[a_m * KC_LD + a_k + e] = ra[e];
             Bs[b_n * KC_LD + b_k + e] = rb[e];
         }
@@ -154,7 +173,7 @@ __global__ __launch_bounds__(256) void k_gemm_f64(gemm_args g)
         const double s1 = nhp_block_sum(t_sum, red);
         const double s2 = nhp_block_sum(t_sum2, red);
         if (tid == 0) {
-            const size_t b = (size_t)blockIdx.x + (size_t)blockIdx.y * gridDim.x;
+            const size_t b = (size_t)bx + (size_t)by * gridDim.x;
             g.partials[2 * b] = s1;
             g.partials[2 * b + 1] = s2;
         }
@@ -171,7 +190,7 @@ __global__ __launch_bounds__(256) void k_gemm_f64(gemm_args g)
         __syncthreads();
         if (tid < BN) {
             const int wn2 = tid >> 6, cl = tid & 63, col = n0 + tid;
-            if (col < g.N) g.partials[(size_t)blockIdx.y * g.N + col] = wcol[wn2][cl] + wcol[2 + wn2][cl];
+            if (col < g.N) g.partials[(size_t)by * g.N + col] = wcol[wn2][cl] + wcol[2 + wn2][cl];
         }
     }
 }
@@ -318,12 +337,19 @@ __global__ __launch_bounds__(256) void k_vb_baseline(int N, int row_blocks, cons
                                                      const double *__restrict__ e0, double alpha0, double beta0,
                                                      double Tdt, double *__restrict__ alpha_v, double *__restrict__ beta_v)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
+    // 256 threads = 64 columns x 4 row-slices; fixed-order combine keeps the sum deterministic
+    __shared__ double part[4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double s = 0.0;
-    for (int r = 0; r < row_blocks; ++r) s += colpart[(size_t)r * N + c];
-    alpha_v[c] = alpha0 + e0[c] * s;
-    beta_v[c] = 1.0 / beta0 + Tdt;
+    if (c < N)
+        for (int r = sl; r < row_blocks; r += 4) s += colpart[(size_t)r * N + c];
+    part[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && c < N) {
+        alpha_v[c] = alpha0 + e0[c] * (((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl]);
+        beta_v[c] = 1.0 / beta0 + Tdt;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_sum_pairs(const double *__restrict__ partials, int n, double lg_const,
@@ -559,7 +585,7 @@ extern "C" nhp_status nhp_disc_vb_step(nhp_ctx *ctx, const nhp_disc_dataset *ds,
     g2.out = dslab;
     launch_gemm<false, EPI_SLAB>(g2, splits, st);
     NHP_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_vb_baseline, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, (int)N, row_blocks, dcolp, de0,
+    hipLaunchKernelGGL(k_vb_baseline, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, (int)N, row_blocks, dcolp, de0,
                        alpha0, beta0, (double)T * dt, dav, dbv);
     hipLaunchKernelGGL(k_vb_finish, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, st, (int)N, (int)B, splits, dslab, dE,
                        ds->d_colsum, kappa, nu, gamma, dkv, dnv, dgv);
