@@ -40,6 +40,17 @@ def algorithmic_bytes(N, M, kind):
     return 16 * M + 8 * P + 8
 
 
+def measured_traffic(workload):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json: FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE); None when
+    the workload has not been profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f)[workload]["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def run_workload(nhp, ctx, name, N, M, steps, warmup, sync):
     import ctypes as C
     from nhp_amd import _lib
@@ -167,8 +178,8 @@ def config_workloads(nhp, ctx, which):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=os.environ.get("NHP_BENCH_WORKLOAD", "windowed_k8"), choices=sorted(WORKLOADS))
     ap.add_argument("--nodes", type=int, default=1024)
     ap.add_argument("--events", type=int, default=1_000_000)
@@ -186,10 +197,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # NHP_BENCH_BACKEND=gloo lets the N>1 path be rehearsed on a one-GPU box (ranks share device 0)
+    backend = os.environ.get("NHP_BENCH_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count()) if backend != "nccl" else local
     torch.cuda.set_device(local)
+    tdev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as entry
     nhp = entry.load_package()
@@ -202,8 +220,8 @@ def main():
             torch.cuda.synchronize()
 
     r = run_workload(nhp, ctx, args.workload, args.nodes, args.events, args.steps, args.warmup, sync)
-    wall = torch.tensor([r["wall"]], dtype=torch.float64, device="cuda")
-    lls = torch.tensor([r["ll"]], dtype=torch.float64, device="cuda")
+    wall = torch.tensor([r["wall"]], dtype=torch.float64, device=tdev)
+    lls = torch.tensor([r["ll"]], dtype=torch.float64, device=tdev)
     if world > 1:
         dist.all_reduce(wall, op=dist.ReduceOp.MAX)
         gathered = [torch.zeros_like(lls) for _ in range(world)] if rank == 0 else None
@@ -227,7 +245,8 @@ def main():
                                    f"dt_max=1, {args.workload} (S-metric, SURVEY 8d)",
                        "pairs_per_eval": r["pairs"], "independent_streams": world},
             "roofline": {"bound": "hbm", "achieved": B / (ms_kernel * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": B / (ms_kernel * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": B / (ms_kernel * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(args.workload),
                          "algorithmic_bytes": B, "kernel_ms": ms_kernel,
                          "pair_rate_per_s": r["pairs"] / (ms_kernel * 1e-3)},
             "loglik": [float(v) for v in lls.cpu()],
