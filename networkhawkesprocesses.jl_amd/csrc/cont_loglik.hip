@@ -116,15 +116,20 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_windowed(nhp_cont_args a, int mas
     constexpr int GROUPS = NHP_BLOCK / G;
     const int gid = tid / G, gl = tid % G;
     const int nchild = it.kend - it.kbeg;
-    for (int k0 = gid; k0 < ((a.dbg & 1) ? 0 : nchild); k0 += GROUPS * U) {
+    // slot of (wave, u, group-in-wave) inside a round: a wave's U*GW children are contiguous in the
+    // round's window-sorted order
+    constexpr int GW = 64 / G;
+    const int slot0 = (gid / GW) * (GW * U) + (gid % GW);
+    for (int r0 = 0; r0 < ((a.dbg & 1) ? 0 : nchild); r0 += GROUPS * U) {
         double t[U], s[U];
-        int j[U], f[U], idx[U];
+        int j[U], f[U], idx[U], kks[U];
         bool valid[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int kk = k0 + u * GROUPS;
+            const int kk = r0 + slot0 + u * GW;
+            kks[u] = kk;
             valid[u] = kk < nchild;
-            const nhp_child ch = a.child_w[it.kbeg + (valid[u] ? kk : k0)];
+            const nhp_child ch = a.child_w[it.kbeg + (valid[u] ? kk : r0)];
             t[u] = ch.t; idx[u] = ch.idx;
             j[u] = ch.idx - 1 - gl;
             f[u] = valid[u] ? ch.first : 0x7fffffff;
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_windowed(nhp_cont_args a, int mas
             s[u] = group_sum<G>(s[u]);
             if (gl == 0 && valid[u]) {
                 const double lam = baseline_at(a, c, t[u]) + s[u];
-                lam_buf[k0 + u * GROUPS] = lam;
+                lam_buf[kks[u]] = lam;
                 if (lambda_out) lambda_out[idx[u]] = lam;
             }
         }
