@@ -153,8 +153,17 @@ def config_workloads(nhp, ctx, which):
             nhp.resample_(proc, ds, rng, step=step[0], seed=1, ctx=ctx)
             step[0] += 1
         t_g = timed(gibbs, 3)
+        import ctypes as C
+        from nhp_amd import _lib, inference
+        model, pri = proc.device_model(ctx), inference._priors(proc)
+
+        def device_sweep():
+            _lib.check(_lib.lib().nhp_cont_gibbs_step(ctx.h, ds.h, model.h, C.byref(pri), 1, step[0]), ctx.h)
+            step[0] += 1
+        t_d = timed(device_sweep, 20)
         out.append({"workload": "c3 N=1024 M=1e6 logit-normal network, mcmc! step (A fixed)",
-                    "parent_sampler_plus_stats_ms": 1e3 * t_s, "full_gibbs_step_ms": 1e3 * t_g,
+                    "device_gibbs_sweep_ms": 1e3 * t_d, "mcmc_steps_per_sec": 1.0 / t_d,
+                    "parent_sampler_plus_stats_to_host_ms": 1e3 * t_s, "host_draw_gibbs_step_ms": 1e3 * t_g,
                     "pairs": int(ds.pairs)})
     if "c4" in which:      # discrete Gaussian-basis standard Hawkes, N=512, K=8, T=1e5
         N, B, L, T = 512, 8, 32, 100_000

@@ -154,6 +154,22 @@ nhp_status nhp_cont_resample_parents(nhp_ctx *ctx, const nhp_cont_dataset *ds,
                                      const nhp_cont_model *model, const double *u,
                                      uint64_t seed, uint64_t step,
                                      int64_t *parents, int64_t *parentnodes, nhp_cont_stats *stats);
+/* One Gibbs sweep of resample!(process, data) (src/continuous.jl:202-208,350-358) entirely on the
+ * device: parents + statistics as above, then the conjugate draws of HomogeneousProcess
+ * (src/baselines.jl:72-77), DenseWeightModel (src/weights.jl:59-64) and the impulse response
+ * (src/impulses.jl:68-73 or :204-214) written straight into the device-resident model.  Draws are
+ * Philox-keyed by (seed, step, element): reproducible; distributionally (not bitwise) equal to
+ * Julia's samplers.  The adjacency matrix is left unchanged. */
+typedef struct {
+    double alpha0, beta0;    /* HomogeneousProcess.α0, β0 */
+    double kappa, nu;        /* DenseWeightModel.κ, ν */
+    double a, b;             /* ExponentialImpulseResponse.α, β  |  LogitNormalImpulseResponse.α0, β0 */
+    double mu_mu, kappa_mu;  /* LogitNormalImpulseResponse.μμ, κμ */
+} nhp_gibbs_priors;
+nhp_status nhp_cont_gibbs_step(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_model *model,
+                               const nhp_gibbs_priors *priors, uint64_t seed, uint64_t step);
+/* params(process) of the device-resident model: [λ0; θ | μ; τ; W]  src/continuous.jl:116-119 */
+nhp_status nhp_cont_model_get_params(nhp_ctx *ctx, const nhp_cont_model *model, double *x, int64_t len);
 /* the uniform stream itself (host side, same bits as the kernel draws) */
 void nhp_uniform_stream(uint64_t seed, uint64_t step, int64_t n, double *u);
 

@@ -38,6 +38,10 @@ class ModelDesc(C.Structure):
                 ("W", _dp), ("A", _dp)]
 
 
+class GibbsPriors(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("alpha0", "beta0", "kappa", "nu", "a", "b", "mu_mu", "kappa_mu")]
+
+
 class Stats(C.Structure):
     _fields_ = [("cnt0", _dp), ("Mn", _dp), ("Mnm", _dp), ("Xnm", _dp), ("Vnm", _dp)]
 
@@ -70,6 +74,8 @@ def _declare(lib):
     f("nhp_cont_loglik_enqueue", i32, _vp, _vp, _vp, i32, i32)
     f("nhp_ctx_fetch", i32, _vp, i32, i32, _dp)
     f("nhp_cont_event_intensity", i32, _vp, _vp, _vp, _dp)
+    f("nhp_cont_gibbs_step", i32, _vp, _vp, _vp, C.POINTER(GibbsPriors), u64, u64)
+    f("nhp_cont_model_get_params", i32, _vp, _vp, _dp, i64)
     f("nhp_probe_math", i32, _vp, i32, _dp, _dp, i64, _dp)
     f("nhp_probe_rate", i32, _vp, i32, i32, i32, _dp)
     for name, args in (

@@ -232,25 +232,31 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_stats(nhp_cont_args a, const int3
     }
 }
 
-extern "C" nhp_status nhp_cont_resample_parents(nhp_ctx *ctx, const nhp_cont_dataset *ds,
-                                                const nhp_cont_model *m, const double *u,
-                                                uint64_t seed, uint64_t step,
-                                                int64_t *parents, int64_t *parentnodes, nhp_cont_stats *stats)
+// Device-resident outputs of one sampler + statistics pass (all inside ctx->d_scratch).
+struct samp_out {
+    int64_t *parents, *pnodes;
+    int32_t *pn_b;
+    double *dt_b;
+    double *cnt0, *Mn, *Mnm, *X, *V;
+};
+
+static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, const double *u,
+                              uint64_t seed, uint64_t step, bool want_parents, bool want_stats, samp_out *o)
 {
-    NHP_TRY(nhp_check_pair(ctx, ds, m));
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t M = (size_t)ds->M, N = (size_t)ds->N, NN = N * N, Mp = M ? M : 1;
-    // scratch layout (8-byte aligned blocks)
     size_t off = 0;
-    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    auto carve = [&](size_t bytes) { size_t r = off; off += (bytes + 255) & ~(size_t)255; return r; };
     const size_t o_par = carve(8 * Mp), o_pno = carve(8 * Mp), o_pnb = carve(4 * Mp), o_dtb = carve(8 * Mp);
     const size_t o_u = carve(u ? 8 * Mp : 8), o_err = carve(8);
     const size_t o_cnt0 = carve(8 * N), o_Mn = carve(8 * N), o_Mnm = carve(8 * NN), o_X = carve(8 * NN), o_V = carve(8 * NN);
     NHP_TRY(nhp_ctx_reserve_scratch(ctx, off));
     char *base = (char *)ctx->d_scratch;
-    int64_t *d_par = (int64_t *)(base + o_par), *d_pno = (int64_t *)(base + o_pno);
-    int32_t *d_pnb = (int32_t *)(base + o_pnb);
-    double *d_dtb = (double *)(base + o_dtb), *d_u = u ? (double *)(base + o_u) : nullptr;
+    o->parents = (int64_t *)(base + o_par); o->pnodes = (int64_t *)(base + o_pno);
+    o->pn_b = (int32_t *)(base + o_pnb); o->dt_b = (double *)(base + o_dtb);
+    o->cnt0 = (double *)(base + o_cnt0); o->Mn = (double *)(base + o_Mn); o->Mnm = (double *)(base + o_Mnm);
+    o->X = (double *)(base + o_X); o->V = (double *)(base + o_V);
+    double *d_u = u ? (double *)(base + o_u) : nullptr;
     int *d_err = (int *)(base + o_err);
     hipStream_t st = ctx->stream;
     NHP_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(int), st));
@@ -263,31 +269,162 @@ extern "C" nhp_status nhp_cont_resample_parents(nhp_ctx *ctx, const nhp_cont_dat
     dim3 grid((unsigned)ds->n_items);
     if (m->impulse_kind == NHP_IMPULSE_EXPONENTIAL)
         hipLaunchKernelGGL((k_sampler<NHP_IMPULSE_EXPONENTIAL>), grid, dim3(NHP_BLOCK), lds, st, a, d_u, seed, step,
-                           parents ? d_par : nullptr, parentnodes ? d_pno : nullptr, d_pnb, d_dtb, d_err);
+                           want_parents ? o->parents : nullptr, want_parents ? o->pnodes : nullptr, o->pn_b, o->dt_b, d_err);
     else
         hipLaunchKernelGGL((k_sampler<NHP_IMPULSE_LOGITNORMAL>), grid, dim3(NHP_BLOCK), lds, st, a, d_u, seed, step,
-                           parents ? d_par : nullptr, parentnodes ? d_pno : nullptr, d_pnb, d_dtb, d_err);
+                           want_parents ? o->parents : nullptr, want_parents ? o->pnodes : nullptr, o->pn_b, o->dt_b, d_err);
     NHP_HIP(ctx, hipGetLastError());
+    if (want_stats) {
+        hipLaunchKernelGGL(k_stats, dim3((unsigned)N), dim3(NHP_BLOCK), 0, st, a, o->pn_b, o->dt_b, o->cnt0, o->Mn, o->Mnm, o->X, o->V);
+        NHP_HIP(ctx, hipGetLastError());
+    }
     int h_err = 0;
     NHP_HIP(ctx, hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (stats) {
-        double *d_cnt0 = (double *)(base + o_cnt0), *d_Mn = (double *)(base + o_Mn), *d_Mnm = (double *)(base + o_Mnm);
-        double *d_X = (double *)(base + o_X), *d_V = (double *)(base + o_V);
-        hipLaunchKernelGGL(k_stats, dim3((unsigned)N), dim3(NHP_BLOCK), 0, st, a, d_pnb, d_dtb, d_cnt0, d_Mn, d_Mnm, d_X, d_V);
-        NHP_HIP(ctx, hipGetLastError());
-        if (stats->cnt0) NHP_HIP(ctx, hipMemcpyAsync(stats->cnt0, d_cnt0, 8 * N, hipMemcpyDeviceToHost, st));
-        if (stats->Mn) NHP_HIP(ctx, hipMemcpyAsync(stats->Mn, d_Mn, 8 * N, hipMemcpyDeviceToHost, st));
-        if (stats->Mnm) NHP_HIP(ctx, hipMemcpyAsync(stats->Mnm, d_Mnm, 8 * NN, hipMemcpyDeviceToHost, st));
-        if (stats->Xnm) NHP_HIP(ctx, hipMemcpyAsync(stats->Xnm, d_X, 8 * NN, hipMemcpyDeviceToHost, st));
-        if (stats->Vnm && m->impulse_kind == NHP_IMPULSE_LOGITNORMAL)
-            NHP_HIP(ctx, hipMemcpyAsync(stats->Vnm, d_V, 8 * NN, hipMemcpyDeviceToHost, st));
-    }
-    if (parents && M) NHP_HIP(ctx, hipMemcpyAsync(parents, d_par, 8 * M, hipMemcpyDeviceToHost, st));
-    if (parentnodes && M) NHP_HIP(ctx, hipMemcpyAsync(parentnodes, d_pno, 8 * M, hipMemcpyDeviceToHost, st));
     NHP_HIP(ctx, hipStreamSynchronize(st));
     if (h_err) {
         nhp_set_error(ctx, "resample_parents: weights of some event do not sum to a positive finite value");
         return NHP_EDOMAIN;
     }
+    return NHP_OK;
+}
+
+extern "C" nhp_status nhp_cont_resample_parents(nhp_ctx *ctx, const nhp_cont_dataset *ds,
+                                                const nhp_cont_model *m, const double *u,
+                                                uint64_t seed, uint64_t step,
+                                                int64_t *parents, int64_t *parentnodes, nhp_cont_stats *stats)
+{
+    NHP_TRY(nhp_check_pair(ctx, ds, m));
+    samp_out o;
+    NHP_TRY(run_sampler(ctx, ds, m, u, seed, step, parents || parentnodes, stats != nullptr, &o));
+    const size_t M = (size_t)ds->M, N = (size_t)ds->N, NN = N * N;
+    hipStream_t st = ctx->stream;
+    if (stats) {
+        if (stats->cnt0) NHP_HIP(ctx, hipMemcpyAsync(stats->cnt0, o.cnt0, 8 * N, hipMemcpyDeviceToHost, st));
+        if (stats->Mn) NHP_HIP(ctx, hipMemcpyAsync(stats->Mn, o.Mn, 8 * N, hipMemcpyDeviceToHost, st));
+        if (stats->Mnm) NHP_HIP(ctx, hipMemcpyAsync(stats->Mnm, o.Mnm, 8 * NN, hipMemcpyDeviceToHost, st));
+        if (stats->Xnm) NHP_HIP(ctx, hipMemcpyAsync(stats->Xnm, o.X, 8 * NN, hipMemcpyDeviceToHost, st));
+        if (stats->Vnm && m->impulse_kind == NHP_IMPULSE_LOGITNORMAL)
+            NHP_HIP(ctx, hipMemcpyAsync(stats->Vnm, o.V, 8 * NN, hipMemcpyDeviceToHost, st));
+    }
+    if (parents && M) NHP_HIP(ctx, hipMemcpyAsync(parents, o.parents, 8 * M, hipMemcpyDeviceToHost, st));
+    if (parentnodes && M) NHP_HIP(ctx, hipMemcpyAsync(parentnodes, o.pnodes, 8 * M, hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipStreamSynchronize(st));
+    return NHP_OK;
+}
+
+// ---- device-side conjugate draws (reference resample! bodies: src/baselines.jl:72-77,
+// src/weights.jl:59-64, src/impulses.jl:68-73,204-214).  Counter-based: element e of draw family
+// `fam` at chain step `step` consumes Philox counters (e, attempt) under key (seed ^ fam-constant,
+// step), so a chain is reproducible on the device and independent of launch geometry.  Julia's
+// samplers cannot be matched bit for bit ([3P] Distributions / Random); parity is distributional.
+__device__ __forceinline__ void philox_2u(uint64_t key, uint64_t step, uint64_t e, uint32_t attempt, double *ua, double *ub)
+{
+    uint32_t c0 = (uint32_t)e, c1 = (uint32_t)(e >> 32) ^ (attempt << 8), c2 = (uint32_t)step, c3 = (uint32_t)(step >> 32);
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    // (0,1]: never 0, so log() below is finite
+    *ua = ((double)((((uint64_t)c0 << 32) | c1) >> 11) + 1.0) * 1.1102230246251565e-16;
+    *ub = ((double)((((uint64_t)c2 << 32) | c3) >> 11) + 1.0) * 1.1102230246251565e-16;
+}
+
+__device__ __forceinline__ double dev_normal(uint64_t key, uint64_t step, uint64_t e, uint32_t attempt)
+{
+    double ua, ub;
+    philox_2u(key, step, e, attempt, &ua, &ub);
+    return sqrt(-2.0 * log(ua)) * cos(6.283185307179586 * ub);          // Box-Muller
+}
+
+// Gamma(shape, scale) by Marsaglia & Tsang (2000); shape < 1 via Gamma(shape+1)·U^(1/shape).
+__device__ double dev_gamma(double shape, double scale, uint64_t key, uint64_t step, uint64_t e)
+{
+    double boost = 1.0;
+    uint32_t attempt = 0;
+    if (shape < 1.0) {
+        double ua, ub;
+        philox_2u(key, step, e, attempt++, &ua, &ub);
+        boost = pow(ua, 1.0 / shape);
+        shape += 1.0;
+    }
+    const double d = shape - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (;;) {
+        const double x = dev_normal(key, step, e, attempt++);
+        double ua, ub;
+        philox_2u(key, step, e, attempt++, &ua, &ub);
+        const double t = 1.0 + c * x, v = t * t * t;
+        if (v > 0.0 && log(ua) < 0.5 * x * x + d - d * v + d * log(v)) return d * v * scale * boost;
+        if (attempt > 200) return d * scale * boost;                       // unreachable in practice
+    }
+}
+
+struct gibbs_priors { double alpha0, beta0, kappa, nu, a, b, mu_mu, kappa_mu; };
+
+__global__ __launch_bounds__(256) void k_gibbs_draw(int N, int impulse_kind, double duration, gibbs_priors pr,
+                                                    uint64_t seed, uint64_t step,
+                                                    const double *__restrict__ cnt0, const double *__restrict__ Mn,
+                                                    const double *__restrict__ Mnm, const double *__restrict__ X,
+                                                    const double *__restrict__ V, double *__restrict__ lambda0,
+                                                    double *__restrict__ p1, double *__restrict__ p2, double *__restrict__ W)
+{
+    const size_t NN = (size_t)N * N;
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < (size_t)N)      // λ0_c ~ Gamma(α0 + cnt0_c, 1/(β0 + T))
+        lambda0[k] = dev_gamma(pr.alpha0 + cnt0[k], 1.0 / (pr.beta0 + duration), seed ^ 0x243F6A8885A308D3ull, step, k);
+    if (k >= NN) return;
+    const double m = Mnm[k];
+    // W[p,c] ~ Gamma(κ + Mnm, 1/(ν + Mn[p]))
+    W[k] = dev_gamma(pr.kappa + m, 1.0 / (pr.nu + Mn[k % N]), seed ^ 0x13198A2E03707344ull, step, k);
+    if (impulse_kind == NHP_IMPULSE_EXPONENTIAL) {
+        // θ ~ Gamma(α + Mnm, 1/(β + Mnm·Xnm))      (Xnm = 0 where Mnm = 0)
+        p1[k] = dev_gamma(pr.a + m, 1.0 / (pr.b + m * X[k]), seed ^ 0xA4093822299F31D0ull, step, k);
+    } else {
+        // τ ~ Gamma(α0 + Mnm/2, 1/βnm),  μ ~ Normal(μnm, ((κμ + Mnm)τ)^-½); NaN (no observations) -> prior
+        const double x = X[k];
+        double bnm = 0.5 * V[k] + m * pr.kappa_mu / (m + pr.kappa_mu) * (x - pr.mu_mu) * (x - pr.mu_mu) * 0.5;
+        if (bnm != bnm) bnm = pr.b;
+        double mnm = (pr.kappa_mu * pr.mu_mu + m * x) / (pr.kappa_mu + m);
+        if (mnm != mnm) mnm = pr.mu_mu;
+        const double tau = dev_gamma(pr.a + 0.5 * m, 1.0 / bnm, seed ^ 0x082EFA98EC4E6C89ull, step, k);
+        p2[k] = tau;
+        p1[k] = mnm + dev_normal(seed ^ 0x452821E638D01377ull, step, k, 0) / sqrt((pr.kappa_mu + m) * tau);
+    }
+}
+
+extern "C" nhp_status nhp_cont_gibbs_step(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_model *m,
+                                          const nhp_gibbs_priors *pr, uint64_t seed, uint64_t step)
+{
+    NHP_TRY(nhp_check_pair(ctx, ds, m));
+    if (!pr) return NHP_EINVAL;
+    if (m->baseline_kind != NHP_BASELINE_HOMOGENEOUS) { nhp_set_error(ctx, "gibbs_step: homogeneous baseline only"); return NHP_ENOTIMPL; }
+    samp_out o;
+    NHP_TRY(run_sampler(ctx, ds, m, nullptr, seed, step, false, true, &o));
+    gibbs_priors g{pr->alpha0, pr->beta0, pr->kappa, pr->nu, pr->a, pr->b, pr->mu_mu, pr->kappa_mu};
+    const size_t NN = (size_t)ds->N * ds->N;
+    hipLaunchKernelGGL(k_gibbs_draw, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, ctx->stream, ds->N, m->impulse_kind,
+                       ds->duration, g, seed, step, o.cnt0, o.Mn, o.Mnm, o.X, o.V, m->d_lambda0, m->d_p1, m->d_p2, m->d_W);
+    NHP_HIP(ctx, hipGetLastError());
+    return NHP_OK;
+}
+
+// params(process) of the device-resident model, standard order [λ0; θ | μ; τ; W]
+extern "C" nhp_status nhp_cont_model_get_params(nhp_ctx *ctx, const nhp_cont_model *m, double *x, int64_t len)
+{
+    if (!ctx || !m || !x) return NHP_EINVAL;
+    if (m->baseline_kind != NHP_BASELINE_HOMOGENEOUS) return NHP_ENOTIMPL;
+    const size_t N = (size_t)m->N, NN = N * N;
+    const size_t nimp = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? NN : 2 * NN;
+    if ((size_t)len != N + nimp + NN) { nhp_set_error(ctx, "Parameter vector length does not match model parameter length."); return NHP_ESHAPE; }
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    NHP_HIP(ctx, hipMemcpyAsync(x, m->d_lambda0, 8 * N, hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipMemcpyAsync(x + N, m->d_p1, 8 * NN, hipMemcpyDeviceToHost, st));
+    if (m->impulse_kind == NHP_IMPULSE_LOGITNORMAL) NHP_HIP(ctx, hipMemcpyAsync(x + N + NN, m->d_p2, 8 * NN, hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipMemcpyAsync(x + N + nimp, m->d_W, 8 * NN, hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipStreamSynchronize(st));
     return NHP_OK;
 }

@@ -139,12 +139,36 @@ def resample_(process, data, rng, step=0, seed=0, ctx=None):
     return process.params()
 
 
-def mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, keep_samples=True, ctx=None):
+def _priors(process):
+    b, w, imp = process.baseline, process.weights, process.impulses
+    if isinstance(imp, ExponentialImpulseResponse):
+        return _lib.GibbsPriors(b.α0, b.β0, w.κ, w.ν, imp.α, imp.β, 0.0, 1.0)
+    return _lib.GibbsPriors(b.α0, b.β0, w.κ, w.ν, imp.α0, imp.β0, imp.μμ, imp.κμ)
+
+
+def _pull_params(process, model, ctx):
+    """Copy the device-resident parameters back into the component structs (in-place semantics of
+    the reference: "all inference methods overwrite model parameters", docs/src/index.md:109-111)."""
+    import ctypes as C
+    N = process.ndims()
+    nimp = N * N * (1 if isinstance(process.impulses, ExponentialImpulseResponse) else 2)
+    x = np.empty(N + nimp + N * N)
+    _lib.check(_lib.lib().nhp_cont_model_get_params(ctx.h, model.h, _lib.dptr(x), len(x)), ctx.h)
+    process.baseline.λ = x[:N].copy()
+    process.impulses.params_(x[N:N + nimp])
+    process.weights.params_(x[N + nimp:])
+
+
+def mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, keep_samples=True, device_draws=True,
+          ctx=None):
     """mcmc!(process, data; nsteps, log_freq, verbose) -- src/inference.jl:49-70.
 
-    `seed` keys both the device-side Philox stream of the parent sampler (counter = step, event)
-    and the host generator of the conjugate draws, so a chain is reproducible and chains with
+    With `device_draws` (default) a whole sweep -- parents, statistics, conjugate draws -- stays on
+    the GPU (nhp_cont_gibbs_step): parameters never cross PCIe unless samples are kept.  With
+    device_draws=False the statistics come back and numpy draws the parameters (same
+    distributions).  `seed` keys every random stream, so a chain is reproducible and chains with
     different seeds are independent (one per GPU: chains.py)."""
+    import ctypes as C
     if not isinstance(process.baseline, HomogeneousProcess):
         raise NotImplementedError("mcmc!: LGCP baseline resampling (src/baselines.jl:212-326) is out of scope")
     ctx = ctx or _lib.default_context()
@@ -152,8 +176,18 @@ def mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, keep_
     rng = np.random.default_rng(seed)
     res = MarkovChainMonteCarlo()
     start = time.time()
+    model = process.device_model(ctx) if device_draws else None
+    pri = _priors(process) if device_draws else None
     while res.steps < nsteps:
-        x = resample_(process, ds, rng, step=res.steps, seed=seed, ctx=ctx)
+        if device_draws:
+            _lib.check(_lib.lib().nhp_cont_gibbs_step(ctx.h, ds.h, model.h, C.byref(pri), seed, res.steps), ctx.h)
+            if isinstance(process, ContinuousNetworkHawkesProcess):
+                process.network.resample_(process.adjacency_matrix, rng)
+            if keep_samples or res.steps == nsteps - 1:
+                _pull_params(process, model, ctx)
+            x = process.params() if keep_samples else None
+        else:
+            x = resample_(process, ds, rng, step=res.steps, seed=seed, ctx=ctx)
         if keep_samples:
             res.samples.append(x)
         res.steps += 1

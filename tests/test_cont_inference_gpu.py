@@ -92,6 +92,41 @@ def test_mcmc_runs_and_is_reproducible(nhp):
     assert all(np.all(np.isfinite(s)) for s in r1.samples)
 
 
+def test_device_draws_match_their_distributions(nhp):
+    # one device sweep on a model whose statistics we also fetch: the N² conjugate draws must have the
+    # moments of Gamma(shape, scale) / Normal the reference's resample! bodies prescribe
+    import ctypes as C
+    from nhp_amd import _lib, inference
+    N = 48
+    c = random_case(N, 40000, 2000.0, "logitnormal", 1.0, seed=31, nhp=nhp)
+    proc, ctx = c["proc"], nhp.default_context()
+    ds = nhp.device_dataset(proc, c["data"], ctx)
+    _, _, st = nhp.resample_parents(proc, ds, seed=9, step=4, with_stats=True, want_parents=False)
+    model = proc.device_model(ctx)
+    pri = inference._priors(proc)
+    _lib.check(_lib.lib().nhp_cont_gibbs_step(ctx.h, ds.h, model.h, C.byref(pri), 9, 4), ctx.h)
+    inference._pull_params(proc, model, ctx)
+    Mnm, Mn, X, V = st["Mnm"], st["Mn"], st["Xnm"], st["Vnm"]
+    # W ~ Gamma(κ + Mnm, 1/(ν + Mn[p])): standardised draws have mean 0, variance 1
+    shape, rate = 1.0 + Mnm, (1.0 + Mn)[:, None] * np.ones((N, N))
+    z = (proc.weights.W - shape / rate) / (np.sqrt(shape) / rate)
+    assert abs(z.mean()) < 4 / N and abs(z.var() - 1.0) < 0.15
+    lam_shape, lam_rate = 1.0 + st["cnt0"], 1.0 + c["T"]
+    zl = (proc.baseline.λ - lam_shape / lam_rate) / (np.sqrt(lam_shape) / lam_rate)
+    assert abs(zl.mean()) < 0.6 and 0.4 < zl.var() < 2.0
+    with np.errstate(invalid="ignore"):
+        bnm = V / 2 + Mnm * 1.0 / (Mnm + 1.0) * (X - 1.0) ** 2 / 2
+        bnm[np.isnan(bnm)] = 1.0
+        mnm = (1.0 + Mnm * X) / (1.0 + Mnm)
+        mnm[np.isnan(mnm)] = 1.0
+    tshape = 1.0 + Mnm / 2
+    zt = (proc.impulses.τ - tshape / bnm) / (np.sqrt(tshape) / bnm)
+    assert abs(zt.mean()) < 4 / N and abs(zt.var() - 1.0) < 0.15
+    zm = (proc.impulses.μ - mnm) * np.sqrt((1.0 + Mnm) * proc.impulses.τ)
+    assert abs(zm.mean()) < 4 / N and abs(zm.var() - 1.0) < 0.1
+    assert np.all(proc.weights.W > 0) and np.all(proc.impulses.τ > 0)
+
+
 def test_mcmc_posterior_concentrates(nhp):
     # exponential standard process, data simulated from known parameters: posterior means land near them
     lam0, W, th = np.array([0.8, 1.2]), np.array([[0.3, 0.1], [0.05, 0.25]]), np.full((2, 2), 2.0)
@@ -99,7 +134,9 @@ def test_mcmc_posterior_concentrates(nhp):
     proc = nhp.ContinuousStandardHawkesProcess(nhp.HomogeneousProcess(np.ones(2)),
                                                nhp.ExponentialImpulseResponse(np.ones((2, 2)), 1.0, 1.0, 10.0),
                                                nhp.DenseWeightModel(0.5 * np.ones((2, 2))))
-    res = nhp.mcmc_(proc, data, nsteps=300, seed=1)
-    post = np.mean(res.samples[100:], axis=0)
-    assert np.all(np.abs(post[:2] - lam0) < 0.12)
-    assert np.all(np.abs(post[6:].reshape((2, 2), order="F") - W) < 0.08)
+    for device_draws in (True, False):
+        proc.params_(np.concatenate([np.ones(2), np.ones(4), 0.5 * np.ones(4)]))
+        res = nhp.mcmc_(proc, data, nsteps=300, seed=1, device_draws=device_draws)
+        post = np.mean(res.samples[100:], axis=0)
+        assert np.all(np.abs(post[:2] - lam0) < 0.12)
+        assert np.all(np.abs(post[6:].reshape((2, 2), order="F") - W) < 0.08)
