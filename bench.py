@@ -161,8 +161,14 @@ def config_workloads(nhp, ctx, which):
             _lib.check(_lib.lib().nhp_cont_gibbs_step(ctx.h, ds.h, model.h, C.byref(pri), 1, step[0]), ctx.h)
             step[0] += 1
         t_d = timed(device_sweep, 20)
-        out.append({"workload": "c3 N=1024 M=1e6 logit-normal network, mcmc! step (A fixed)",
-                    "device_gibbs_sweep_ms": 1e3 * t_d, "mcmc_steps_per_sec": 1.0 / t_d,
+
+        def adjacency():
+            inference.resample_adjacency_matrix_(proc, ds, seed=1, step=step[0], model=model, fetch=False, ctx=ctx)
+            step[0] += 1
+        t_a = timed(adjacency, 5)
+        out.append({"workload": "c3 N=1024 M=1e6 logit-normal network, mcmc! step",
+                    "device_gibbs_sweep_ms": 1e3 * t_d, "adjacency_sweep_ms": 1e3 * t_a,
+                    "mcmc_steps_per_sec": 1.0 / (t_d + t_a),
                     "parent_sampler_plus_stats_to_host_ms": 1e3 * t_s, "host_draw_gibbs_step_ms": 1e3 * t_g,
                     "pairs": int(ds.pairs)})
     if "c4" in which:      # discrete Gaussian-basis standard Hawkes, N=512, K=8, T=1e5

@@ -168,6 +168,15 @@ typedef struct {
 } nhp_gibbs_priors;
 nhp_status nhp_cont_gibbs_step(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_model *model,
                                const nhp_gibbs_priors *priors, uint64_t seed, uint64_t step);
+/* resample_adjacency_matrix!(process, data)  src/continuous.jl:444-487: one Gibbs sweep over the
+ * N x N adjacency matrix of the device-resident model (updated in place).  Link probabilities
+ * (src/networks.jl:65-68): `rho_matrix` [N*N] if non-NULL, else the scalar `rho`.  Bernoulli draws
+ * (u <= p, as Distributions.jl) use `u` [N*N] if non-NULL, else Philox keyed (seed, step, p + c*N).
+ * A_out (nullable) receives the new matrix, n_links (nullable) its number of ones (the statistic
+ * BernoulliNetworkModel's resample! needs, src/networks.jl:70-78). */
+nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_model *model,
+                                       const double *rho_matrix, double rho, const double *u,
+                                       uint64_t seed, uint64_t step, double *A_out, double *n_links);
 /* params(process) of the device-resident model: [λ0; θ | μ; τ; W]  src/continuous.jl:116-119 */
 nhp_status nhp_cont_model_get_params(nhp_ctx *ctx, const nhp_cont_model *model, double *x, int64_t len);
 /* the uniform stream itself (host side, same bits as the kernel draws) */

@@ -19,7 +19,7 @@ from .discrete import (DiscreteDataset, DiscreteGaussianImpulseResponse, Discret
 from . import discrete as _disc
 from .parents import node_counts, parent_counts, resample_parents, uniform_stream  # noqa: F401
 from .inference import (MarkovChainMonteCarlo, MaximumLikelihood, logprior, mcmc_, mle_,  # noqa: F401
-                        resample_)
+                        resample_, resample_adjacency_matrix_)
 from . import synthetic  # noqa: F401
 
 

@@ -232,6 +232,9 @@ class DenseNetworkModel(Network):
     def resample_(self, A, rng):
         return None
 
+    def resample_links_(self, nlinks, size, rng):
+        return None
+
 
 class BernoulliNetworkModel(Network):
     """BernoulliNetworkModel(ρ, N) with Beta(α, β) prior -- src/networks.jl:34-78."""
@@ -250,6 +253,8 @@ class BernoulliNetworkModel(Network):
 
     def resample_(self, A, rng):
         """resample!: ρ ~ Beta(α + ΣA, β + N² - ΣA) -- src/networks.jl:70-78"""
-        s = float(np.sum(A))
-        self.ρ = rng.beta(self.α + s, self.β + A.size - s)
+        return self.resample_links_(float(np.sum(A)), A.size, rng)
+
+    def resample_links_(self, nlinks, size, rng):
+        self.ρ = rng.beta(self.α + nlinks, self.β + size - nlinks)
         return self.ρ

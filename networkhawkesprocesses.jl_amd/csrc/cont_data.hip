@@ -73,6 +73,9 @@ extern "C" nhp_status nhp_cont_dataset_create(nhp_ctx *ctx, const double *events
         pairs += i - f;
     }
     ds->pairs = pairs;
+    ds->h_pair_off.assign((size_t)N + 1, 0);
+    for (int64_t i = 0; i < M; ++i) ds->h_pair_off[node32[i] + 1] += i - first[i];
+    for (int32_t c = 0; c < N; ++c) ds->h_pair_off[c + 1] += ds->h_pair_off[c];
     ds->group = pick_group(M > 0 ? (double)pairs / (double)M : 0.0);
 
     // stable counting sort of children by node

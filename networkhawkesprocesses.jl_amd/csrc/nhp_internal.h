@@ -69,6 +69,7 @@ struct nhp_cont_dataset {
     // host copies kept for host-side helpers
     std::vector<int32_t> h_boff;
     std::vector<double> h_cnt;
+    std::vector<int64_t> h_pair_off;    // [N+1] prefix of window pairs per child node (adjacency sweep scratch)
 };
 
 struct nhp_cont_model {

@@ -120,12 +120,34 @@ def mle_(process, data, optimizer="L-BFGS-B", verbose=False, f_abstol=1e-6, regu
                              "success" if (state["converged"] or res.success) else "failure")
 
 
+def resample_adjacency_matrix_(process, data, u=None, seed=0, step=0, model=None, fetch=True, ctx=None):
+    """resample_adjacency_matrix!(process, data) -- src/continuous.jl:444-470: one Gibbs sweep of the
+    adjacency matrix, columns in parallel, entries of a column in sequence (resample_column! :472-487).
+    `u` (N x N, [parent, child]) supplies the Bernoulli uniforms explicitly; otherwise they come from
+    Philox keyed (seed, step).  Updates process.adjacency_matrix in place and returns the link count."""
+    import ctypes as C
+    ctx = ctx or _lib.default_context()
+    ds = device_dataset(process, data, ctx)
+    model = model or process.device_model(ctx)
+    N = process.ndims()
+    link = np.asarray(process.network.link_probability(), dtype=np.float64)
+    scalar = float(link.flat[0]) if np.all(link == link.flat[0]) else None
+    rho_m = None if scalar is not None else _lib.colmajor(link)
+    uu = None if u is None else _lib.colmajor(np.asarray(u, dtype=np.float64))
+    A = np.empty(N * N) if fetch else None
+    nl = C.c_double()
+    _lib.check(_lib.lib().nhp_cont_resample_adjacency(ctx.h, ds.h, model.h, _lib.dptr(rho_m), scalar if scalar is not None else 0.5,
+                                                      _lib.dptr(uu), seed, step, _lib.dptr(A), C.byref(nl)), ctx.h)
+    if fetch:
+        process.adjacency_matrix = A.reshape((N, N), order="F")
+    return nl.value
+
+
 def resample_(process, data, rng, step=0, seed=0, ctx=None):
     """resample!(process, data) -- src/continuous.jl:202-208,350-358: one Gibbs sweep.
 
     Parents and every sufficient statistic come from one GPU call; the conjugate draws are host
-    numpy.  For the network process the adjacency matrix is held fixed (its Gibbs update,
-    src/continuous.jl:444-519, is the first "next" row of SURVEY.md 8f) and only ρ is redrawn."""
+    numpy; the network process then resamples its adjacency matrix on the GPU and redraws ρ."""
     _, _, st = resample_parents(process, data, seed=seed, step=step, with_stats=True, want_parents=False, ctx=ctx)
     duration = data.duration if hasattr(data, "duration") else data[2]
     process.baseline.resample_(st["cnt0"], duration, rng)
@@ -135,6 +157,7 @@ def resample_(process, data, rng, step=0, seed=0, ctx=None):
     else:
         process.impulses.resample_(st["Mnm"], st["Xnm"], st["Vnm"], rng)
     if isinstance(process, ContinuousNetworkHawkesProcess):
+        resample_adjacency_matrix_(process, data, seed=seed, step=step, ctx=ctx)
         process.network.resample_(process.adjacency_matrix, rng)
     return process.params()
 
@@ -182,7 +205,9 @@ def mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, keep_
         if device_draws:
             _lib.check(_lib.lib().nhp_cont_gibbs_step(ctx.h, ds.h, model.h, C.byref(pri), seed, res.steps), ctx.h)
             if isinstance(process, ContinuousNetworkHawkesProcess):
-                process.network.resample_(process.adjacency_matrix, rng)
+                last = keep_samples or res.steps == nsteps - 1
+                links = resample_adjacency_matrix_(process, ds, seed=seed, step=res.steps, model=model, fetch=last, ctx=ctx)
+                process.network.resample_links_(links, process.ndims() ** 2, rng)
             if keep_samples or res.steps == nsteps - 1:
                 _pull_params(process, model, ctx)
             x = process.params() if keep_samples else None

@@ -446,6 +446,64 @@ void orc_log_duration_stats(const double *times, const int64_t *nodes, const int
     free(Mnm);
 }
 
+/* ------------------------------------------------------------------ adjacency Gibbs
+ * resample_adjacency_matrix! / resample_column!: src/continuous.jl:444-487.
+ * integrated_intensity(process, node, nodecounts, duration): :489-498.
+ * sum_log_intensity: :500-519 -- note `index == 1 && continue` sits AFTER λ0 is read, so the very
+ * first event's log λ0 is dropped from the sum (cancels between ll0 and ll1). */
+static double adj_sum_log_intensity(const orc_cont_model *m, const double *times, const int64_t *nodes,
+                                    int64_t M, int32_t node0)
+{
+    double S = 0.0;
+    for (int64_t i = 0; i < M; ++i) {
+        if (nodes[i] - 1 != node0) continue;
+        if (i == 0) continue;
+        double lam;
+        if (total_intensity(m, times, nodes, i, 0, &lam)) return NAN;
+        S += log(lam);
+    }
+    return S;
+}
+
+static double adj_integrated_intensity(const orc_cont_model *m, int32_t node0, const double *cnt, double duration)
+{
+    double I;
+    if (m->baseline_kind == ORC_BASELINE_HOMOGENEOUS) I = m->lambda0[node0] * duration;
+    else I = orc_linear_integrate(m->grid_x, m->lambda0 + (size_t)node0 * m->grid_n, m->grid_n);
+    for (int32_t p = 0; p < m->n_nodes; ++p)
+        I += m->A[IDX(p, node0, m->n_nodes)] * m->W[IDX(p, node0, m->n_nodes)] * cnt[p];
+    return I;
+}
+
+int orc_cont_resample_adjacency(const orc_cont_model *m, const double *times, const int64_t *nodes,
+                                int64_t M, double duration, const double *rho, const double *u, double *A)
+{
+    int rc = validate_data(m, times, nodes, M);
+    if (rc) return rc;
+    int32_t N = m->n_nodes;
+    orc_cont_model w = *m;
+    w.A = A;                                             /* work on the caller's matrix in place */
+    double *cnt = (double *)malloc(sizeof(double) * (size_t)N);
+    orc_node_counts(nodes, M, N, cnt);
+    for (int32_t c = 0; c < N; ++c)
+        for (int32_t p = 0; p < N; ++p) {
+            size_t k = IDX(p, c, N);
+            A[k] = 0.0;
+            double ll0 = -adj_integrated_intensity(&w, c, cnt, duration);
+            ll0 += adj_sum_log_intensity(&w, times, nodes, M, c);
+            ll0 += log(1.0 - rho[k]);
+            A[k] = 1.0;
+            double ll1 = -adj_integrated_intensity(&w, c, cnt, duration);
+            ll1 += adj_sum_log_intensity(&w, times, nodes, M, c);
+            ll1 += log(rho[k]);
+            double mx = ll0 > ll1 ? ll0 : ll1;
+            double Z = mx + log(exp(ll0 - mx) + exp(ll1 - mx));
+            A[k] = (u[k] <= exp(ll1 - Z)) ? 1.0 : 0.0;
+        }
+    free(cnt);
+    return ORC_OK;
+}
+
 /* ------------------------------------------------------------------ analytic gradient
  * No reference code: the reference hands Optim no gradient (src/continuous.jl:190), so one
  * gradient costs it 2P objective calls.  Formulas from SURVEY.md 7; validated in tests/ by

@@ -87,6 +87,13 @@ void orc_duration_mean(const double *times, const int64_t *nodes, const int64_t 
 void orc_log_duration_stats(const double *times, const int64_t *nodes, const int64_t *parents,
                             int64_t M, int32_t N, double dt_max, double *Xnm, double *Vnm);
 
+/* ---- adjacency-matrix Gibbs sweep (src/continuous.jl:444-519; logsumexp src/utils/helpers.jl:13-16;
+ * link_probability src/networks.jl:65-68).  A (N*N, 0/1 doubles) is updated in place, column by
+ * column, parent by parent; u[p + c*N] is the explicit uniform of the Bernoulli draw
+ * ([3P] Distributions: rand(Bernoulli(q)) = rand() <= q); rho[p + c*N] the link probability. */
+int orc_cont_resample_adjacency(const orc_cont_model *m, const double *times, const int64_t *nodes,
+                                int64_t M, double duration, const double *rho, const double *u, double *A);
+
 /* ---- analytic gradient of the continuous ll (formulas: SURVEY.md 7; no reference code) */
 int orc_cont_loglik_grad(const orc_cont_model *m, const double *times, const int64_t *nodes,
                          int64_t M, double duration, int recursive, double *ll, double *grad);

@@ -219,6 +219,15 @@ def log_duration_stats(times, nodes, parents, N, dt_max):
     return X.T.copy(), V.T.copy()
 
 
+def resample_adjacency(model, times, nodes, duration, rho, u):
+    """One sweep of resample_adjacency_matrix!; rho, u: N x N arrays indexed [parent, child].  Returns the new A."""
+    t, n, tp, np_, M = _data(times, nodes)
+    A = _col(model.A).copy()
+    r, uu = _col(np.broadcast_to(rho, model.A.shape)), _col(u)
+    _chk(lib().orc_cont_resample_adjacency(C.byref(model.c), tp, np_, M, C.c_double(duration), _p(r), _p(uu), _p(A)))
+    return A.reshape(model.A.shape, order="F")
+
+
 def loglik_grad(model, times, nodes, duration, recursive=False):
     t, n, tp, np_, M = _data(times, nodes)
     N = model.N

@@ -140,3 +140,43 @@ def test_mcmc_posterior_concentrates(nhp):
         post = np.mean(res.samples[100:], axis=0)
         assert np.all(np.abs(post[:2] - lam0) < 0.12)
         assert np.all(np.abs(post[6:].reshape((2, 2), order="F") - W) < 0.08)
+
+
+@pytest.mark.parametrize("kind,lgcp", [("exponential", False), ("logitnormal", False), ("exponential", True)])
+def test_adjacency_gibbs_matches_oracle(nhp, orc, kind, lgcp):
+    # resample_adjacency_matrix! (src/continuous.jl:444-519) with explicit Bernoulli uniforms: the
+    # GPU sweep (every pair evaluated once, incremental λ updates) must take the same N² decisions as
+    # the oracle's literal restatement (two full event scans per entry)
+    N = 7
+    c = random_case(N, 1500, 120.0, kind, 1.5, network=True, lgcp=lgcp, seed=41, nhp=nhp, orc=orc)
+    u = np.random.default_rng(3).uniform(size=(N, N))
+    c["proc"].network.ρ = 0.35
+    want = orc.resample_adjacency(c["om"], c["times"], c["nodes"], c["T"], 0.35, u)
+    links = nhp.resample_adjacency_matrix_(c["proc"], c["data"], u=u)
+    assert np.array_equal(c["proc"].adjacency_matrix, want)
+    assert links == want.sum()
+    assert 0 < want.sum() < N * N                                    # a non-trivial draw
+    # ρ = 1 (DenseNetworkModel): log(1-ρ) = -Inf -> every link present
+    c["proc"].network = nhp.DenseNetworkModel(N)
+    nhp.resample_adjacency_matrix_(c["proc"], c["data"], u=u)
+    assert np.all(c["proc"].adjacency_matrix == 1.0)
+
+
+def test_network_mcmc_recovers_structure(nhp):
+    # two blocks: node 1 excites node 2 strongly, nothing else; the adjacency posterior should find it
+    lam0 = np.array([1.0, 0.2, 0.5])
+    W = np.array([[0.0, 0.8, 0.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.0]])
+    th = np.full((3, 3), 3.0)
+    data = nhp.synthetic.branching_sample(lam0, W, th, 2500.0, seed=5)
+    proc = nhp.ContinuousNetworkHawkesProcess(nhp.HomogeneousProcess(np.ones(3)),
+                                              nhp.ExponentialImpulseResponse(np.ones((3, 3)), 1.0, 1.0, 5.0),
+                                              nhp.DenseWeightModel(0.3 * np.ones((3, 3))), np.ones((3, 3)),
+                                              nhp.BernoulliNetworkModel(0.5, 3))
+    res = nhp.mcmc_(proc, data, nsteps=250, seed=2)
+    S = np.array(res.samples[80:])
+    A_mean = S[:, -9:].mean(axis=0).reshape((3, 3), order="F")
+    W_mean = S[:, 4:13].mean(axis=0).reshape((3, 3), order="F")
+    assert A_mean[0, 1] > 0.95 and (A_mean * W_mean)[0, 1] > 0.5
+    eff = A_mean * W_mean
+    eff[0, 1] = 0.0
+    assert eff.max() < 0.15
