@@ -120,7 +120,7 @@ extern "C" nhp_status nhp_cont_dataset_create(nhp_ctx *ctx, const double *events
     // order (48.8 us).  The sum does not depend on the order and the order is fixed: deterministic.
     std::vector<nhp_child> child_w(child);
     {
-        const int G = ds->group, U = G <= 8 ? 4 : (G <= 32 ? 2 : 1);
+        const int G = ds->group, U = G <= 8 ? NHP_U_SMALL : (G <= 32 ? NHP_U_MID : 1);
         const int round = (NHP_BLOCK / G) * U;
         const char *flat = getenv("NHP_SORT");
         const int mode = flat ? atoi(flat) : 2;

@@ -249,7 +249,7 @@ static void launch_group(int G, dim3 grid, size_t lds, hipStream_t st, const nhp
                            lambda_out, counter, out);                                                         \
         break;
     switch (G) {
-        NHP_CASE(1, 4) NHP_CASE(2, 4) NHP_CASE(4, 4) NHP_CASE(8, 4) NHP_CASE(16, 2) NHP_CASE(32, 2)
+        NHP_CASE(1, NHP_U_SMALL) NHP_CASE(2, NHP_U_SMALL) NHP_CASE(4, NHP_U_SMALL) NHP_CASE(8, NHP_U_SMALL) NHP_CASE(16, NHP_U_MID) NHP_CASE(32, NHP_U_MID)
     default:
         hipLaunchKernelGGL((k_windowed<IMP, 64, 1>), grid, dim3(NHP_BLOCK), lds, st, a, mask, partials, lambda_out, counter, out);
     }

@@ -10,6 +10,13 @@
 
 #define NHP_BLOCK 256          // 4 waves of 64 lanes
 #define NHP_WAVES (NHP_BLOCK / 64)
+// children a group keeps in flight in the windowed kernels (host sorting and kernel must agree)
+#ifndef NHP_U_SMALL
+#define NHP_U_SMALL 4   // G <= 8
+#endif
+#ifndef NHP_U_MID
+#define NHP_U_MID 4     // G = 16, 32 (tools/uvar.sh: 4 beats 2 by 5-8 % at K=64, 512)
+#endif
 
 struct nhp_ctx {
     int device = 0;
