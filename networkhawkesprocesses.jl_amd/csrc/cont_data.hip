@@ -121,7 +121,7 @@ extern "C" nhp_status nhp_cont_dataset_create(nhp_ctx *ctx, const double *events
     std::vector<nhp_child> child_w(child);
     {
         const int G = ds->group, U = G <= 8 ? NHP_U_SMALL : (G <= 32 ? NHP_U_MID : 1);
-        const int round = (NHP_BLOCK / G) * U;
+        const int round = (NHP_WBLOCK / G) * U;
         const char *flat = getenv("NHP_SORT");
         const int mode = flat ? atoi(flat) : 2;
         auto longer = [](const nhp_child &x, const nhp_child &y) { return (x.idx - x.first) > (y.idx - y.first); };

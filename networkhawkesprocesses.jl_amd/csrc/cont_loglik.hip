@@ -58,7 +58,7 @@ __device__ __forceinline__ double baseline_at(const nhp_cont_args &a, int c, dou
 __device__ __forceinline__ double baseline_integral_part(const nhp_cont_args &a)
 {
     double sb = 0.0;
-    for (int c = threadIdx.x; c < a.N; c += NHP_BLOCK) {
+    for (int c = threadIdx.x; c < a.N; c += blockDim.x) {
         if (a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) {
             sb += a.lambda0[c] * a.duration;
         } else {
@@ -78,15 +78,15 @@ __device__ __forceinline__ double baseline_integral_part(const nhp_cont_args &a)
 #define NHP_SHARDS 64
 
 template <int IMP, int G, int U>
-__global__ __launch_bounds__(NHP_BLOCK) void k_windowed(nhp_cont_args a, int mask_integral,
+__global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int mask_integral,
                                                         double *__restrict__ partials,
                                                         double *__restrict__ lambda_out,
                                                         unsigned int *__restrict__ counter,
                                                         double *__restrict__ out)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    double *red = reinterpret_cast<double *>(smem);                 // [NHP_WAVES] + flag at [4]
-    double2 *col = reinterpret_cast<double2 *>(smem + 64);          // [N]
+    double *red = reinterpret_cast<double *>(smem);                 // [waves <= 16] + flag at [16]
+    double2 *col = reinterpret_cast<double2 *>(smem + 192);         // [N]
     double *colw = reinterpret_cast<double *>(col + a.N);           // [N], logit-normal only
     double *lam_buf = colw + (IMP == NHP_IMPULSE_EXPONENTIAL ? 0 : a.N);   // [children of the item]
 
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_windowed(nhp_cont_args a, int mas
 
     // ---- stage column c; the node's first item also owns the column's integral term
     double integ = 0.0;
-    for (int p = tid; p < ((a.dbg & 2) ? 0 : N); p += NHP_BLOCK) {
+    for (int p = tid; p < ((a.dbg & 2) ? 0 : N); p += NHP_WBLOCK) {
         const size_t k = (size_t)p + (size_t)c * N;
         double w = a.W[k], wint = w;
         if (a.A) {
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_windowed(nhp_cont_args a, int mas
     __syncthreads();
 
     // ---- children: G lanes per child, U children per group in flight
-    constexpr int GROUPS = NHP_BLOCK / G;
+    constexpr int GROUPS = NHP_WBLOCK / G;
     const int gid = tid / G, gl = tid % G;
     const int nchild = it.kend - it.kbeg;
     // slot of (wave, u, group-in-wave) inside a round: a wave's U*GW children are contiguous in the
@@ -173,9 +173,9 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_windowed(nhp_cont_args a, int mas
     __syncthreads();
     // ---- deferred logs: every lane busy, one child each
     double acc = 0.0;
-    for (int k = tid; k < ((a.dbg & 4) ? 0 : nchild); k += NHP_BLOCK) acc += nhp_log(lam_buf[k]);
-    const double blk = nhp_block_sum(acc, red);
-    const double blk_int = nhp_block_sum(integ, red);
+    for (int k = tid; k < ((a.dbg & 4) ? 0 : nchild); k += NHP_WBLOCK) acc += nhp_log(lam_buf[k]);
+    const double blk = nhp_block_sum_n<NHP_WBLOCK / 64>(acc, red);
+    const double blk_int = nhp_block_sum_n<NHP_WBLOCK / 64>(integ, red);
     if (!out) {
         if (tid == 0) {
             partials[2 * (size_t)blockIdx.x] = blk;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_windowed(nhp_cont_args a, int mas
     // fixed order (deterministic).  Hand-off per the sc1 recipe (cdna_hip_programming.md G16):
     // write-through stores of the partials, drain, one relaxed agent-scope ticket; the reader
     // uses sc1 loads only.  The last workgroup leaves the ticket counter at 0 for the next launch.
-    int *flag = reinterpret_cast<int *>(red + 4);
+    int *flag = reinterpret_cast<int *>(red + 16);
     if (tid == 0) {
         __hip_atomic_store(&partials[2 * (size_t)blockIdx.x], blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&partials[2 * (size_t)blockIdx.x + 1], blk_int, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -206,14 +206,14 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_windowed(nhp_cont_args a, int mas
     __syncthreads();
     if (!*flag) return;
     double sl = 0.0, si = 0.0;
-    for (unsigned int i = tid; i < gridDim.x; i += NHP_BLOCK) {
+    for (unsigned int i = tid; i < gridDim.x; i += NHP_WBLOCK) {
         sl += __hip_atomic_load(&partials[2 * (size_t)i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         si += __hip_atomic_load(&partials[2 * (size_t)i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     double sb = baseline_integral_part(a);
-    sl = nhp_block_sum(sl, red);
-    si = nhp_block_sum(si, red);
-    sb = nhp_block_sum(sb, red);
+    sl = nhp_block_sum_n<NHP_WBLOCK / 64>(sl, red);
+    si = nhp_block_sum_n<NHP_WBLOCK / 64>(si, red);
+    sb = nhp_block_sum_n<NHP_WBLOCK / 64>(sb, red);
     if (tid == 0) {
         *out = (0.0 - sb) - si + sl;
     }
@@ -245,13 +245,13 @@ static void launch_group(int G, dim3 grid, size_t lds, hipStream_t st, const nhp
 {
 #define NHP_CASE(g, u)                                                                                        \
     case g:                                                                                                   \
-        hipLaunchKernelGGL((k_windowed<IMP, g, u>), grid, dim3(NHP_BLOCK), lds, st, a, mask, partials,        \
+        hipLaunchKernelGGL((k_windowed<IMP, g, u>), grid, dim3(NHP_WBLOCK), lds, st, a, mask, partials,       \
                            lambda_out, counter, out);                                                         \
         break;
     switch (G) {
         NHP_CASE(1, NHP_U_SMALL) NHP_CASE(2, NHP_U_SMALL) NHP_CASE(4, NHP_U_SMALL) NHP_CASE(8, NHP_U_SMALL) NHP_CASE(16, NHP_U_MID) NHP_CASE(32, NHP_U_MID)
     default:
-        hipLaunchKernelGGL((k_windowed<IMP, 64, 1>), grid, dim3(NHP_BLOCK), lds, st, a, mask, partials, lambda_out, counter, out);
+        hipLaunchKernelGGL((k_windowed<IMP, 64, 1>), grid, dim3(NHP_WBLOCK), lds, st, a, mask, partials, lambda_out, counter, out);
     }
 #undef NHP_CASE
 }
@@ -261,7 +261,7 @@ static nhp_status run_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const n
 {
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t per = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? 16 : 24;
-    const size_t lds = 64 + per * (size_t)ds->N + 8 * (size_t)(ds->max_item > 0 ? ds->max_item : 1);
+    const size_t lds = 192 + per * (size_t)ds->N + 8 * (size_t)(ds->max_item > 0 ? ds->max_item : 1);
     if (lds > 64 * 1024) { nhp_set_error(ctx, "n_nodes = %d exceeds the 64 KiB LDS column budget", ds->N); return NHP_ENOTIMPL; }
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)ds->n_items));
     nhp_cont_args a = nhp_make_args(ds, m);

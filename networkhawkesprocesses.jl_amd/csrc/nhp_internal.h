@@ -180,8 +180,9 @@ __device__ __forceinline__ double nhp_wave_sum_shfl(double v)
     return v;
 }
 
-// Sum over a 256-thread block; result valid in thread 0.  `red` holds >= NHP_WAVES doubles.
-__device__ __forceinline__ double nhp_block_sum(double v, double *red)
+// Sum over a block of NW waves; result valid in thread 0.  `red` holds >= NW doubles.
+template <int NW>
+__device__ __forceinline__ double nhp_block_sum_n(double v, double *red)
 {
     v = nhp_wave_sum(v);
     __syncthreads();
@@ -189,6 +190,13 @@ __device__ __forceinline__ double nhp_block_sum(double v, double *red)
     __syncthreads();
     double s = 0.0;
     if (threadIdx.x == 0)
-        for (int w = 0; w < NHP_WAVES; ++w) s += red[w];
+        for (int w = 0; w < NW; ++w) s += red[w];
     return s;
 }
+
+__device__ __forceinline__ double nhp_block_sum(double v, double *red) { return nhp_block_sum_n<NHP_WAVES>(v, red); }
+
+// workgroup size of the windowed log-likelihood kernel (its own knob: more waves per staged column)
+#ifndef NHP_WBLOCK
+#define NHP_WBLOCK 256
+#endif
