@@ -98,6 +98,35 @@ extern "C" nhp_status nhp_cont_dataset_create(nhp_ctx *ctx, const double *events
     const char *env = getenv("NHP_CHUNK");
     if (env && atoi(env) > 0) chunk = std::min(atoi(env), 4096);
     std::vector<nhp_item> items;
+    // XCD-aware layout (NHP_XCD=TP, TP in {2,4}; off by default until it wins): workgroups are dealt
+    // round-robin over the 8 XCDs, so item b runs on XCD b % 8.  Giving XCD x = s*(8/TP) + g the
+    // children of time part s on the nodes with c % (8/TP) == g makes every XCD touch only 1/TP of
+    // the event array (its 4 MiB L2 no longer streams all 16 MB) at the price of staging each
+    // column TP times.  Speed heuristic only: any placement gives the same result.
+    const char *xenv = getenv("NHP_XCD");
+    const int TP = xenv ? atoi(xenv) : 0;
+    if ((TP == 2 || TP == 4) && N >= 8 && M >= 16 * (int64_t)N) {
+        const int NG = 8 / TP;
+        for (int32_t c0 = 0; c0 < N; c0 += NG)
+            for (int s = 0; s < TP; ++s)
+                for (int g = 0; g < NG; ++g) {
+                    nhp_item it;
+                    const int32_t c = c0 + g < N ? c0 + g : N - 1;
+                    const bool real = c0 + g < N;
+                    const int32_t b = ds->h_boff[c], e = ds->h_boff[c + 1];
+                    // children of c whose event index lies in [M*s/TP, M*(s+1)/TP): contiguous (time order)
+                    auto lower = [&](int64_t bound) {
+                        int32_t lo = b, hi = e;
+                        while (lo < hi) { int32_t mid = (lo + hi) >> 1; if (child[mid].idx < bound) lo = mid + 1; else hi = mid; }
+                        return lo;
+                    };
+                    it.node = c;
+                    it.kbeg = real ? lower(M * s / TP) : b;
+                    it.kend = real ? lower(M * (s + 1) / TP) : b;
+                    it.first = real && s == 0;
+                    items.push_back(it);
+                }
+    } else
     for (int32_t c = 0; c < N; ++c) {
         int32_t b = ds->h_boff[c], e = ds->h_boff[c + 1];
         int32_t n = e - b;
