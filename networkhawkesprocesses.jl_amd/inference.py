@@ -93,10 +93,22 @@ def mle_(process, data, optimizer="L-BFGS-B", verbose=False, f_abstol=1e-6, regu
     state = {"minloss": np.inf, "steps": 0, "converged": False, "last": None}
     start = time.time()
 
+    import ctypes as C
+    from .continuous import _check_recursive
+    model = process.device_model(ctx)
+    flags = _check_recursive(process, recursive)
+    P = len(x0)
+
     def fg(x):
-        process.params_(x)
-        ll, g = loglikelihood_gradient(process, ds, recursive=recursive, ctx=ctx)
+        # params!(process, x) straight into the device-resident model: x already is the reference's
+        # column-major parameter vector, so nothing is re-packed on the host per objective call
+        model.set_params(x)
+        g = np.empty(P)
+        ll_c = C.c_double()
+        _lib.check(_lib.lib().nhp_cont_loglik_grad(ctx.h, ds.h, model.h, flags, C.byref(ll_c), _lib.dptr(g), P), ctx.h)
+        ll = ll_c.value
         if regularize:
+            process.params_(x)
             ll += logprior(process)
             g = g + _logprior_gradient(process)
         state["last"] = -ll
