@@ -34,6 +34,16 @@ __device__ __forceinline__ double adj_baseline(const nhp_cont_args &a, int c, do
     return (y[lo + 1] * (t - x[lo]) + y[lo] * (x[lo + 1] - t)) / (x[lo + 1] - x[lo]);
 }
 
+// wave-local ordering of LDS traffic: wait for this wave's outstanding LDS operations (lgkmcnt(0)
+// only -- global stores stay in flight) and keep the compiler from moving LDS accesses across it
+#define NHP_LDS_SYNC()                                   \
+    do {                                                 \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_s_waitcnt(0xc07f);              \
+        __builtin_amdgcn_wave_barrier();                 \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
 template <int IMP>
 __global__ __launch_bounds__(NHP_BLOCK) void k_adjacency(nhp_cont_args a, double *__restrict__ A,
                                                          const int64_t *__restrict__ pair_off,
@@ -44,7 +54,6 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adjacency(nhp_cont_args a, double
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = a.N, c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double *red = reinterpret_cast<double *>(smem);                        // [8]: reductions + broadcast
     double2 *col = reinterpret_cast<double2 *>(smem + 64);                 // [N] exp {θ, W}; logit {μ, √τ}
     double *colw = reinterpret_cast<double *>(col + N);                    // [N] logit: W
     double *lam = colw + (IMP == NHP_IMPULSE_EXPONENTIAL ? 0 : N);         // [max_children] current λ_k
@@ -121,47 +130,67 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adjacency(nhp_cont_args a, double
     }
     __syncthreads();
 
-    // ---- phase 2: sequential Gibbs over parent nodes
+    // ---- phase 2: sequential Gibbs over parent nodes.  A parent node touches only a handful of
+    // children, so ONE wave walks the column: no block barriers on the 1..N critical path, only
+    // wave-local LDS ordering (LDS operations of a wave complete in issue order; the fence makes the
+    // atomics of all lanes visible before any lane reads them back).  The per-entry constants --
+    // uniform draw, prior log-odds, -W·cnt -- are precomputed by the whole block into LDS.
+    double *uni = reinterpret_cast<double *>(smem + (((reinterpret_cast<unsigned char *>(scan_tmp + NHP_BLOCK) - smem) + 7) & ~(size_t)7));   // [N] logit of the draw u[p,c]
+    double *bias = uni + N;                                                // [N] log ρ - log(1-ρ) - W·cnt[p]
+    double *acol = bias + N;                                               // [N] current A[·,c]
+    for (int p = tid; p < N; p += NHP_BLOCK) {
+        const size_t kpc = (size_t)p + (size_t)c * N;
+        const double rho = rho_mat ? rho_mat[kpc] : rho_scalar;
+        const double w = IMP == NHP_IMPULSE_EXPONENTIAL ? col[p].y : colw[p];
+        // the Bernoulli rule u <= exp(ll1 - logsumexp(ll0, ll1)) = 1/(1 + e^{-d}) is logit(u) <= d:
+        // the logit is taken here, in parallel, so the serial chain below carries no exp and no division
+        const double uu = u ? u[kpc] : nhp_philox_uniform(seed ^ 0xBE5466CF34E90C6Cull, step, kpc);
+        uni[p] = nhp_log(uu / (1.0 - uu));
+        bias[p] = -(w * a.cnt[p]) + nhp_log(rho) - nhp_log(1.0 - rho);
+        acol[p] = A[kpc];
+    }
+    __syncthreads();
+    if (wave != 0) return;
     double links = 0.0;
-    for (int p = 0; p < N; ++p) {
+    // entries of parent p: lane l owns entry eb + l (+64, +128, ... for the rare long lists).  The first
+    // chunk of parent p+1 is fetched while p is processed, so no global-load latency sits on the chain.
+    int nk = -1;
+    double nx = 0.0;
+    if (N > 0 && start[0] + lane < start[1]) { nk = ent_k[base + start[0] + lane]; nx = ent_x[base + start[0] + lane]; }
+    for (int p = 0; p < ((a.dbg & 64) ? 0 : N); ++p) {
         const int eb = start[p], ee = start[p + 1];
         const size_t kpc = (size_t)p + (size_t)c * N;
-        const double aold = A[kpc];
-        for (int e = eb + tid; e < ee; e += NHP_BLOCK) atomicAdd(&dx[ent_k[base + e]], ent_x[base + e]);
-        __syncthreads();
+        const double aold = acol[p];
+        const int ck = nk;                       // this lane's first entry of p (or -1)
+        const double cx = nx;
+        nk = -1;
+        if (p + 1 < N && ee + lane < start[p + 2]) { nk = ent_k[base + ee + lane]; nx = ent_x[base + ee + lane]; }
+        if (ck >= 0) atomicAdd(&dx[ck], cx);
+        for (int e = eb + 64 + lane; e < ee; e += 64) atomicAdd(&dx[ent_k[base + e]], ent_x[base + e]);
+        NHP_LDS_SYNC();
         double delta = 0.0;
-        for (int e = eb + tid; e < ee; e += NHP_BLOCK) {
-            const int k = ent_k[base + e];
+        auto own = [&](int k) {
             if (atomicExch(&marker[k], p + 1) != p + 1) {           // first entry of child k for this p owns it
                 const double d = dx[k];
                 const double l0 = lam[k] - aold * d;
                 delta += nhp_log(l0 + d) - nhp_log(l0);
             }
-        }
+        };
+        if (ck >= 0) own(ck);
+        for (int e = eb + 64 + lane; e < ee; e += 64) own(ent_k[base + e]);
         delta = nhp_wave_sum(delta);
-        if (lane == 0) red[wave] = delta;
-        __syncthreads();
-        if (tid == 0) {
-            const double rho = rho_mat ? rho_mat[kpc] : rho_scalar;
-            const double w = IMP == NHP_IMPULSE_EXPONENTIAL ? col[p].y : colw[p];
-            const double d = -(w * a.cnt[p]) + (((red[0] + red[1]) + red[2]) + red[3]) + nhp_log(rho) - nhp_log(1.0 - rho);
-            // exp(ll1 - logsumexp(ll0, ll1)) with ll1 - ll0 = d
-            const double prob = d >= 0.0 ? 1.0 / (1.0 + nhp_exp(-d)) : nhp_exp(d) / (1.0 + nhp_exp(d));
-            const double draw = u ? u[kpc] : nhp_philox_uniform(seed ^ 0xBE5466CF34E90C6Cull, step, kpc);
-            const double anew = draw <= prob ? 1.0 : 0.0;
-            A[kpc] = anew;
-            red[4] = anew;
-        }
-        __syncthreads();
-        const double anew = red[4];
+        const double d = bias[p] + delta;
+        const double anew = uni[p] <= d ? 1.0 : 0.0;             // ll1 - ll0 = d
+        if (lane == 0) A[kpc] = anew;
         links += anew;
-        for (int e = eb + tid; e < ee; e += NHP_BLOCK) {
-            const int k = ent_k[base + e];
+        auto settle = [&](int k) {
             // the first taker carries the child's total
-            const double d = __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long *>(&dx[k]), 0ull));
-            if (d != 0.0 && anew != aold) lam[k] += (anew - aold) * d;
-        }
-        __syncthreads();
+            const double dd = __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long *>(&dx[k]), 0ull));
+            if (dd != 0.0 && anew != aold) lam[k] += (anew - aold) * dd;
+        };
+        if (ck >= 0) settle(ck);
+        for (int e = eb + 64 + lane; e < ee; e += 64) settle(ent_k[base + e]);
+        NHP_LDS_SYNC();
     }
     if (tid == 0 && col_links) col_links[c] = links;
 }
@@ -178,7 +207,7 @@ extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_d
     int max_children = 1;
     for (size_t c = 0; c < N; ++c) max_children = std::max(max_children, ds->h_boff[c + 1] - ds->h_boff[c]);
     const size_t per = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? 16 : 24;
-    const size_t lds = 64 + per * N + 20 * (size_t)max_children + 4 * (2 * N + 1 + NHP_BLOCK) + 16;
+    const size_t lds = 64 + per * N + 20 * (size_t)max_children + 4 * (2 * N + 2 + NHP_BLOCK) + 24 * N + 16;
     if (lds > 160 * 1024) {
         nhp_set_error(ctx, "resample_adjacency: a node with %d events (N = %d) exceeds the 160 KiB LDS column state", max_children, ds->N);
         return NHP_ENOTIMPL;

@@ -142,9 +142,13 @@ def resample_adjacency_matrix_(process, data, u=None, seed=0, step=0, model=None
     ds = device_dataset(process, data, ctx)
     model = model or process.device_model(ctx)
     N = process.ndims()
-    link = np.asarray(process.network.link_probability(), dtype=np.float64)
-    scalar = float(link.flat[0]) if np.all(link == link.flat[0]) else None
-    rho_m = None if scalar is not None else _lib.colmajor(link)
+    from .components import BernoulliNetworkModel, DenseNetworkModel
+    if isinstance(process.network, BernoulliNetworkModel):       # link_probability = ρ .* ones  (src/networks.jl:65-68)
+        scalar, rho_m = float(process.network.ρ), None
+    elif isinstance(process.network, DenseNetworkModel):
+        scalar, rho_m = 1.0, None
+    else:
+        scalar, rho_m = None, _lib.colmajor(np.asarray(process.network.link_probability(), dtype=np.float64))
     uu = None if u is None else _lib.colmajor(np.asarray(u, dtype=np.float64))
     A = np.empty(N * N) if fetch else None
     nl = C.c_double()
