@@ -31,8 +31,9 @@ template <int IMP>
 __device__ __forceinline__ double samp_weight(const nhp_cont_args &a, const samp_col &sc, double t, int j)
 {
 #pragma clang fp contract(off)
-    const double dt = t - a.times[j];
-    const int p = a.nodes[j];
+    const nhp_event e = a.ev[j];                  // one 16-byte load: (t_j, n_j)
+    const double dt = t - e.t;
+    const int p = e.node;
     const double2 q = sc.col[p];
     if (IMP == NHP_IMPULSE_EXPONENTIAL) return q.y * nhp_pdf_exponential(q.x, dt);
     return sc.colw[p] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
@@ -157,8 +158,10 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_sampler(nhp_cont_args a, const do
     }
 }
 
-// ---- statistics: workgroup c, lane p scans the children of c ------------------------------
-#define STAT_PQ 4      // parent nodes per lane per sweep
+// ---- statistics: workgroup c scans the children of c; thread t owns the parent nodes p = t (mod 256)
+// Every child is looked at once per wave: the wave whose lane owns the child's parent node takes a
+// (rare) branch and updates that node's cells in LDS -- thread-exclusive addresses, no atomics, and
+// every (p,c) cell accumulates in child time order, the order of the reference's serial loops.
 __global__ __launch_bounds__(NHP_BLOCK) void k_stats(nhp_cont_args a, const int32_t *__restrict__ pn_b,
                                                      const double *__restrict__ dt_b,
                                                      double *__restrict__ cnt0, double *__restrict__ Mn,
@@ -166,66 +169,71 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_stats(nhp_cont_args a, const int3
                                                      double *__restrict__ Vnm)
 {
 #pragma clang fp contract(off)
-    __shared__ int s_pn[NHP_BLOCK];
-    __shared__ double s_v[NHP_BLOCK];
-    __shared__ double red[NHP_WAVES];
-    const int c = blockIdx.x, N = a.N, tid = threadIdx.x;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int c = blockIdx.x, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *cnt = reinterpret_cast<double *>(smem);          // [N] events on c attributed to p
+    double *sx = cnt + N;                                    // [N] Σ value, then the mean
+    double *sv = sx + N;                                     // [N] Σ (value - mean)²
+    int *s_pn = reinterpret_cast<int *>(sv + N);             // [NHP_BLOCK] staged parent nodes
+    double *s_v = reinterpret_cast<double *>(s_pn + NHP_BLOCK);   // [NHP_BLOCK] staged values
+    double *red = s_v + NHP_BLOCK;                           // [NHP_WAVES]
     const int kb = a.boff[c], ke = a.boff[c + 1];
     const bool lognorm = a.impulse_kind == NHP_IMPULSE_LOGITNORMAL;
+    for (int p = tid; p < N; p += NHP_BLOCK) { cnt[p] = 0.0; sx[p] = 0.0; sv[p] = 0.0; }
 
-    for (int p0 = 0; p0 < N; p0 += NHP_BLOCK * STAT_PQ) {
-        double cnt[STAT_PQ], sx[STAT_PQ], sv[STAT_PQ], mean[STAT_PQ];
-#pragma unroll
-        for (int q = 0; q < STAT_PQ; ++q) { cnt[q] = 0.0; sx[q] = 0.0; sv[q] = 0.0; mean[q] = 0.0; }
-        for (int pass = 0; pass < (lognorm ? 2 : 1); ++pass) {
-            for (int k0 = kb; k0 < ke; k0 += NHP_BLOCK) {
-                __syncthreads();
-                const int k = k0 + tid;
-                int pn = -1;
-                double v = 0.0;
-                if (k < ke) {
-                    pn = pn_b[k];
-                    const double d = dt_b[k];
-                    // log_duration: log((child - parent) / (Δtmax - (child - parent)))  src/impulses.jl:228
-                    v = (lognorm && pn >= 0) ? nhp_log(d / (a.dt_max - d)) : d;
-                }
-                s_pn[tid] = pn;
-                s_v[tid] = v;
-                __syncthreads();
-                const int nb = min(NHP_BLOCK, ke - k0);
-                for (int e = 0; e < nb; ++e) {
-                    const int pe = s_pn[e];
-                    const double ve = s_v[e];
-#pragma unroll
-                    for (int q = 0; q < STAT_PQ; ++q) {
-                        if (pe == p0 + tid + q * NHP_BLOCK) {
-                            if (pass == 0) { cnt[q] += 1.0; sx[q] = sx[q] + ve; }
-                            else { const double dlt = ve - mean[q]; sv[q] = sv[q] + dlt * dlt; }
-                        }
+    double base_cnt = 0.0;
+    for (int pass = 0; pass < (lognorm ? 2 : 1); ++pass) {
+        for (int k0 = kb; k0 < ke; k0 += NHP_BLOCK) {
+            __syncthreads();
+            const int k = k0 + tid;
+            int pn = -1;
+            double v = 0.0;
+            if (k < ke) {
+                pn = pn_b[k];
+                const double d = dt_b[k];
+                // log_duration: log((child - parent) / (Δtmax - (child - parent)))  src/impulses.jl:228
+                v = (lognorm && pn >= 0) ? nhp_log(d / (a.dt_max - d)) : d;
+                if (pass == 0 && pn < 0) base_cnt += 1.0;
+            }
+            s_pn[tid] = pn;
+            s_v[tid] = v;
+            __syncthreads();
+            const int nb = min(NHP_BLOCK, ke - k0);
+            // each wave picks, with one ballot per 64 staged children, the children whose owner lane it
+            // hosts (owner thread = parent node mod 256) and visits only those, in order
+            for (int ch = 0; ch < nb; ch += 64) {
+                const int e = ch + lane;
+                const int pe = e < nb ? s_pn[e] : -1;
+                const double ve = e < nb ? s_v[e] : 0.0;
+                unsigned long long m = __ballot(pe >= 0 && ((pe >> 6) & (NHP_WAVES - 1)) == wave);
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int pb = __builtin_amdgcn_readlane(pe, b);
+                    const double vb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ve), b),
+                                                       __builtin_amdgcn_readlane(__double2loint(ve), b));
+                    if ((pb & 63) == lane) {
+                        if (pass == 0) { cnt[pb] += 1.0; sx[pb] = sx[pb] + vb; }
+                        else { const double dlt = vb - sx[pb]; sv[pb] = sv[pb] + dlt * dlt; }
                     }
                 }
             }
-            if (pass == 0) {
-#pragma unroll
-                for (int q = 0; q < STAT_PQ; ++q) mean[q] = sx[q] / cnt[q];      // NaN when cnt == 0
-            }
         }
-#pragma unroll
-        for (int q = 0; q < STAT_PQ; ++q) {
-            const int p = p0 + tid + q * NHP_BLOCK;
-            if (p < N) {
-                const size_t k = (size_t)p + (size_t)c * N;
-                if (Mnm) Mnm[k] = cnt[q];
-                // exponential: fillna!(Xnm ./ Mnm, 0) (src/impulses.jl:95); logit-normal keeps NaN (:222)
-                if (Xnm) Xnm[k] = (!lognorm && cnt[q] == 0.0) ? 0.0 : mean[q];
-                if (Vnm && lognorm) Vnm[k] = sv[q];
-            }
+        if (pass == 0) {
+            __syncthreads();
+            for (int p = tid; p < N; p += NHP_BLOCK) sx[p] = sx[p] / cnt[p];     // mean; NaN when cnt == 0
         }
     }
+    __syncthreads();
+    for (int p = tid; p < N; p += NHP_BLOCK) {
+        const size_t k = (size_t)p + (size_t)c * N;
+        if (Mnm) Mnm[k] = cnt[p];
+        // exponential: fillna!(Xnm ./ Mnm, 0) (src/impulses.jl:95); logit-normal keeps NaN (:222)
+        if (Xnm) Xnm[k] = (!lognorm && cnt[p] == 0.0) ? 0.0 : sx[p];
+        if (Vnm && lognorm) Vnm[k] = sv[p];
+    }
     // baseline-attributed events on c and events on c
-    double b = 0.0;
-    for (int k = kb + tid; k < ke; k += NHP_BLOCK) b += pn_b[k] < 0 ? 1.0 : 0.0;
-    b = nhp_block_sum(b, red);
+    const double b = nhp_block_sum(base_cnt, red);
     if (tid == 0) {
         if (cnt0) cnt0[c] = b;
         if (Mn) Mn[c] = (double)(ke - kb);
@@ -275,7 +283,9 @@ static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
                            want_parents ? o->parents : nullptr, want_parents ? o->pnodes : nullptr, o->pn_b, o->dt_b, d_err);
     NHP_HIP(ctx, hipGetLastError());
     if (want_stats) {
-        hipLaunchKernelGGL(k_stats, dim3((unsigned)N), dim3(NHP_BLOCK), 0, st, a, o->pn_b, o->dt_b, o->cnt0, o->Mn, o->Mnm, o->X, o->V);
+        const size_t lds_stats = 8 * (3 * N + NHP_BLOCK + NHP_WAVES) + 4 * NHP_BLOCK + 16;
+        if (lds_stats > 64 * 1024) { nhp_set_error(ctx, "statistics: n_nodes = %d exceeds the LDS budget", ds->N); return NHP_ENOTIMPL; }
+        hipLaunchKernelGGL(k_stats, dim3((unsigned)N), dim3(NHP_BLOCK), lds_stats, st, a, o->pn_b, o->dt_b, o->cnt0, o->Mn, o->Mnm, o->X, o->V);
         NHP_HIP(ctx, hipGetLastError());
     }
     int h_err = 0;
