@@ -58,23 +58,31 @@ __device__ __forceinline__ double samp_baseline(const nhp_cont_args &a, int c, d
 #define SAMP_W(k) ((k) < n - 1 ? samp_weight<IMP>(a, sc, t, i - 1 - (k)) : base)
 
 // Sequential left fold over [lo, hi] -- Julia's mapreduce_impl leaf (and the n < 16 path).
+#define SAMP_CACHE 16      // weights per child kept in LDS between the sum pass and the scan pass
+#define SAMP_CLD 17        // row stride (doubles): odd, so lanes reading the same k hit distinct banks
+
 template <int IMP>
 __device__ __forceinline__ double samp_fold(const nhp_cont_args &a, const samp_col &sc, double t, int i,
-                                            int n, double base, int lo, int hi)
+                                            int n, double base, int lo, int hi, double *wcache)
 {
 #pragma clang fp contract(off)
     double v = SAMP_W(lo);
-    for (int k = lo + 1; k <= hi; ++k) v = v + SAMP_W(k);
+    if (lo < SAMP_CACHE) wcache[lo] = v;
+    for (int k = lo + 1; k <= hi; ++k) {
+        const double w = SAMP_W(k);
+        if (k < SAMP_CACHE) wcache[k] = w;
+        v = v + w;
+    }
     return v;
 }
 
 // Julia Base `sum` over n boxed elements: sequential for n <= 1024, otherwise split at
 // lo + (hi-lo)>>1 recursively (reduce.jl, pairwise_blocksize = 1024).  Iterative post-order.
 template <int IMP>
-__device__ double samp_sum(const nhp_cont_args &a, const samp_col &sc, double t, int i, int n, double base)
+__device__ double samp_sum(const nhp_cont_args &a, const samp_col &sc, double t, int i, int n, double base, double *wcache)
 {
 #pragma clang fp contract(off)
-    if (n <= 1024) return samp_fold<IMP>(a, sc, t, i, n, base, 0, n - 1);
+    if (n <= 1024) return samp_fold<IMP>(a, sc, t, i, n, base, 0, n - 1, wcache);
     int s_lo[24], s_hi[24], s_state[24];
     double s_left[24];
     int sp = 0;
@@ -85,7 +93,7 @@ __device__ double samp_sum(const nhp_cont_args &a, const samp_col &sc, double t,
         const int lo = s_lo[f], hi = s_hi[f];
         if (s_state[f] == 0) {
             if (hi - lo < 1024) {
-                ret = samp_fold<IMP>(a, sc, t, i, n, base, lo, hi);
+                ret = samp_fold<IMP>(a, sc, t, i, n, base, lo, hi, wcache);
                 --sp;
             } else {
                 s_state[f] = 1;
@@ -116,6 +124,10 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_sampler(nhp_cont_args a, const do
     double *colw = reinterpret_cast<double *>(col + a.N);
     const nhp_item it = a.items[blockIdx.x];
     const int c = it.node, N = a.N, tid = threadIdx.x;
+    // the first SAMP_CACHE weights of a child survive from the sum pass to the scan pass in LDS: at
+    // short windows the scan then costs no second round of exp / log evaluations (same values, so the
+    // indices stay bit-exact)
+    double *wcache = colw + (IMP == NHP_IMPULSE_EXPONENTIAL ? 0 : a.N) + (size_t)tid * SAMP_CLD;
     for (int p = tid; p < N; p += NHP_BLOCK) {
         const size_t k = (size_t)p + (size_t)c * N;
         double w = a.W[k];
@@ -139,14 +151,14 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_sampler(nhp_cont_args a, const do
         if (i > 0) {                                       // index == 1 -> (0, 0): src/parents.jl:26-28
             const int n = i - ch.first + 1;
             const double base = samp_baseline(a, c, t);
-            const double s = samp_sum<IMP>(a, sc, t, i, n, base);
+            const double s = samp_sum<IMP>(a, sc, t, i, n, base, wcache);
             if (!(s > 0.0) || !(s < __builtin_inf())) *err = 1;
             const double draw = u ? u[i] : nhp_philox_uniform(seed, step, (uint64_t)i);
             int kk = 0;
-            double cp = SAMP_W(0) / s;
+            double cp = wcache[0] / s;
             while (cp <= draw && kk < n - 1) {
                 ++kk;
-                cp = cp + SAMP_W(kk) / s;
+                cp = cp + (kk < SAMP_CACHE ? wcache[kk] : SAMP_W(kk)) / s;
             }
             if (kk < n - 1) parent = i - 1 - kk;
         }
@@ -272,7 +284,7 @@ static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
 
     nhp_cont_args a = nhp_make_args(ds, m);
     const size_t per = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? 16 : 24;
-    const size_t lds = per * N;
+    const size_t lds = per * N + 8 * (size_t)NHP_BLOCK * SAMP_CLD;
     if (lds > 64 * 1024) { nhp_set_error(ctx, "n_nodes = %d exceeds the 64 KiB LDS column budget", ds->N); return NHP_ENOTIMPL; }
     dim3 grid((unsigned)ds->n_items);
     if (m->impulse_kind == NHP_IMPULSE_EXPONENTIAL)
