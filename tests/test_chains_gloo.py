@@ -46,16 +46,20 @@ WORKER = textwrap.dedent("""
         assert np.array_equal(allsum[k]["mean"], want["mean"]) and np.array_equal(allsum[k]["m2"], want["m2"])
     dist.barrier()
     dist.destroy_process_group()
-    print("rank", rank, "ok")
+    os.write(1, ("rank %d ok\n" % rank).encode())      # one write: the two ranks share the pipe
 """)
 
 
 def test_two_rank_gloo_gather(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
+    import socket
+    with socket.socket() as sk:                      # a free port: reruns must not collide in TIME_WAIT
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29531", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
