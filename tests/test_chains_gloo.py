@@ -46,7 +46,7 @@ WORKER = textwrap.dedent("""
         assert np.array_equal(allsum[k]["mean"], want["mean"]) and np.array_equal(allsum[k]["m2"], want["m2"])
     dist.barrier()
     dist.destroy_process_group()
-    os.write(1, ("rank %d ok\n" % rank).encode())      # one write: the two ranks share the pipe
+    os.write(1, ("rank %d ok" % rank + chr(10)).encode())      # one write: the two ranks share the pipe
 """)
 
 
