@@ -175,14 +175,14 @@ def config_workloads(nhp, ctx, which):
         N, B, L, T = 512, 8, 32, 100_000
         rng = np.random.default_rng(7)
         data = rng.poisson(0.05, (N, T)).astype(np.int64)
-        th = np.full((N, N, B), 1.0 / B)
+        th = np.asfortranarray(np.full((N, N, B), 1.0 / B))      # column-major like the Julia arrays: no repacking per call
         imp = nhp.DiscreteGaussianImpulseResponse(th, L, 1.0)
         proc = nhp.DiscreteStandardHawkesProcess(nhp.DiscreteHomogeneousProcess(rng.uniform(0.02, 0.08, N), 1.0), imp,
-                                                 nhp.DenseWeightModel(rng.uniform(0, 1, (N, N)) / N), 1.0)
+                                                 nhp.DenseWeightModel(np.asfortranarray(rng.uniform(0, 1, (N, N)) / N)), 1.0)
         dsd = nhp.DiscreteDataset(ctx, data)
         t_c = timed(lambda: nhp.convolve(proc, dsd, ctx=ctx), 3)
         t_ll = timed(lambda: nhp.loglikelihood(proc, data, convolved=dsd, ctx=ctx), 5)
-        t_vb = timed(lambda: nhp.update_(proc, data, dsd, ctx=ctx), 3)
+        t_vb = timed(lambda: nhp.update_(proc, data, dsd, ctx=ctx, n_steps=10), 2) / 10.0     # 10 resident steps per call
         flop = 2.0 * T * N * N * B
         out.append({"workload": "c4 discrete N=512 B=8 L=32 T=1e5", "convolve_ms": 1e3 * t_c, "loglik_ms": 1e3 * t_ll,
                     "loglik_tflops_fp64": flop / t_ll / 1e12, "vb_step_ms": 1e3 * t_vb,

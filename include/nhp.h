@@ -214,6 +214,11 @@ nhp_status nhp_disc_vb_step(nhp_ctx *ctx, const nhp_disc_dataset *ds, double dt,
                             double alpha0, double beta0, double kappa, double nu, double gamma,
                             double *alpha_v, double *beta_v, double *kappa_v, double *nu_v,
                             double *gamma_v);
+/* n_steps consecutive update! steps of vb! (src/inference.jl:153-181) with the variational parameters
+ * resident on the device in between (one upload, one download) */
+nhp_status nhp_disc_vb_run(nhp_ctx *ctx, const nhp_disc_dataset *ds, double dt,
+                           double alpha0, double beta0, double kappa, double nu, double gamma, int32_t n_steps,
+                           double *alpha_v, double *beta_v, double *kappa_v, double *nu_v, double *gamma_v);
 
 #ifdef __cplusplus
 }

@@ -89,6 +89,7 @@ def _declare(lib):
         ("nhp_disc_intensity", (_vp, _vp, _dp, _dp, _dp, _dp, dbl, _dp)),
         ("nhp_disc_loglik", (_vp, _vp, _dp, _dp, _dp, _dp, dbl, _dp)),
         ("nhp_disc_vb_step", (_vp, _vp, dbl, dbl, dbl, dbl, dbl, dbl, _dp, _dp, _dp, _dp, _dp)),
+        ("nhp_disc_vb_run", (_vp, _vp, dbl, dbl, dbl, dbl, dbl, dbl, i32, _dp, _dp, _dp, _dp, _dp)),
     ):
         if hasattr(lib, name):
             f(name, i32, *args)

@@ -183,7 +183,7 @@ class DenseWeightModel(Weights):
     """DenseWeightModel(W[, κ, ν, κv, νv]) -- src/weights.jl:47-55."""
 
     def __init__(self, W, κ=1.0, ν=1.0, κv=None, νv=None):
-        self.W = np.array(W, dtype=np.float64)
+        self.W = np.array(W, dtype=np.float64, order="K")
         self.κ, self.ν = float(κ), float(ν)
         self.κv = np.ones_like(self.W) if κv is None else np.array(κv, dtype=np.float64)
         self.νv = np.ones_like(self.W) if νv is None else np.array(νv, dtype=np.float64)

@@ -536,10 +536,19 @@ extern "C" nhp_status nhp_disc_loglik(nhp_ctx *ctx, const nhp_disc_dataset *ds, 
     return nhp_ctx_fetch(ctx, 0, 1, ll);
 }
 
+// (nhp_disc_vb_run is declared in include/nhp.h)
 extern "C" nhp_status nhp_disc_vb_step(nhp_ctx *ctx, const nhp_disc_dataset *ds, double dt,
                                        double alpha0, double beta0, double kappa, double nu, double gamma,
                                        double *alpha_v, double *beta_v, double *kappa_v, double *nu_v, double *gamma_v)
 {
+    return nhp_disc_vb_run(ctx, ds, dt, alpha0, beta0, kappa, nu, gamma, 1, alpha_v, beta_v, kappa_v, nu_v, gamma_v);
+}
+
+extern "C" nhp_status nhp_disc_vb_run(nhp_ctx *ctx, const nhp_disc_dataset *ds, double dt,
+                                      double alpha0, double beta0, double kappa, double nu, double gamma, int32_t n_steps,
+                                      double *alpha_v, double *beta_v, double *kappa_v, double *nu_v, double *gamma_v)
+{
+    if (n_steps < 1) return NHP_EINVAL;
     if (!ctx || !ds || !alpha_v || !beta_v || !kappa_v || !nu_v || !gamma_v) return NHP_EINVAL;
     if (!ds->d_conv) { nhp_set_error(ctx, "convolve(process, data) must run before update!"); return NHP_EINVAL; }
     NHP_HIP(ctx, hipSetDevice(ctx->device));
@@ -571,25 +580,27 @@ extern "C" nhp_status nhp_disc_vb_step(nhp_ctx *ctx, const nhp_disc_dataset *ds,
     NHP_HIP(ctx, hipMemcpyAsync(dkv, kappa_v, 8 * NN, hipMemcpyHostToDevice, st));
     NHP_HIP(ctx, hipMemcpyAsync(dnv, nu_v, 8 * NN, hipMemcpyHostToDevice, st));
     NHP_HIP(ctx, hipMemcpyAsync(dgv, gamma_v, 8 * NN * B, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_vb_factors, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, st, (int)N, (int)B, dav, dbv, dkv, dnv, dgv, dE, de0);
-    NHP_HIP(ctx, hipGetLastError());
-    // GEMM-1: Z = e0 ⊕ G·E, R = data / Z, column sums of R
-    gemm_args g1{};
-    g1.A = ds->d_conv; g1.lda = T; g1.B = dE; g1.ldb = K; g1.M = (int)T; g1.N = (int)N; g1.K = (int)K; g1.k_chunk = (int)K;
-    g1.base = de0; g1.dataT = ds->d_dataT; g1.out = dR; g1.partials = dcolp;
-    launch_gemm<true, EPI_VB_Z>(g1, 1, st);
-    NHP_HIP(ctx, hipGetLastError());
-    // GEMM-2: slabs_z = Gᵀ·R over T-chunk z
-    gemm_args g2{};
-    g2.A = ds->d_conv; g2.lda = T; g2.B = dR; g2.ldb = T; g2.M = (int)K; g2.N = (int)N; g2.K = (int)T; g2.k_chunk = k_chunk;
-    g2.out = dslab;
-    launch_gemm<false, EPI_SLAB>(g2, splits, st);
-    NHP_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_vb_baseline, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, (int)N, row_blocks, dcolp, de0,
-                       alpha0, beta0, (double)T * dt, dav, dbv);
-    hipLaunchKernelGGL(k_vb_finish, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, st, (int)N, (int)B, splits, dslab, dE,
-                       ds->d_colsum, kappa, nu, gamma, dkv, dnv, dgv);
-    NHP_HIP(ctx, hipGetLastError());
+    for (int step = 0; step < n_steps; ++step) {      // variational parameters stay on the device between steps
+        hipLaunchKernelGGL(k_vb_factors, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, st, (int)N, (int)B, dav, dbv, dkv, dnv, dgv, dE, de0);
+        NHP_HIP(ctx, hipGetLastError());
+        // GEMM-1: Z = e0 ⊕ G·E, R = data / Z, column sums of R
+        gemm_args g1{};
+        g1.A = ds->d_conv; g1.lda = T; g1.B = dE; g1.ldb = K; g1.M = (int)T; g1.N = (int)N; g1.K = (int)K; g1.k_chunk = (int)K;
+        g1.base = de0; g1.dataT = ds->d_dataT; g1.out = dR; g1.partials = dcolp;
+        launch_gemm<true, EPI_VB_Z>(g1, 1, st);
+        NHP_HIP(ctx, hipGetLastError());
+        // GEMM-2: slabs_z = Gᵀ·R over T-chunk z
+        gemm_args g2{};
+        g2.A = ds->d_conv; g2.lda = T; g2.B = dR; g2.ldb = T; g2.M = (int)K; g2.N = (int)N; g2.K = (int)T; g2.k_chunk = k_chunk;
+        g2.out = dslab;
+        launch_gemm<false, EPI_SLAB>(g2, splits, st);
+        NHP_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_vb_baseline, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, (int)N, row_blocks, dcolp, de0,
+                           alpha0, beta0, (double)T * dt, dav, dbv);
+        hipLaunchKernelGGL(k_vb_finish, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, st, (int)N, (int)B, splits, dslab, dE,
+                           ds->d_colsum, kappa, nu, gamma, dkv, dnv, dgv);
+        NHP_HIP(ctx, hipGetLastError());
+    }
     NHP_HIP(ctx, hipMemcpyAsync(alpha_v, dav, 8 * N, hipMemcpyDeviceToHost, st));
     NHP_HIP(ctx, hipMemcpyAsync(beta_v, dbv, 8 * N, hipMemcpyDeviceToHost, st));
     NHP_HIP(ctx, hipMemcpyAsync(kappa_v, dkv, 8 * NN, hipMemcpyDeviceToHost, st));

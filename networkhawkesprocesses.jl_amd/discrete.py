@@ -109,7 +109,7 @@ class DiscreteGaussianImpulseResponse(DiscreteImpulseResponse):
     with Σ_b θ[p,c,·] = 1."""
 
     def __init__(self, θ, nlags, dt=1.0):
-        θ = np.array(θ, dtype=np.float64)
+        θ = np.array(θ, dtype=np.float64, order="K")
         if not np.all(θ.sum(axis=2) == 1.0):
             raise ValueError("Invalid discrete basis parameter.")
         self.θ, self.γ, self.γv, self.nlags, self.dt = θ, 1.0, np.ones_like(θ), int(nlags), float(dt)
@@ -248,9 +248,10 @@ def disc_loglikelihood(process, data=None, convolved=None, ctx=None):
     return ll.value
 
 
-def update_(process, data, convolved, ctx=None):
-    """update!(process, data, convolved) -- src/discrete.jl:369-375: one mean-field step; the
-    variational parameters of baseline, weights and impulses are overwritten in place."""
+def update_(process, data, convolved, ctx=None, n_steps=1):
+    """update!(process, data, convolved) -- src/discrete.jl:369-375: one mean-field step (or n_steps
+    of them with the parameters resident on the device in between); the variational parameters of
+    baseline, weights and impulses are overwritten in place."""
     if not isinstance(process, DiscreteStandardHawkesProcess) or not isinstance(process.weights, DenseWeightModel):
         raise NotImplementedError("VB exists only for DiscreteStandardHawkesProcess + DenseWeightModel "
                                   "(the reference's network / sparse variants are broken: SURVEY D6)")
@@ -260,8 +261,8 @@ def update_(process, data, convolved, ctx=None):
     N, B = process.ndims(), imp.nbasis()
     av, bv = _lib.f64(b.αv).copy(), _lib.f64(b.βv).copy()
     kv, nv, gv = _lib.colmajor(w.κv).copy(), _lib.colmajor(w.νv).copy(), _lib.colmajor(imp.γv).copy()
-    _lib.check(_lib.lib().nhp_disc_vb_step(ctx.h, ds.h, process.dt, b.α0, b.β0, w.κ, w.ν, imp.γ,
-                                           _lib.dptr(av), _lib.dptr(bv), _lib.dptr(kv), _lib.dptr(nv), _lib.dptr(gv)),
+    _lib.check(_lib.lib().nhp_disc_vb_run(ctx.h, ds.h, process.dt, b.α0, b.β0, w.κ, w.ν, imp.γ, n_steps,
+                                          _lib.dptr(av), _lib.dptr(bv), _lib.dptr(kv), _lib.dptr(nv), _lib.dptr(gv)),
                ctx.h)
     b.αv, b.βv = av, bv
     w.κv, w.νv = kv.reshape((N, N), order="F"), nv.reshape((N, N), order="F")
@@ -279,13 +280,19 @@ class VariationalInference:
         return f"\n* Status: {self.status}\n    step: {self.step}\n    elapsed: {self.elapsed}"
 
 
-def vb_(process, data, max_steps=1000, Δx_thresh=1e-6, Δq_thresh=1e-2, verbose=False, ctx=None):
+def vb_(process, data, max_steps=1000, Δx_thresh=1e-6, Δq_thresh=1e-2, verbose=False, keep_trace=True, ctx=None):
     """vb!(process, data; max_steps, Δx_thresh, Δq_thresh, verbose) -- src/inference.jl:153-181.
-    Like the reference (whose convergence test is commented out, :163-176) it runs max_steps updates."""
+    Like the reference (whose convergence test is commented out, :163-176) it runs max_steps updates.
+    keep_trace=False runs them back to back on the device and records only the final parameters
+    (the reference's per-step trace is 2N + N²B + 2N² doubles a step)."""
     ctx = ctx or _lib.default_context()
     start = time.time()
     convolved = convolve(process, data, ctx)
     res = VariationalInference()
+    if not keep_trace and max_steps > 0:
+        update_(process, data, convolved, ctx, n_steps=max_steps)
+        res.trace.append(process.variational_params())
+        res.step = max_steps
     while res.step < max_steps:
         update_(process, data, convolved, ctx)
         res.trace.append(process.variational_params())

@@ -81,6 +81,9 @@ def test_vb_driver_and_errors(nhp):
     proc, data, *_ = make(nhp, 4, 200, 2, 4, seed=2)
     res = nhp.vb_(proc, data, max_steps=5)
     assert res.step == 5 and len(res.trace) == 5
+    proc2, _d, *_ = make(nhp, 4, 200, 2, 4, seed=2)
+    res2 = nhp.vb_(proc2, data, max_steps=5, keep_trace=False)      # 5 steps resident on the device
+    assert res2.step == 5 and np.allclose(res2.trace[-1], res.trace[-1], rtol=1e-12)
     assert np.all(proc.weights.νv == 1.0 + data.sum(axis=1)[:, None])
     netproc, *_ = make(nhp, 4, 200, 2, 4, seed=2, network=True)
     with pytest.raises(NotImplementedError):
