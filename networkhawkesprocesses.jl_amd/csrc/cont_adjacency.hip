@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adjacency(nhp_cont_args a, double
     int nk = -1;
     double nx = 0.0;
     if (N > 0 && start[0] + lane < start[1]) { nk = ent_k[base + start[0] + lane]; nx = ent_x[base + start[0] + lane]; }
-    for (int p = 0; p < ((a.dbg & 64) ? 0 : N); ++p) {
+    for (int p = 0; p < (NHP_SKIP(a, 64) ? 0 : N); ++p) {
         const int eb = start[p], ee = start[p + 1];
         const size_t kpc = (size_t)p + (size_t)c * N;
         const double aold = acol[p];

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
 
     // ---- stage column c; the node's first item also owns the column's integral term
     double integ = 0.0;
-    for (int p = tid; p < ((a.dbg & 2) ? 0 : N); p += NHP_WBLOCK) {
+    for (int p = tid; p < (NHP_SKIP(a, 2) ? 0 : N); p += NHP_WBLOCK) {
         const size_t k = (size_t)p + (size_t)c * N;
         double w = a.W[k], wint = w;
         if (a.A) {
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
     // round's window-sorted order
     constexpr int GW = 64 / G;
     const int slot0 = (gid / GW) * (GW * U) + (gid % GW);
-    for (int r0 = 0; r0 < ((a.dbg & 1) ? 0 : nchild); r0 += GROUPS * U) {
+    for (int r0 = 0; r0 < (NHP_SKIP(a, 1) ? 0 : nchild); r0 += GROUPS * U) {
         double t[U], s[U];
         int j[U], f[U], idx[U], kks[U];
         bool valid[U];
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
         bool more = false;
 #pragma unroll
         for (int u = 0; u < U; ++u) more |= j[u] >= f[u];
-        if (a.dbg & 8) more = false;
+        if (NHP_SKIP(a, 8)) more = false;
         nhp_event e[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) e[u] = a.ev[j[u] > 0 ? j[u] : 0];
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
     __syncthreads();
     // ---- deferred logs: every lane busy, one child each
     double acc = 0.0;
-    for (int k = tid; k < ((a.dbg & 4) ? 0 : nchild); k += NHP_WBLOCK) acc += nhp_log(lam_buf[k]);
+    for (int k = tid; k < (NHP_SKIP(a, 4) ? 0 : nchild); k += NHP_WBLOCK) acc += nhp_log(lam_buf[k]);
     const double blk = nhp_block_sum_n<NHP_WBLOCK / 64>(acc, red);
     const double blk_int = nhp_block_sum_n<NHP_WBLOCK / 64>(integ, red);
     if (!out) {

@@ -104,7 +104,7 @@ struct nhp_cont_args {
     int64_t M;
     int32_t N, grid_n, baseline_kind, impulse_kind;
     double dt_max, inv_dtmax, duration;
-    int32_t dbg;        // NHP_DBG ablation bits (timing experiments only; results are wrong when set)
+    int32_t dbg;        // phase-ablation bits; only read in -DNHP_ABLATE builds (tools/ablate.sh)
 };
 
 struct nhp_disc_dataset {
@@ -195,6 +195,14 @@ __device__ __forceinline__ double nhp_block_sum_n(double v, double *red)
 }
 
 __device__ __forceinline__ double nhp_block_sum(double v, double *red) { return nhp_block_sum_n<NHP_WAVES>(v, red); }
+
+// Phase ablation for timing experiments (tools/ablate.sh): compiled in only with -DNHP_ABLATE,
+// where env NHP_DBG selects phases to skip (results are then wrong by design).
+#ifdef NHP_ABLATE
+#define NHP_SKIP(a, bit) ((a).dbg & (bit))
+#else
+#define NHP_SKIP(a, bit) 0
+#endif
 
 // workgroup size of the windowed log-likelihood kernel (its own knob: more waves per staged column)
 #ifndef NHP_WBLOCK
