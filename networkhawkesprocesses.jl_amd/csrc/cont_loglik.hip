@@ -142,6 +142,36 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
         nhp_event e[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) e[u] = a.ev[j[u] > 0 ? j[u] : 0];
+        // steady state (wide groups = long windows only; measured slower for G <= 16): iterations in
+        // which every one of this lane's U slots still has a parent, so nothing is predicated ...
+        int nfull = G >= 32 ? 0x7fffffff : 0;
+        if (G >= 32) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int left = j[u] >= f[u] ? (j[u] - f[u]) / G + 1 : 0;
+                nfull = left < nfull ? left : nfull;
+            }
+        }
+        if (NHP_SKIP(a, 8)) nfull = 0;
+        for (int itn = 0; itn < nfull; ++itn) {
+            nhp_event en[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) en[u] = a.ev[j[u] - G > 0 ? j[u] - G : 0];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double dt = t[u] - e[u].t;
+                const double2 q = col[e[u].node];
+                if (IMP == NHP_IMPULSE_EXPONENTIAL) s[u] += q.y * nhp_pdf_exponential(q.x, dt);
+                else s[u] += colw[e[u].node] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
+                j[u] -= G;
+                e[u] = en[u];
+            }
+        }
+        // ... then the ragged tail, predicated per slot
+        more = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) more |= j[u] >= f[u];
+        if (NHP_SKIP(a, 8)) more = false;
         while (more) {
             nhp_event en[U];                       // next iteration's parents, in flight under the math
 #pragma unroll

@@ -23,9 +23,12 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 #define BM 128
 #define BN 128
+#ifndef BK
 #define BK 16
+#endif
+#define EPT (BK / 2)    // staged elements per thread and operand: 128 x BK tile / 256 threads
 #define A_MC_LD (BM + 16)     // m-contiguous image: row stride ≡ 128 B (mod 256) -> kk rows hit disjoint banks
-#define KC_LD (BK + 1)        // k-contiguous image: 136-B rows -> 16 lanes x 2 kk conflict-free
+#define KC_LD (BK + 2)        // k-contiguous image: row stride = 2 (mod 32) bank pairs -> 16 lanes x 2 kk conflict-free
 
 enum { EPI_INTENSITY = 0, EPI_LOGLIK = 1, EPI_VB_Z = 2, EPI_SLAB = 3 };
 
@@ -46,10 +49,11 @@ struct gemm_args {
 template <bool A_MCONTIG, int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 waves/SIMD: <= 256 VGPR+AGPR
 {
-    __shared__ double As[A_MCONTIG ? BK * A_MC_LD : BM * KC_LD];
-    __shared__ double Bs[BN * KC_LD];
-    __shared__ double red[NHP_WAVES];
-    __shared__ double wcol[NHP_WAVES][64];
+    extern __shared__ __align__(16) double gsm[];
+    double *As = gsm;                                              // [A_MCONTIG ? BK * A_MC_LD : BM * KC_LD]
+    double *Bs = As + (A_MCONTIG ? BK * A_MC_LD : BM * KC_LD);     // [BN * KC_LD]
+    double *red = Bs + BN * KC_LD;                                 // [NHP_WAVES]
+    double(*wcol)[64] = reinterpret_cast<double(*)[64]>(red + NHP_WAVES);   // [NHP_WAVES][64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -72,12 +76,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
         for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
     // per-thread staging coordinates: 8 consecutive elements along the contiguous dimension
-    // m-contig A: thread (k = tid/16, m = tid%16 + 16 e): at fixed e a wave covers 4 k-rows x 128 B,
+    // m-contig A: thread (k = tid/16 (+16 for the second half of a BK=32 tile), m = tid%16 + 16 e): at fixed e a wave covers 4 k-rows x 128 B,
     // coalesced in HBM and conflict-free as ds_write_b64 (consecutive lanes -> consecutive doubles)
-    const int a_k = A_MCONTIG ? tid >> 4 : (tid & 1) * 8;          // m-contig: k row;  k-contig: k offset
+    const int a_k = A_MCONTIG ? tid >> 4 : (tid & 1) * EPT;        // m-contig: k row;  k-contig: k offset
     const int a_m = A_MCONTIG ? (tid & 15) : tid >> 1;             // m-contig: m offset; k-contig: m row
-    const int b_k = (tid & 1) * 8, b_n = tid >> 1;
-    double ra[8], rb[8];
+    const int b_k = (tid & 1) * EPT, b_n = tid >> 1;
+    double ra[EPT], rb[EPT];
 
     // Per-thread operand pointers advance by one tile per iteration; the 8 elements of a thread sit
     // at compile-time offsets from them, so the loop carries no 64-bit index arithmetic (with one
@@ -88,15 +92,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
     const size_t a_step = A_MCONTIG ? (size_t)BK * g.lda : (size_t)BK;
     unsigned a_ok = 0;                       // bit e: row of element e is inside the matrix
 #pragma unroll
-    for (int e = 0; e < 8; ++e) a_ok |= ((A_MCONTIG ? m0 + a_m + 16 * e : m0 + a_m) < g.M ? 1u : 0u) << e;
+    for (int e = 0; e < 8; ++e) a_ok |= ((A_MCONTIG ? m0 + a_m + 16 * e : m0 + a_m) < g.M ? 1u : 0u) << e;   // bit e: m-slot e
     const bool b_ok = n0 + b_n < g.N;
 
     auto load_tiles = [&](int k0) {
         const bool full = k0 + BK <= kend;   // only the last tile of a ragged K needs per-element checks
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool ka = full || (A_MCONTIG ? k0 + a_k : k0 + a_k + e) < kend;
-            ra[e] = ((a_ok >> e) & 1u) && ka ? (A_MCONTIG ? pa[16 * e] : pa[e]) : 0.0;
+        for (int e = 0; e < EPT; ++e) {
+            // m-contig: element e = (m-slot e % 8, k-row a_k + 16 (e / 8)); k-contig: k offset a_k + e
+            const bool ka = full || (A_MCONTIG ? k0 + a_k + 16 * (e >> 3) : k0 + a_k + e) < kend;
+            const bool ma = A_MCONTIG ? ((a_ok >> (e & 7)) & 1u) : (a_ok & 1u);
+            ra[e] = ma && ka ? (A_MCONTIG ? pa[16 * (e & 7) + (size_t)(16 * (e >> 3)) * g.lda] : pa[e]) : 0.0;
             const bool kb = full || k0 + b_k + e < kend;
             rb[e] = b_ok && kb ? pb[e] : 0.0;
         }
@@ -105,8 +111,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (A_MCONTIG) As[a_k * A_MC_LD + a_m + 16 * e] = ra[e];
+        for (int e = 0; e < EPT; ++e) {
+            if (A_MCONTIG) As[(a_k + 16 * (e >> 3)) * A_MC_LD + a_m + 16 * (e & 7)] = ra[e];
             else As[a_m * KC_LD + a_k + e] = ra[e];
             Bs[b_n * KC_LD + b_k + e] = rb[e];
         }
@@ -462,7 +468,10 @@ template <bool AMC, int EPI>
 static void launch_gemm(const gemm_args &g, int splits, hipStream_t st)
 {
     dim3 grid((unsigned)((g.N + BN - 1) / BN), (unsigned)((g.M + BM - 1) / BM), (unsigned)splits);
-    hipLaunchKernelGGL((k_gemm_f64<AMC, EPI>), grid, dim3(256), 0, st, g);
+    const size_t lds = 8 * ((AMC ? BK * A_MC_LD : BM * KC_LD) + BN * KC_LD + NHP_WAVES + NHP_WAVES * 64);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)k_gemm_f64<AMC, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_gemm_f64<AMC, EPI>), grid, dim3(256), lds, st, g);
 }
 
 // uploads the model pieces, builds E and base on the device; returns pointers into scratch
