@@ -275,12 +275,16 @@ static void launch_group(int G, dim3 grid, size_t lds, hipStream_t st, const nhp
 {
 #define NHP_CASE(g, u)                                                                                        \
     case g:                                                                                                   \
+        if (lds > 64 * 1024)                                                                                  \
+            (void)hipFuncSetAttribute((const void *)k_windowed<IMP, g, u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_windowed<IMP, g, u>), grid, dim3(NHP_WBLOCK), lds, st, a, mask, partials,       \
                            lambda_out, counter, out);                                                         \
         break;
     switch (G) {
         NHP_CASE(1, NHP_U_SMALL) NHP_CASE(2, NHP_U_SMALL) NHP_CASE(4, NHP_U_SMALL) NHP_CASE(8, NHP_U_SMALL) NHP_CASE(16, NHP_U_MID) NHP_CASE(32, NHP_U_MID)
     default:
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)k_windowed<IMP, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_windowed<IMP, 64, 1>), grid, dim3(NHP_WBLOCK), lds, st, a, mask, partials, lambda_out, counter, out);
     }
 #undef NHP_CASE
@@ -292,7 +296,7 @@ static nhp_status run_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const n
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t per = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? 16 : 24;
     const size_t lds = 192 + per * (size_t)ds->N + 8 * (size_t)(ds->max_item > 0 ? ds->max_item : 1);
-    if (lds > 64 * 1024) { nhp_set_error(ctx, "n_nodes = %d exceeds the 64 KiB LDS column budget", ds->N); return NHP_ENOTIMPL; }
+    if (lds > 160 * 1024) { nhp_set_error(ctx, "n_nodes = %d exceeds the 160 KiB LDS column budget", ds->N); return NHP_ENOTIMPL; }
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)ds->n_items));
     nhp_cont_args a = nhp_make_args(ds, m);
     dim3 grid((unsigned)ds->n_items);

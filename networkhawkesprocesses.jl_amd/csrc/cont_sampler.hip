@@ -285,7 +285,11 @@ static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
     nhp_cont_args a = nhp_make_args(ds, m);
     const size_t per = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? 16 : 24;
     const size_t lds = per * N + 8 * (size_t)NHP_BLOCK * SAMP_CLD;
-    if (lds > 64 * 1024) { nhp_set_error(ctx, "n_nodes = %d exceeds the 64 KiB LDS column budget", ds->N); return NHP_ENOTIMPL; }
+    if (lds > 160 * 1024) { nhp_set_error(ctx, "n_nodes = %d exceeds the 160 KiB LDS column budget", ds->N); return NHP_ENOTIMPL; }
+    if (lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void *)k_sampler<NHP_IMPULSE_EXPONENTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)k_sampler<NHP_IMPULSE_LOGITNORMAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     dim3 grid((unsigned)ds->n_items);
     if (m->impulse_kind == NHP_IMPULSE_EXPONENTIAL)
         hipLaunchKernelGGL((k_sampler<NHP_IMPULSE_EXPONENTIAL>), grid, dim3(NHP_BLOCK), lds, st, a, d_u, seed, step,
@@ -296,7 +300,8 @@ static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
     NHP_HIP(ctx, hipGetLastError());
     if (want_stats) {
         const size_t lds_stats = 8 * (3 * N + NHP_BLOCK + NHP_WAVES) + 4 * NHP_BLOCK + 16;
-        if (lds_stats > 64 * 1024) { nhp_set_error(ctx, "statistics: n_nodes = %d exceeds the LDS budget", ds->N); return NHP_ENOTIMPL; }
+        if (lds_stats > 160 * 1024) { nhp_set_error(ctx, "statistics: n_nodes = %d exceeds the LDS budget", ds->N); return NHP_ENOTIMPL; }
+        if (lds_stats > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_stats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stats);
         hipLaunchKernelGGL(k_stats, dim3((unsigned)N), dim3(NHP_BLOCK), lds_stats, st, a, o->pn_b, o->dt_b, o->cnt0, o->Mn, o->Mnm, o->X, o->V);
         NHP_HIP(ctx, hipGetLastError());
     }

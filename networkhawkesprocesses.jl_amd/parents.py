@@ -34,7 +34,7 @@ def resample_parents(process, data, u=None, seed=0, step=0, with_stats=False, wa
         C.byref(st) if st is not None else None), ctx.h)
     if not with_stats:
         return parents, pnodes
-    stats = {k: (v if v.size == N else v.reshape((N, N), order="F")) for k, v in keep.items()}
+    stats = {k: (v if k in ("cnt0", "Mn") else v.reshape((N, N), order="F")) for k, v in keep.items()}
     return parents, pnodes, stats
 
 
