@@ -132,6 +132,10 @@ nhp_status nhp_cont_loglik(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_c
 nhp_status nhp_cont_loglik_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds,
                                    const nhp_cont_model *model, int32_t flags, int32_t slot);
 nhp_status nhp_ctx_fetch(nhp_ctx *ctx, int32_t first_slot, int32_t n, double *out);
+/* nb log-likelihoods of nb device-resident models on one dataset (the 2P objective calls of a
+ * finite-difference gradient, a population of chains): launched back to back, one synchronisation */
+nhp_status nhp_cont_loglik_batch(nhp_ctx *ctx, const nhp_cont_dataset *ds,
+                                 const nhp_cont_model *const *models, int32_t nb, int32_t flags, double *ll);
 
 /* log-likelihood and its analytic gradient in params! order [λ0; θ | μ; τ; W] (homogeneous
  * baseline).  Replaces the 2P finite-difference objective calls Optim makes inside mle!

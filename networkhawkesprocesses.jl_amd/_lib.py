@@ -73,6 +73,7 @@ def _declare(lib):
     f("nhp_cont_loglik", i32, _vp, _vp, _vp, i32, _dp)
     f("nhp_cont_loglik_enqueue", i32, _vp, _vp, _vp, i32, i32)
     f("nhp_ctx_fetch", i32, _vp, i32, i32, _dp)
+    f("nhp_cont_loglik_batch", i32, _vp, _vp, C.POINTER(_vp), i32, i32, _dp)
     f("nhp_cont_event_intensity", i32, _vp, _vp, _vp, _dp)
     f("nhp_cont_gibbs_step", i32, _vp, _vp, _vp, C.POINTER(GibbsPriors), u64, u64)
     f("nhp_cont_model_get_params", i32, _vp, _vp, _dp, i64)

@@ -350,6 +350,19 @@ extern "C" nhp_status nhp_cont_loglik(nhp_ctx *ctx, const nhp_cont_dataset *ds, 
     return nhp_ctx_fetch(ctx, 0, 1, ll);
 }
 
+// nb evaluations (finite-difference sweeps, chain populations) back to back, one synchronisation
+extern "C" nhp_status nhp_cont_loglik_batch(nhp_ctx *ctx, const nhp_cont_dataset *ds,
+                                            const nhp_cont_model *const *models, int32_t nb, int32_t flags, double *ll)
+{
+    if (!models || !ll || nb < 0) return NHP_EINVAL;
+    for (int32_t done = 0; done < nb; done += NHP_MAX_SLOTS) {
+        const int32_t n = nb - done < NHP_MAX_SLOTS ? nb - done : NHP_MAX_SLOTS;
+        for (int32_t k = 0; k < n; ++k) NHP_TRY(enqueue(ctx, ds, models[done + k], flags, k));
+        NHP_TRY(nhp_ctx_fetch(ctx, 0, n, ll + done));
+    }
+    return NHP_OK;
+}
+
 extern "C" nhp_status nhp_cont_event_intensity(nhp_ctx *ctx, const nhp_cont_dataset *ds,
                                                const nhp_cont_model *m, double *lambda)
 {

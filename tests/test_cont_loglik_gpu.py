@@ -156,3 +156,19 @@ def test_metric_size_properties(nhp, orc):
     a = nhp.loglikelihood(proc, data, recursive=False)
     b = nhp.loglikelihood(proc, data, recursive=True)
     assert rel(a, b) < 1e-9
+
+
+def test_batch_of_models(nhp, orc):
+    # nhp_cont_loglik_batch: several parameter sets on one dataset, one synchronisation
+    import ctypes as C
+    from nhp_amd import _lib
+    ctx = nhp.default_context()
+    cases = [random_case(6, 1500, 90.0, "exponential", 1.0, seed=s, nhp=nhp, orc=orc) for s in (50, 51, 52)]
+    data = cases[0]["data"]
+    ds = nhp.device_dataset(cases[0]["proc"], data, ctx)
+    models = [c["proc"].device_model(ctx) for c in cases]
+    arr = (C.c_void_p * 3)(*[m.h for m in models])
+    out = np.empty(3)
+    _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, ds.h, arr, 3, 0, _lib.dptr(out)), ctx.h)
+    for c, got in zip(cases, out):
+        assert rel(got, orc.loglik_windowed(c["om"], data[0], data[1], data[2])) < TOL
