@@ -34,16 +34,6 @@ __device__ __forceinline__ double adj_baseline(const nhp_cont_args &a, int c, do
     return (y[lo + 1] * (t - x[lo]) + y[lo] * (x[lo + 1] - t)) / (x[lo + 1] - x[lo]);
 }
 
-// wave-local ordering of LDS traffic: wait for this wave's outstanding LDS operations (lgkmcnt(0)
-// only -- global stores stay in flight) and keep the compiler from moving LDS accesses across it
-#define NHP_LDS_SYNC()                                   \
-    do {                                                 \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-        __builtin_amdgcn_s_waitcnt(0xc07f);              \
-        __builtin_amdgcn_wave_barrier();                 \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
-    } while (0)
-
 template <int IMP>
 __global__ __launch_bounds__(NHP_BLOCK) void k_adjacency(nhp_cont_args a, double *__restrict__ A,
                                                          const int64_t *__restrict__ pair_off,

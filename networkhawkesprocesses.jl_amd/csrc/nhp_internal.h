@@ -144,6 +144,17 @@ nhp_status nhp_launch_recursive(nhp_ctx *ctx, const nhp_cont_dataset *ds, const 
 nhp_status nhp_launch_finalize(nhp_ctx *ctx, const nhp_cont_args &a, int n_partials, double *d_out);
 nhp_status nhp_launch_event_intensity(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_lambda);
 
+// wave-local ordering of LDS traffic: wait for this wave's outstanding LDS operations (lgkmcnt(0)
+// only -- global stores stay in flight) and keep the compiler from moving LDS accesses across it
+#define NHP_LDS_SYNC()                                   \
+    do {                                                 \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_s_waitcnt(0xc07f);              \
+        __builtin_amdgcn_wave_barrier();                 \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+
 // ---- device helpers --------------------------------------------------------------------
 __device__ __forceinline__ double nhp_dpp_add(double v, const int sel)
 {
