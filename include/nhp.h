@@ -181,6 +181,16 @@ nhp_status nhp_cont_gibbs_step(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_con
 nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_model *model,
                                        const double *rho_matrix, double rho, const double *u,
                                        uint64_t seed, uint64_t step, double *A_out, double *n_links);
+/* loglikelihood(process::LogGaussianCoxProcess, data, node, y)  src/baselines.jl:247-254, for all
+ * nodes in one call: ll[c] = -trapezoid(lam_c) + Σ log lam_c(t_i) over node c's events that
+ * split_extract (:227-238) attributes to the baseline (sampled parent node 0).  lam [N*grid_n]
+ * (node c at c*grid_n) is the candidate intensity exp.(m .+ y_c) on grid_x [grid_n].  The
+ * attribution is `parentnodes` [M] (resample_parents' second vector) if non-NULL -- it then
+ * stays on the device with the dataset -- else the one left there by the latest
+ * nhp_cont_resample_parents / nhp_cont_gibbs_step on this dataset.  NHP_EDOMAIN if an event lies
+ * outside [grid_x[0], grid_x[end]] (the interpolator's DomainError, src/utils/interpolation.jl:27). */
+nhp_status nhp_cont_lgcp_loglik(nhp_ctx *ctx, const nhp_cont_dataset *ds, const int64_t *parentnodes,
+                                const double *grid_x, int32_t grid_n, const double *lam, double *ll);
 /* params(process) of the device-resident model: [λ0; θ | μ; τ; W]  src/continuous.jl:116-119 */
 nhp_status nhp_cont_model_get_params(nhp_ctx *ctx, const nhp_cont_model *model, double *x, int64_t len);
 /* the uniform stream itself (host side, same bits as the kernel draws) */

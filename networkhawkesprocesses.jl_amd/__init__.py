@@ -7,8 +7,9 @@ Julia's `f!` becomes `f_`.
 """
 from ._lib import Context, DomainError, NhpError, default_context  # noqa: F401
 from .components import (BernoulliNetworkModel, DenseNetworkModel, DenseWeightModel,  # noqa: F401
-                         ExponentialImpulseResponse, HomogeneousProcess, LogGaussianCoxProcess,
-                         LogitNormalImpulseResponse)
+                         ExponentialImpulseResponse, GaussianProcess, HomogeneousProcess,
+                         LogGaussianCoxProcess, LogitNormalImpulseResponse, OrnsteinUhlenbeckKernel,
+                         PeriodicKernel, SquaredExponentialKernel, split_extract)
 from .continuous import (ContinuousHawkesProcess, ContinuousNetworkHawkesProcess,  # noqa: F401
                          ContinuousStandardHawkesProcess, DeviceDataset, HawkesProcess, device_dataset,
                          loglikelihood_gradient, total_intensity)

@@ -71,9 +71,88 @@ class HomogeneousProcess(Baseline):
         return self.λ
 
 
+# ---- Gaussian-process plumbing of the LGCP baseline (src/utils/gaussian.jl, src/utils/helpers.jl:1-11)
+def posdef_(sigma, maxiter=3):
+    """posdef!: shift the diagonal until the smallest eigenvalue is positive -- src/utils/helpers.jl:1-11"""
+    sigma = np.array(sigma, dtype=np.float64)
+    for _ in range(maxiter):
+        eps = 2 * np.min(np.linalg.eigvalsh(sigma))
+        if eps > 0.0:
+            return sigma
+        sigma[np.diag_indices_from(sigma)] -= eps
+    print("WARNING: failed to make sigma positive definite")
+    return sigma
+
+
+class Kernel:
+    def __call__(self, x, y=None):
+        """kernel(x, y) on scalars; kernel(x::Vector) -> posdef!(Σ) -- src/utils/gaussian.jl:8-17"""
+        if y is not None:
+            return self.k(x, y)
+        x = np.asarray(x, dtype=np.float64)
+        return posdef_(self.k(x[:, None], x[None, :]))
+
+
+class SquaredExponentialKernel(Kernel):
+    """σ² exp(-((x-y)/η)²/2) -- src/utils/gaussian.jl:19-24"""
+
+    def __init__(self, σ, η):
+        self.σ, self.η = σ, η
+
+    def k(self, x, y):
+        return self.σ ** 2 * np.exp(-((x - y) / self.η) ** 2 / 2)
+
+
+class OrnsteinUhlenbeckKernel(Kernel):
+    """σ² exp(-|x-y|/η) -- src/utils/gaussian.jl:26-31"""
+
+    def __init__(self, σ, η):
+        self.σ, self.η = σ, η
+
+    def k(self, x, y):
+        return self.σ ** 2 * np.exp(-np.abs(x - y) / self.η)
+
+
+class PeriodicKernel(Kernel):
+    """σ² exp(-2 (sin(π|x-y|/θ)/η)²) -- src/utils/gaussian.jl:33-39"""
+
+    def __init__(self, σ, η, θ):
+        self.σ, self.η, self.θ = σ, η, θ
+
+    def k(self, x, y):
+        return self.σ ** 2 * np.exp(-2 * (np.sin(np.pi * np.abs(x - y) / self.θ) / self.η) ** 2)
+
+
+class GaussianProcess:
+    """GaussianProcess(kernel) / GaussianProcess(mu, kernel) -- src/utils/gaussian.jl:60-83"""
+
+    def __init__(self, *args):
+        self.mu, self.kernel = (np.zeros_like, args[0]) if len(args) == 1 else args
+
+    def cov(self, x):
+        return self.kernel(np.asarray(x, dtype=np.float64))
+
+    def rand(self, x, rng, sigma=None):
+        x = np.asarray(x, dtype=np.float64)
+        sigma = self.cov(x) if sigma is None else sigma
+        return np.asarray(self.mu(x), dtype=np.float64) + np.linalg.cholesky(sigma) @ rng.standard_normal(len(x))
+
+
+def split_extract(data, parents, nnodes):
+    """Events attributed to the baseline (parent node 0), split by node -- src/baselines.jl:227-238."""
+    events, nodes, duration = data
+    events, nodes = np.asarray(events, dtype=np.float64), np.asarray(nodes, dtype=np.int64)
+    parentnodes = np.asarray(parents[1], dtype=np.int64)
+    out = []
+    for node in range(1, nnodes + 1):
+        idx = np.flatnonzero((nodes == node) & (parentnodes == 0)) if len(nodes) else np.array([], dtype=np.int64)
+        out.append((events[idx], nodes[idx], duration))
+    return out
+
+
 class LogGaussianCoxProcess(Baseline):
-    """Evaluator part of LogGaussianCoxProcess(x, λ, Σ, m) -- src/baselines.jl:148-173:
-    piecewise-linear intensity through (x, λ[k]) per node (src/utils/interpolation.jl)."""
+    """LogGaussianCoxProcess(x, λ, Σ | kernel, m) -- src/baselines.jl:148-173: piecewise-linear
+    intensity through (x, λ[k]) per node (src/utils/interpolation.jl), λ = exp(m + y), y ~ N(0, Σ)."""
 
     def __init__(self, x, λ, Σ=None, m=0.0):
         x = np.asarray(x, dtype=np.float64)
@@ -84,21 +163,81 @@ class LogGaussianCoxProcess(Baseline):
         for v in self.λ:
             if len(v) != len(x):
                 raise ValueError("intensity vectors must match the grid")
-        self.Σ, self.m = Σ, float(m)
+        self.Σ = Σ(x) if isinstance(Σ, Kernel) else (None if Σ is None else np.asarray(Σ, dtype=np.float64))
+        self.m = float(m)
+
+    @classmethod
+    def from_gp(cls, gp, m, T, n, k, rng):
+        """LogGaussianCoxProcess(gp, m, T, n, k): random intensities on n+1 grid points -- src/baselines.jl:164-171"""
+        x = np.linspace(0.0, T, n + 1)
+        Σ = gp.cov(x)
+        return cls(x, [np.exp(m + gp.rand(x, rng, sigma=Σ)) for _ in range(k)], Σ, m)
 
     def ndims(self):
         return len(self.λ)
 
-    def __len__(self):
-        return self.x[-1]
+    def length(self):
+        """length(process) = x[end], the longest duration the process supports -- src/baselines.jl:173"""
+        return float(self.x[-1])
 
     def params(self):
         return np.concatenate(self.λ)
+
+    def params_(self, x):
+        """params!: src/baselines.jl:175-188"""
+        if len(x) != sum(len(v) for v in self.λ):
+            raise ValueError("Parameter vector length does not match model parameter length.")
+        G = len(self.x)
+        self.λ = [np.array(x[k * G:(k + 1) * G], dtype=np.float64) for k in range(len(self.λ))]
 
     def integrated_intensity(self, duration=None):
         """integrate.(LinearInterpolator) -- src/baselines.jl:336; ignores duration"""
         dx = np.diff(self.x)
         return np.array([np.sum(0.5 * (y[:-1] + y[1:]) * dx) for y in self.λ])
+
+    def candidate_loglikelihood(self, ds, Y, parentnodes=None):
+        """loglikelihood(process, data, node, y) (src/baselines.jl:247-254) of latent curves Y [N, G],
+        one per node, in a single GPU call.  The baseline-attributed events are those the latest
+        parent sweep left on the device with `ds`, unless `parentnodes` is given."""
+        from . import _lib
+        lam = _lib.f64(np.exp(self.m + np.asarray(Y, dtype=np.float64)).ravel())
+        pn = None if parentnodes is None else np.ascontiguousarray(parentnodes, dtype=np.int64)
+        out = np.empty(self.ndims())
+        _lib.check(_lib.lib().nhp_cont_lgcp_loglik(ds.ctx.h, ds.h, _lib.iptr(pn), _lib.dptr(self.x), len(self.x),
+                                                   _lib.dptr(lam), _lib.dptr(out)), ds.ctx.h)
+        return out
+
+    def resample_(self, ds, rng, parentnodes=None, max_attempts=100):
+        """resample!(process, data, parents; sampler=elliptical_slice) -- src/baselines.jl:212-245,287-326
+        (Murray et al. 2010).  The reference runs one slice loop per node; the loops are independent,
+        so they advance in lock step here and each round scores the pending candidates of all nodes
+        with one GPU call."""
+        if self.Σ is None:
+            raise ValueError("LogGaussianCoxProcess needs Σ to be resampled")
+        N, G = self.ndims(), len(self.x)
+        L = np.linalg.cholesky(self.Σ)
+        Y = np.log(np.vstack(self.λ)) - self.m                      # init_y: :241
+        V = rng.standard_normal((N, G)) @ L.T                       # v ~ N(0, Σ)
+        lly = self.candidate_loglikelihood(ds, Y, parentnodes) + np.log(rng.uniform(size=N))
+        θ = 2 * np.pi * rng.uniform(size=N)
+        θmin, θmax = θ - 2 * np.pi, θ.copy()
+        Ynew = Y * np.cos(θ)[:, None] + V * np.sin(θ)[:, None]
+        done = self.candidate_loglikelihood(ds, Ynew) >= lly
+        attempts = 1
+        while not done.all():
+            if attempts >= max_attempts:
+                raise RuntimeError("Elliptical slice sampling reached maximum attempts.")
+            attempts += 1
+            todo = ~done
+            neg = θ < 0.0
+            θmin = np.where(todo & neg, θ, θmin)
+            θmax = np.where(todo & ~neg, θ, θmax)
+            θ = np.where(todo, θmin + (θmax - θmin) * rng.uniform(size=N), θ)
+            cand = Y * np.cos(θ)[:, None] + V * np.sin(θ)[:, None]
+            Ynew = np.where(todo[:, None], cand, Ynew)              # accepted nodes keep their draw
+            done = done | (todo & (self.candidate_loglikelihood(ds, Ynew) >= lly))
+        self.λ = [np.exp(self.m + Ynew[k]) for k in range(N)]       # resample_node!: :242-244
+        return [v.copy() for v in self.λ]
 
 
 # ------------------------------------------------------------------------------ impulses

@@ -176,6 +176,11 @@ extern "C" nhp_status nhp_cont_dataset_create(nhp_ctx *ctx, const double *events
         nhp_cont_dataset_destroy(ds);
         return s;
     }
+    if (hipMalloc((void **)&ds->d_pn, 4 * (size_t)(M ? M : 1)) != hipSuccess) {
+        nhp_set_error(ctx, "out of device memory (parent-node buffer)");
+        nhp_cont_dataset_destroy(ds);
+        return NHP_ENOMEM;
+    }
     hipError_t e = hipStreamSynchronize(ctx->stream);   // host vectors go out of scope below
     if (e != hipSuccess) { nhp_set_error(ctx, "upload failed: %s", hipGetErrorString(e)); nhp_cont_dataset_destroy(ds); return NHP_EHIP; }
     *out = ds;
@@ -188,7 +193,7 @@ extern "C" void nhp_cont_dataset_destroy(nhp_cont_dataset *ds)
     (void)hipSetDevice(ds->ctx->device);
     (void)hipStreamSynchronize(ds->ctx->stream);
     (void)hipFree(ds->d_times); (void)hipFree(ds->d_nodes); (void)hipFree(ds->d_child); (void)hipFree(ds->d_child_w); (void)hipFree(ds->d_ev);
-    (void)hipFree(ds->d_boff); (void)hipFree(ds->d_items); (void)hipFree(ds->d_cnt);
+    (void)hipFree(ds->d_boff); (void)hipFree(ds->d_items); (void)hipFree(ds->d_cnt); (void)hipFree(ds->d_pn);
     delete ds;
 }
 

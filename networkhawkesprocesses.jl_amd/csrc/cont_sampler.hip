@@ -267,13 +267,14 @@ static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
     const size_t M = (size_t)ds->M, N = (size_t)ds->N, NN = N * N, Mp = M ? M : 1;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t r = off; off += (bytes + 255) & ~(size_t)255; return r; };
-    const size_t o_par = carve(8 * Mp), o_pno = carve(8 * Mp), o_pnb = carve(4 * Mp), o_dtb = carve(8 * Mp);
+    const size_t o_par = carve(8 * Mp), o_pno = carve(8 * Mp), o_dtb = carve(8 * Mp);
     const size_t o_u = carve(u ? 8 * Mp : 8), o_err = carve(8);
     const size_t o_cnt0 = carve(8 * N), o_Mn = carve(8 * N), o_Mnm = carve(8 * NN), o_X = carve(8 * NN), o_V = carve(8 * NN);
     NHP_TRY(nhp_ctx_reserve_scratch(ctx, off));
     char *base = (char *)ctx->d_scratch;
     o->parents = (int64_t *)(base + o_par); o->pnodes = (int64_t *)(base + o_pno);
-    o->pn_b = (int32_t *)(base + o_pnb); o->dt_b = (double *)(base + o_dtb);
+    o->pn_b = ds->d_pn;                      // kept with the dataset: the LGCP baseline update reads it later
+    o->dt_b = (double *)(base + o_dtb);
     o->cnt0 = (double *)(base + o_cnt0); o->Mn = (double *)(base + o_Mn); o->Mnm = (double *)(base + o_Mnm);
     o->X = (double *)(base + o_X); o->V = (double *)(base + o_V);
     double *d_u = u ? (double *)(base + o_u) : nullptr;
@@ -298,6 +299,7 @@ static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
         hipLaunchKernelGGL((k_sampler<NHP_IMPULSE_LOGITNORMAL>), grid, dim3(NHP_BLOCK), lds, st, a, d_u, seed, step,
                            want_parents ? o->parents : nullptr, want_parents ? o->pnodes : nullptr, o->pn_b, o->dt_b, d_err);
     NHP_HIP(ctx, hipGetLastError());
+    ds->pn_valid = true;
     if (want_stats) {
         const size_t lds_stats = 8 * (3 * N + NHP_BLOCK + NHP_WAVES) + 4 * NHP_BLOCK + 16;
         if (lds_stats > 160 * 1024) { nhp_set_error(ctx, "statistics: n_nodes = %d exceeds the LDS budget", ds->N); return NHP_ENOTIMPL; }

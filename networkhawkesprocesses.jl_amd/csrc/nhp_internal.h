@@ -73,6 +73,8 @@ struct nhp_cont_dataset {
     int32_t *d_boff = nullptr;          // [N+1] bucket offsets
     nhp_item *d_items = nullptr;        // [n_items]
     double *d_cnt = nullptr;            // [N] events per node
+    int32_t *d_pn = nullptr;            // [M] bucket order: parent node of each child from the latest parent sweep (-1 = baseline)
+    mutable bool pn_valid = false;      // d_pn holds an assignment (set by the sampler / nhp_cont_lgcp_loglik)
     // host copies kept for host-side helpers
     std::vector<int32_t> h_boff;
     std::vector<double> h_cnt;

@@ -166,7 +166,10 @@ def resample_(process, data, rng, step=0, seed=0, ctx=None):
     numpy; the network process then resamples its adjacency matrix on the GPU and redraws ρ."""
     _, _, st = resample_parents(process, data, seed=seed, step=step, with_stats=True, want_parents=False, ctx=ctx)
     duration = data.duration if hasattr(data, "duration") else data[2]
-    process.baseline.resample_(st["cnt0"], duration, rng)
+    if isinstance(process.baseline, HomogeneousProcess):
+        process.baseline.resample_(st["cnt0"], duration, rng)
+    else:       # LGCP: elliptical slice on the events the sweep above attributed to the baseline
+        process.baseline.resample_(device_dataset(process, data, ctx), rng)
     process.weights.resample_(st["Mn"], st["Mnm"], rng)
     if isinstance(process.impulses, ExponentialImpulseResponse):
         process.impulses.resample_(st["Mnm"], st["Xnm"], rng)
@@ -209,7 +212,7 @@ def mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, keep_
     different seeds are independent (one per GPU: chains.py)."""
     import ctypes as C
     if not isinstance(process.baseline, HomogeneousProcess):
-        raise NotImplementedError("mcmc!: LGCP baseline resampling (src/baselines.jl:212-326) is out of scope")
+        device_draws = False      # nhp_cont_gibbs_step draws the homogeneous λ0; the LGCP curve is a host slice loop
     ctx = ctx or _lib.default_context()
     ds = device_dataset(process, data, ctx)
     rng = np.random.default_rng(seed)

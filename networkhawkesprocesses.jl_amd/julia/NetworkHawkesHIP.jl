@@ -135,4 +135,18 @@ function loglikelihood_gradient(p::NHP.ContinuousStandardHawkesProcess, data; re
     ll[], g
 end
 
+# loglikelihood(process::LogGaussianCoxProcess, data, node, y) for every node at once
+# (src/baselines.jl:247-254): Y is G x N, column c the candidate latent curve of node c.
+# `parentnodes === nothing` reuses the attribution the latest resample_parents left on the device.
+function lgcp_loglikelihood(b::NHP.LogGaussianCoxProcess, ds::Dataset, Y::Matrix{Float64};
+                            parentnodes::Union{Nothing,Vector{Int64}}=nothing, ctx=context())
+    lam = exp.(b.m .+ Y)
+    ll = Vector{Float64}(undef, size(Y, 2))
+    pn = parentnodes === nothing ? Ptr{Int64}(C_NULL) : pointer(parentnodes)
+    GC.@preserve parentnodes lam ll check(ccall((:nhp_cont_lgcp_loglik, libnhp), Int32,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}),
+        ctx.h, ds.h, pn, b.x, Int32(length(b.x)), lam, ll), ctx.h)
+    ll
+end
+
 end # module

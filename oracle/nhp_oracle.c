@@ -740,3 +740,24 @@ int orc_disc_vb_step(const int64_t *data, const double *conv, int64_t T, int32_t
     free(u); free(e0); free(E);
     return ORC_OK;
 }
+
+/* loglikelihood(process::LogGaussianCoxProcess, data, node, y) for every node at once:
+ * src/baselines.jl:247-254 on the events split_extract (:227-238) keeps -- node c's events whose
+ * sampled parent node is 0 (the baseline).  lam[c*G + k] = exp(m + y_c[k]) is the candidate
+ * intensity on the grid; ll[c] = -trapezoid(lam_c) + sum_i log lam_c(t_i). */
+int orc_lgcp_loglik(const double *times, const int64_t *nodes, const int64_t *parentnodes, int64_t M,
+                    int32_t N, const double *grid_x, int32_t G, const double *lam, double *ll)
+{
+    for (int32_t c = 0; c < N; ++c) ll[c] = -orc_linear_integrate(grid_x, lam + (size_t)c * G, G);
+    for (int64_t i = 0; i < M; ++i) {
+        if (parentnodes[i] != 0) continue;
+        const int64_t c = nodes[i] - 1;
+        if (c < 0 || c >= N) return ORC_EDOMAIN;
+        double f;
+        int rc = orc_linear_interpolate(grid_x, lam + (size_t)c * G, G, times[i], &f);
+        if (rc != ORC_OK) return rc;
+        ll[c] += log(f);
+    }
+    return ORC_OK;
+}
+

@@ -94,6 +94,10 @@ void orc_log_duration_stats(const double *times, const int64_t *nodes, const int
 int orc_cont_resample_adjacency(const orc_cont_model *m, const double *times, const int64_t *nodes,
                                 int64_t M, double duration, const double *rho, const double *u, double *A);
 
+/* ---- LGCP baseline likelihood inside the elliptical-slice sampler (src/baselines.jl:227-254) */
+int orc_lgcp_loglik(const double *times, const int64_t *nodes, const int64_t *parentnodes, int64_t M,
+                    int32_t N, const double *grid_x, int32_t G, const double *lam, double *ll);
+
 /* ---- analytic gradient of the continuous ll (formulas: SURVEY.md 7; no reference code) */
 int orc_cont_loglik_grad(const orc_cont_model *m, const double *times, const int64_t *nodes,
                          int64_t M, double duration, int recursive, double *ll, double *grad);

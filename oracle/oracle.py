@@ -228,6 +228,16 @@ def resample_adjacency(model, times, nodes, duration, rho, u):
     return A.reshape(model.A.shape, order="F")
 
 
+def lgcp_loglik(times, nodes, parentnodes, N, grid_x, lam):
+    """ll[c] of the baseline-attributed events of every node under candidate grid intensities lam [N, G]."""
+    t, n, tp, np_, M = _data(times, nodes)
+    pn, pnp = _i64(parentnodes)
+    x, L = _f(grid_x), _f(np.asarray(lam, dtype=np.float64).reshape(N, -1))
+    out = np.empty(N)
+    _chk(lib().orc_lgcp_loglik(tp, np_, pnp, M, C.c_int32(N), _p(x), C.c_int32(len(x)), _p(L), _p(out)))
+    return out
+
+
 def loglik_grad(model, times, nodes, duration, recursive=False):
     t, n, tp, np_, M = _data(times, nodes)
     N = model.N
