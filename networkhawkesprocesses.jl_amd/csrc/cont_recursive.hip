@@ -42,14 +42,16 @@ __device__ __forceinline__ double rec_baseline(const nhp_cont_args &a, int c, do
 // pass) and TWO segment accumulators, so that folding segment k+1 and consuming segment k share
 // one barrier interval: one barrier per child instead of two, and two independent instruction
 // streams for the scheduler to interleave.
-#define REC_PQ 8     // parent nodes per thread (N <= 2048)
-
-__global__ __launch_bounds__(NHP_BLOCK) void k_recursive(nhp_cont_args a, double *__restrict__ partials)
+// BLOCK threads, PQ parent nodes per thread (N <= BLOCK * PQ); the launcher picks 256 x 8 up to
+// N = 2048 and 512 x 8 up to 4096.
+template <int BLOCK, int PQ>
+__global__ __launch_bounds__(BLOCK) void k_recursive(nhp_cont_args a, double *__restrict__ partials)
 {
+    constexpr int WAVES = BLOCK / 64, REC_PQ = PQ;
     extern __shared__ __align__(16) unsigned char smem[];
-    double *red = reinterpret_cast<double *>(smem);              // [4]
-    double *ring = red + 4;                                      // [2][NHP_RING * NHP_WAVES]
-    double *th = ring + 2 * NHP_RING * NHP_WAVES;                // [N] θ[p,c]
+    double *red = reinterpret_cast<double *>(smem);              // [8]
+    double *ring = red + 8;                                      // [2][NHP_RING * WAVES]
+    double *th = ring + 2 * NHP_RING * WAVES;                // [N] θ[p,c]
     double *acc0 = th + a.N;                                     // [N] segment accumulators (double-buffered)
     double *acc1 = acc0 + a.N;
 
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_recursive(nhp_cont_args a, double
     double integ = 0.0;
 #pragma unroll
     for (int q = 0; q < REC_PQ; ++q) {
-        const int p = tid + q * NHP_BLOCK;
+        const int p = tid + q * BLOCK;
         S[q] = 0.0; thr[q] = 0.0; wthr[q] = 0.0;
         if (p < N) {
             const size_t k = (size_t)p + (size_t)c * N;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_recursive(nhp_cont_args a, double
 
     // fold the events of [jb, je) into acc, referenced to time tk  (t_j > 0: the D9 seen-flag)
     auto fold = [&](double *acc, int jb, int je, double tk) {
-        for (int j = jb + tid; j < je; j += NHP_BLOCK) {
+        for (int j = jb + tid; j < je; j += BLOCK) {
             const nhp_event e = a.ev[j];
             if (e.t > 0.0) atomicAdd(&acc[e.node], nhp_exp_neg(-(th[e.node] * (tk - e.t))));
         }
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_recursive(nhp_cont_args a, double
         double part = 0.0;
 #pragma unroll
         for (int q = 0; q < REC_PQ; ++q) {
-            const int p = tid + q * NHP_BLOCK;
+            const int p = tid + q * BLOCK;
             if (p < N) {
                 double s = S[q];
                 if (k != kb) s *= nhp_exp_neg(-(thr[q] * gap));
@@ -120,13 +122,13 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_recursive(nhp_cont_args a, double
         part = nhp_wave_sum(part);
         const int slot = (k - kb) & (NHP_RING - 1);
         const int half = ((k - kb) / NHP_RING) & 1;
-        if (lane == 0) ring[(half * NHP_RING + slot) * NHP_WAVES + wave] = part;
+        if (lane == 0) ring[(half * NHP_RING + slot) * WAVES + wave] = part;
         __syncthreads();
         if (slot == NHP_RING - 1 || k == ke - 1) {
             if (tid <= slot) {
                 const double tk = a.child[k - slot + tid].t;
                 double lam = rec_baseline(a, c, tk);
-                for (int w = 0; w < NHP_WAVES; ++w) lam += ring[(half * NHP_RING + tid) * NHP_WAVES + w];
+                for (int w = 0; w < WAVES; ++w) lam += ring[(half * NHP_RING + tid) * WAVES + w];
                 logsum += nhp_log(lam);
             }
         }
@@ -134,8 +136,8 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_recursive(nhp_cont_args a, double
         ch_t = nx_t; ch_idx = nx_idx;
         nx_t = nn_t; nx_idx = nn_idx;
     }
-    const double blk = nhp_block_sum(logsum, red);
-    const double blk_int = nhp_block_sum(integ, red);
+    const double blk = nhp_block_sum_n<WAVES>(logsum, red);
+    const double blk_int = nhp_block_sum_n<WAVES>(integ, red);
     if (tid == 0) {
         partials[2 * (size_t)c] = blk;
         partials[2 * (size_t)c + 1] = blk_int;
@@ -146,12 +148,20 @@ nhp_status nhp_launch_recursive(nhp_ctx *ctx, const nhp_cont_dataset *ds, const 
 {
     if (m->impulse_kind != NHP_IMPULSE_EXPONENTIAL) return NHP_EINVAL;
     NHP_HIP(ctx, hipSetDevice(ctx->device));
-    if (ds->N > REC_PQ * NHP_BLOCK) { nhp_set_error(ctx, "recursive ll: n_nodes = %d > %d not supported", ds->N, REC_PQ * NHP_BLOCK); return NHP_ENOTIMPL; }
-    const size_t lds = sizeof(double) * (4 + 2 * NHP_RING * NHP_WAVES + 3 * (size_t)ds->N);
-    if (lds > 64 * 1024) { nhp_set_error(ctx, "recursive ll: n_nodes = %d exceeds the 64 KiB LDS state budget", ds->N); return NHP_ENOTIMPL; }
+    if (ds->N > 4096) { nhp_set_error(ctx, "recursive ll: n_nodes = %d > 4096 not supported", ds->N); return NHP_ENOTIMPL; }
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)ds->N));
     nhp_cont_args a = nhp_make_args(ds, m);
-    hipLaunchKernelGGL(k_recursive, dim3((unsigned)ds->N), dim3(NHP_BLOCK), lds, ctx->stream, a, ctx->d_partials);
+#define NHP_REC_LAUNCH(B, Q)                                                                                   \
+    do {                                                                                                       \
+        const size_t lds = sizeof(double) * (8 + 2 * NHP_RING * ((B) / 64) + 3 * (size_t)ds->N);               \
+        if (lds > 64 * 1024)                                                                                   \
+            (void)hipFuncSetAttribute((const void *)k_recursive<B, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_recursive<B, Q>), dim3((unsigned)ds->N), dim3(B), lds, ctx->stream, a, ctx->d_partials); \
+    } while (0)
+    // measured at N = 1024, M = 1e6: 256 x 8 3.16 ms, 256 x 4 3.18, 512 x 4 3.35, 128 x 8 4.19, 64 x 16 7.35
+    if (ds->N <= 2048) NHP_REC_LAUNCH(256, 8);
+    else NHP_REC_LAUNCH(512, 8);
+#undef NHP_REC_LAUNCH
     NHP_HIP(ctx, hipGetLastError());
     return nhp_launch_finalize(ctx, a, ds->N, d_out);
 }

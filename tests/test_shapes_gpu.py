@@ -43,6 +43,7 @@ CASES = [  # N, M, T, kind, dt_max, network, skew
     (257, 9000, 30.0, "logitnormal", 5.0, False, False),         # ~1500 parents per window
     (64, 6000, 1e7, "exponential", 1e-3, False, False),          # every window empty
     (4500, 40000, 2000.0, "exponential", 0.2, False, False),     # columns above the default 64 KiB LDS carve-out
+    (3000, 30000, 1500.0, "exponential", 0.3, False, False),     # recursive kernel's 512-thread variant (2048 < N <= 4096)
 ]
 
 
@@ -53,7 +54,7 @@ def test_loglik_sampler_and_gradient_on_awkward_shapes(nhp, orc, N, M, T, kind, 
     got = nhp.loglikelihood(proc, data, recursive=False)
     want = orc.loglik_windowed(om, t, n, dur, flags=orc.FAST_INTEGRAL)
     assert rel(got, want) < 1e-11
-    if kind == "exponential" and N <= 2048:                       # recursive kernel: register-resident state, N <= 2048
+    if kind == "exponential" and N <= 4096:                       # recursive kernel: register-resident state, N <= 4096
         got = nhp.loglikelihood(proc, data, recursive=True)
         want = orc.loglik_recursive(om, t, n, dur, flags=orc.FAST_INTEGRAL)
         assert rel(got, want) < 1e-11
