@@ -203,11 +203,15 @@ static void launch_grad_group(int G, dim3 grid, size_t lds, hipStream_t st, cons
 {
 #define NHP_CASE(g)                                                                                      \
     case g:                                                                                              \
+        if (lds > 64 * 1024)                                                                             \
+            (void)hipFuncSetAttribute((const void *)k_grad_windowed<IMP, g>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_grad_windowed<IMP, g>), grid, dim3(NHP_BLOCK), lds, st, a, lambda, grad);  \
         break;
     switch (G) {
         NHP_CASE(1) NHP_CASE(2) NHP_CASE(4) NHP_CASE(8) NHP_CASE(16) NHP_CASE(32)
     default:
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)k_grad_windowed<IMP, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_grad_windowed<IMP, 64>), grid, dim3(NHP_BLOCK), lds, st, a, lambda, grad);
     }
 #undef NHP_CASE
@@ -244,7 +248,7 @@ extern "C" nhp_status nhp_cont_loglik_grad(nhp_ctx *ctx, const nhp_cont_dataset 
         NHP_TRY(nhp_launch_event_intensity(ctx, ds, m, d_lambda));          // pass A: partials + λ_i
         NHP_TRY(nhp_launch_finalize(ctx, a, ds->n_items, ctx->d_results));
         const size_t lds = 32 + 16 * N + 8 * N * (exp_imp ? 2 : 3);
-        if (lds > 64 * 1024) { nhp_set_error(ctx, "gradient: n_nodes = %d exceeds the 64 KiB LDS budget", ds->N); return NHP_ENOTIMPL; }
+        if (lds > 160 * 1024) { nhp_set_error(ctx, "gradient: n_nodes = %d exceeds the 160 KiB LDS budget", ds->N); return NHP_ENOTIMPL; }
         dim3 grid((unsigned)ds->n_items);
         if (exp_imp) launch_grad_group<NHP_IMPULSE_EXPONENTIAL>(ds->group, grid, lds, st, a, d_lambda, d_grad);
         else launch_grad_group<NHP_IMPULSE_LOGITNORMAL>(ds->group, grid, lds, st, a, d_lambda, d_grad);
