@@ -6,14 +6,16 @@
 // node (2·N² event scans per sweep).  Columns are independent; inside column c the entries are
 // sampled one parent node after the other, each conditional on the current state of the column.
 //
-// Here workgroup c owns column c.  Phase 1 evaluates every parent-child pair of the column ONCE,
-// x = W[p,c]·ħ(Δt), and counting-sorts the pairs by parent node p into (child slot, x) lists, while
-// λ_k = λ0 + Σ A[p,c]·x is accumulated per child in LDS.  Phase 2 walks p = 1..N: only the children
-// that have a parent on node p are touched --
+// Here column c is owned by one workgroup per phase.  Phase 1 (k_adj_pairs, 256 lanes) evaluates every
+// parent-child pair of the column ONCE, x = W[p,c]·ħ(Δt), and counting-sorts the pairs by parent node
+// p into (child slot, x) lists, while λ_k = λ0 + Σ A[p,c]·x is accumulated per child.  Phase 2
+// (k_adj_sweep, one wave) walks p = 1..N: only the children that have a parent on node p are touched --
 //     ll1 - ll0 = -W[p,c]·cnt[p] + Σ_k [log(λ_k⁰ + x_kp) - log λ_k⁰] + log ρ - log(1-ρ),
 // (the baseline integral and the first event's dropped term, SURVEY D10, cancel) -- the entry is
 // drawn with the reference's Bernoulli rule u <= exp(ll1 - logsumexp(ll0, ll1)), and the affected
-// λ_k are updated.  Work per sweep: Σ pairs instead of 2·N²·M.
+// λ_k are updated.  Work per sweep: Σ pairs instead of 2·N²·M.  The phases are separate kernels because
+// the sweep is a serial chain per column: what matters is that ALL columns run at once, and a one-wave
+// workgroup with 20 bytes of LDS per child fits 6+ to a CU where the fused kernel (72 KB) fit two.
 #include <algorithm>
 
 #include "nhp_internal.h"
@@ -35,21 +37,21 @@ __device__ __forceinline__ double adj_baseline(const nhp_cont_args &a, int c, do
 }
 
 template <int IMP>
-__global__ __launch_bounds__(NHP_BLOCK) void k_adjacency(nhp_cont_args a, double *__restrict__ A,
+__global__ __launch_bounds__(NHP_BLOCK) void k_adj_pairs(nhp_cont_args a, const double *__restrict__ A,
                                                          const int64_t *__restrict__ pair_off,
                                                          int32_t *__restrict__ ent_k, double *__restrict__ ent_x,
-                                                         const double *__restrict__ rho_mat, double rho_scalar,
-                                                         const double *__restrict__ u, uint64_t seed, uint64_t step,
-                                                         int max_children, double *__restrict__ col_links)
+                                                         int max_children, int group, int32_t *__restrict__ col_start,
+                                                         double *__restrict__ lam_g)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int N = a.N, c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = a.N, c = blockIdx.x, tid = threadIdx.x;
+    // `group` lanes share a child (the dataset's lanes-per-child width, a power of two <= 64), so a wave
+    // has 64/group windows in flight instead of one
+    const int gl = tid & (group - 1), gid = tid / group, ngroups = NHP_BLOCK / group;
     double2 *col = reinterpret_cast<double2 *>(smem + 64);                 // [N] exp {θ, W}; logit {μ, √τ}
     double *colw = reinterpret_cast<double *>(col + N);                    // [N] logit: W
     double *lam = colw + (IMP == NHP_IMPULSE_EXPONENTIAL ? 0 : N);         // [max_children] current λ_k
-    double *dx = lam + max_children;                                       // [max_children] Σ x_kp of the current p
-    int *marker = reinterpret_cast<int *>(dx + max_children);              // [max_children]
-    int *start = marker + max_children;                                    // [N + 1] pair-list offsets by p
+    int *start = reinterpret_cast<int *>(lam + max_children);              // [N + 1] pair-list offsets by p
     int *cursor = start + N + 1;                                           // [N]
     int *scan_tmp = cursor + N;                                            // [NHP_BLOCK]
 
@@ -64,17 +66,13 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adjacency(nhp_cont_args a, double
         }
         cursor[p] = 0;
     }
-    for (int k = tid; k < nchild; k += NHP_BLOCK) {
-        lam[k] = adj_baseline(a, c, a.child[kb + k].t);
-        dx[k] = 0.0;
-        marker[k] = 0;
-    }
+    for (int k = tid; k < nchild; k += NHP_BLOCK) lam[k] = adj_baseline(a, c, a.child[kb + k].t);
     __syncthreads();
 
-    // ---- phase 1a: pairs per parent node
-    for (int k = wave; k < nchild; k += NHP_WAVES) {
+    // ---- pairs per parent node
+    for (int k = gid; k < nchild; k += ngroups) {
         const nhp_child ch = a.child[kb + k];
-        for (int j = ch.first + lane; j < ch.idx; j += 64) atomicAdd(&cursor[a.nodes[j]], 1);
+        for (int j = ch.first + gl; j < ch.idx; j += group) atomicAdd(&cursor[a.nodes[j]], 1);
     }
     __syncthreads();
     // exclusive scan of cursor -> start (each thread scans a contiguous chunk, thread 0 the chunk sums)
@@ -100,13 +98,14 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adjacency(nhp_cont_args a, double
     for (int p = tid; p < N; p += NHP_BLOCK) cursor[p] = 0;
     __syncthreads();
 
-    // ---- phase 1b: evaluate every pair once, scatter by parent node, accumulate λ_k
+    // ---- evaluate every pair once, scatter by parent node, accumulate λ_k
     const int64_t base = pair_off[c];
-    for (int k = wave; k < nchild; k += NHP_WAVES) {
+    for (int k = gid; k < nchild; k += ngroups) {
         const nhp_child ch = a.child[kb + k];
-        for (int j = ch.first + lane; j < ch.idx; j += 64) {
-            const int p = a.nodes[j];
-            const double dt = ch.t - a.times[j];
+        for (int j = ch.first + gl; j < ch.idx; j += group) {
+            const nhp_event e = a.ev[j];
+            const int p = e.node;
+            const double dt = ch.t - e.t;
             const double2 q = col[p];
             double x;
             if (IMP == NHP_IMPULSE_EXPONENTIAL) x = q.y * nhp_pdf_exponential(q.x, dt);
@@ -119,38 +118,88 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adjacency(nhp_cont_args a, double
         }
     }
     __syncthreads();
+    for (int p = tid; p <= N; p += NHP_BLOCK) col_start[(size_t)c * (N + 1) + p] = start[p];
+    for (int k = tid; k < nchild; k += NHP_BLOCK) lam_g[kb + k] = lam[k];
+}
 
-    // ---- phase 2: sequential Gibbs over parent nodes.  A parent node touches only a handful of
-    // children, so ONE wave walks the column: no block barriers on the 1..N critical path, only
-    // wave-local LDS ordering (LDS operations of a wave complete in issue order; the fence makes the
-    // atomics of all lanes visible before any lane reads them back).  The per-entry constants --
-    // uniform draw, prior log-odds, -W·cnt -- are precomputed by the whole block into LDS.
-    double *uni = reinterpret_cast<double *>(smem + (((reinterpret_cast<unsigned char *>(scan_tmp + NHP_BLOCK) - smem) + 7) & ~(size_t)7));   // [N] logit of the draw u[p,c]
-    double *bias = uni + N;                                                // [N] log ρ - log(1-ρ) - W·cnt[p]
-    double *acol = bias + N;                                               // [N] current A[·,c]
-    for (int p = tid; p < N; p += NHP_BLOCK) {
-        const size_t kpc = (size_t)p + (size_t)c * N;
-        const double rho = rho_mat ? rho_mat[kpc] : rho_scalar;
-        const double w = IMP == NHP_IMPULSE_EXPONENTIAL ? col[p].y : colw[p];
-        // the Bernoulli rule u <= exp(ll1 - logsumexp(ll0, ll1)) = 1/(1 + e^{-d}) is logit(u) <= d:
-        // the logit is taken here, in parallel, so the serial chain below carries no exp and no division
-        const double uu = u ? u[kpc] : nhp_philox_uniform(seed ^ 0xBE5466CF34E90C6Cull, step, kpc);
-        uni[p] = nhp_log(uu / (1.0 - uu));
-        bias[p] = -(w * a.cnt[p]) + nhp_log(rho) - nhp_log(1.0 - rho);
-        acol[p] = A[kpc];
+__device__ __forceinline__ float adj_dpp_add_f32(float v, const int sel)
+{
+    const int b = __float_as_int(v);
+    int q;
+    switch (sel) {
+    case 0: q = __builtin_amdgcn_mov_dpp(b, 0xB1, 0xF, 0xF, true); break;     // quad_perm [1,0,3,2]
+    case 1: q = __builtin_amdgcn_mov_dpp(b, 0x4E, 0xF, 0xF, true); break;     // quad_perm [2,3,0,1]
+    case 2: q = __builtin_amdgcn_mov_dpp(b, 0x141, 0xF, 0xF, true); break;    // row_half_mirror
+    default: q = __builtin_amdgcn_mov_dpp(b, 0x140, 0xF, 0xF, true); break;   // row_mirror
     }
-    __syncthreads();
-    if (wave != 0) return;
+    return v + __int_as_float(q);
+}
+
+__device__ __forceinline__ float adj_wave_sum_f32(float v)          // every lane returns the total
+{
+    v = adj_dpp_add_f32(v, 0); v = adj_dpp_add_f32(v, 1); v = adj_dpp_add_f32(v, 2); v = adj_dpp_add_f32(v, 3);
+    const int b = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
+}
+
+__device__ __forceinline__ double adj_readlane(double v, int l)     // l is wave-uniform
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// ---- the sequential Gibbs walk over parent nodes.  A parent node touches only a handful of children,
+// so ONE wave walks the column: no block barriers on the 1..N critical path, only wave-local LDS
+// ordering (LDS operations of a wave complete in issue order; the fence makes the atomics of all lanes
+// visible before any lane reads them back).  The per-entry constants -- logit of the uniform draw,
+// prior log-odds - W·cnt, current A -- are computed 64 parents at a time, one per lane, and handed to
+// the chain with v_readlane; the entry lists of parent p+1 are fetched while p is processed.
+__global__ __launch_bounds__(64) void k_adj_sweep(nhp_cont_args a, double *__restrict__ A,
+                                                  const int64_t *__restrict__ pair_off,
+                                                  const int32_t *__restrict__ ent_k, const double *__restrict__ ent_x,
+                                                  const int32_t *__restrict__ col_start, const double *__restrict__ lam_g,
+                                                  const double *__restrict__ rho_mat, double rho_scalar,
+                                                  const double *__restrict__ u, uint64_t seed, uint64_t step,
+                                                  int max_children, double *__restrict__ col_links)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int N = a.N, c = blockIdx.x, lane = threadIdx.x;
+    double *lam = reinterpret_cast<double *>(smem);                        // [max_children] current λ_k
+    double *dx = lam + max_children;                                       // [max_children] Σ x_kp of the current p
+    int *marker = reinterpret_cast<int *>(dx + max_children);              // [max_children]
+    int *start = marker + max_children;                                    // [N + 2] pair-list offsets by p
+    const int kb = a.boff[c], nchild = a.boff[c + 1] - kb;
+    for (int k = lane; k < nchild; k += 64) { lam[k] = lam_g[kb + k]; dx[k] = 0.0; marker[k] = 0; }
+    for (int p = lane; p <= N + 1; p += 64) start[p] = col_start[(size_t)c * (N + 1) + (p <= N ? p : N)];
+    NHP_LDS_SYNC();
+
+    const int64_t base = pair_off[c];
     double links = 0.0;
-    // entries of parent p: lane l owns entry eb + l (+64, +128, ... for the rare long lists).  The first
-    // chunk of parent p+1 is fetched while p is processed, so no global-load latency sits on the chain.
+    // entries of parent p: lane l owns entry eb + l (+64, +128, ... for the rare long lists)
     int nk = -1;
     double nx = 0.0;
     if (N > 0 && start[0] + lane < start[1]) { nk = ent_k[base + start[0] + lane]; nx = ent_x[base + start[0] + lane]; }
+    double c_uni = 0.0, c_bias = 0.0, c_a = 0.0;                            // this lane's parent of the current 64-chunk
     for (int p = 0; p < (NHP_SKIP(a, 64) ? 0 : N); ++p) {
+        if ((p & 63) == 0) {
+            const int pp = p + lane;
+            if (pp < N) {
+                const size_t kq = (size_t)pp + (size_t)c * N;
+                const double rho = rho_mat ? rho_mat[kq] : rho_scalar;
+                // the Bernoulli rule u <= exp(ll1 - logsumexp(ll0, ll1)) = 1/(1 + e^{-d}) is logit(u) <= d:
+                // the logit is taken here, off the chain, which then carries no exp and no division
+                const double uu = u ? u[kq] : nhp_philox_uniform(seed ^ 0xBE5466CF34E90C6Cull, step, kq);
+                c_uni = nhp_log(uu / (1.0 - uu));
+                c_bias = -(a.W[kq] * a.cnt[pp]) + nhp_log(rho) - nhp_log(1.0 - rho);
+                c_a = A[kq];
+            }
+        }
         const int eb = start[p], ee = start[p + 1];
         const size_t kpc = (size_t)p + (size_t)c * N;
-        const double aold = acol[p];
+        const double aold = adj_readlane(c_a, p & 63);
+        const double uni_p = adj_readlane(c_uni, p & 63), bias_p = adj_readlane(c_bias, p & 63);
         const int ck = nk;                       // this lane's first entry of p (or -1)
         const double cx = nx;
         nk = -1;
@@ -158,19 +207,38 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adjacency(nhp_cont_args a, double
         if (ck >= 0) atomicAdd(&dx[ck], cx);
         for (int e = eb + 64 + lane; e < ee; e += 64) atomicAdd(&dx[ent_k[base + e]], ent_x[base + e]);
         NHP_LDS_SYNC();
-        double delta = 0.0;
-        auto own = [&](int k) {
-            if (atomicExch(&marker[k], p + 1) != p + 1) {           // first entry of child k for this p owns it
-                const double d = dx[k];
-                const double l0 = lam[k] - aold * d;
-                delta += nhp_log(l0 + d) - nhp_log(l0);
+        // this lane's first-chunk entry: the first entry of child k for this p owns the child
+        bool owned = false;
+        double od = 0.0, ol0 = 1.0;
+        if (ck >= 0 && atomicExch(&marker[ck], p + 1) != p + 1) {
+            owned = true;
+            od = dx[ck];
+            ol0 = lam[ck] - aold * od;
+        }
+        // Screening in fp32: d = bias + Σ log(1 + x/λ⁰) only has to be compared with logit(u), and a
+        // single-precision sum settles that unless the two are within its error of each other (about one
+        // decision in a thousand).  The exact fp64 evaluation below then gives the same answer by
+        // construction, so the result does not depend on which path ran; the λ_k updates are always fp64.
+        double anew = -1.0;
+        if (ee - eb <= 64) {
+            float t32 = owned ? __logf(1.0f + (float)od / (float)ol0) : 0.0f;
+            t32 = adj_wave_sum_f32(t32);
+            const double d32 = bias_p + (double)t32;
+            if (fabs(uni_p - d32) > 1e-3 * (1.0 + (double)t32)) anew = uni_p <= d32 ? 1.0 : 0.0;   // NaN/inf fail the test
+        }
+        if (anew < 0.0) {
+            double delta = owned ? nhp_log(ol0 + od) - nhp_log(ol0) : 0.0;
+            for (int e = eb + 64 + lane; e < ee; e += 64) {
+                const int k = ent_k[base + e];
+                if (atomicExch(&marker[k], p + 1) != p + 1) {
+                    const double d = dx[k];
+                    const double l0 = lam[k] - aold * d;
+                    delta += nhp_log(l0 + d) - nhp_log(l0);
+                }
             }
-        };
-        if (ck >= 0) own(ck);
-        for (int e = eb + 64 + lane; e < ee; e += 64) own(ent_k[base + e]);
-        delta = nhp_wave_sum(delta);
-        const double d = bias[p] + delta;
-        const double anew = uni[p] <= d ? 1.0 : 0.0;             // ll1 - ll0 = d
+            delta = nhp_wave_sum(delta);
+            anew = uni_p <= bias_p + delta ? 1.0 : 0.0;            // ll1 - ll0 = bias + delta
+        }
         if (lane == 0) A[kpc] = anew;
         links += anew;
         auto settle = [&](int k) {
@@ -182,7 +250,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adjacency(nhp_cont_args a, double
         for (int e = eb + 64 + lane; e < ee; e += 64) settle(ent_k[base + e]);
         NHP_LDS_SYNC();
     }
-    if (tid == 0 && col_links) col_links[c] = links;
+    if (lane == 0 && col_links) col_links[c] = links;
 }
 
 extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_model *m,
@@ -196,15 +264,18 @@ extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_d
     const size_t N = (size_t)ds->N, NN = N * N, P = (size_t)(ds->pairs > 0 ? ds->pairs : 1);
     int max_children = 1;
     for (size_t c = 0; c < N; ++c) max_children = std::max(max_children, ds->h_boff[c + 1] - ds->h_boff[c]);
-    const size_t per = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? 16 : 24;
-    const size_t lds = 64 + per * N + 20 * (size_t)max_children + 4 * (2 * N + 2 + NHP_BLOCK) + 24 * N + 16;
-    if (lds > 160 * 1024) {
+    const bool expo = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
+    const size_t lds_pairs = 64 + (expo ? 16 : 24) * N + 8 * (size_t)max_children + 4 * (2 * N + 2 + NHP_BLOCK);
+    const size_t lds_sweep = 20 * (size_t)max_children + 4 * (N + 2);
+    if (lds_pairs > 160 * 1024 || lds_sweep > 160 * 1024) {
         nhp_set_error(ctx, "resample_adjacency: a node with %d events (N = %d) exceeds the 160 KiB LDS column state", max_children, ds->N);
         return NHP_ENOTIMPL;
     }
+    const size_t M1 = (size_t)(ds->M > 0 ? ds->M : 1);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t r = off; off += (bytes + 255) & ~(size_t)255; return r; };
     const size_t o_k = carve(4 * P), o_x = carve(8 * P), o_off = carve(8 * (N + 1)), o_u = carve(8 * NN), o_rho = carve(8 * NN), o_links = carve(8 * N);
+    const size_t o_start = carve(4 * N * (N + 1)), o_lam = carve(8 * M1);
     if (off > ((size_t)48 << 30)) { nhp_set_error(ctx, "resample_adjacency: %zu pairs need too much scratch", P); return NHP_ENOMEM; }
     NHP_TRY(nhp_ctx_reserve_scratch(ctx, off));
     char *base = (char *)ctx->d_scratch;
@@ -216,17 +287,22 @@ extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_d
     const double *d_u = u ? (const double *)(base + o_u) : nullptr;
     const double *d_rho = rho_matrix ? (const double *)(base + o_rho) : nullptr;
     double *d_links = (double *)(base + o_links);
-    if (m->impulse_kind == NHP_IMPULSE_EXPONENTIAL) {
-        if (lds > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adjacency<NHP_IMPULSE_EXPONENTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_adjacency<NHP_IMPULSE_EXPONENTIAL>), dim3((unsigned)N), dim3(NHP_BLOCK), lds, st, a, m->d_A,
-                           (const int64_t *)(base + o_off), (int32_t *)(base + o_k), (double *)(base + o_x), d_rho, rho, d_u, seed, step,
-                           max_children, d_links);
+    const int64_t *d_off = (const int64_t *)(base + o_off);
+    int32_t *d_k = (int32_t *)(base + o_k), *d_start = (int32_t *)(base + o_start);
+    double *d_x = (double *)(base + o_x), *d_lam = (double *)(base + o_lam);
+    if (expo) {
+        if (lds_pairs > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_pairs<NHP_IMPULSE_EXPONENTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pairs));
+        hipLaunchKernelGGL((k_adj_pairs<NHP_IMPULSE_EXPONENTIAL>), dim3((unsigned)N), dim3(NHP_BLOCK), lds_pairs, st, a, m->d_A,
+                           d_off, d_k, d_x, max_children, ds->group, d_start, d_lam);
     } else {
-        if (lds > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adjacency<NHP_IMPULSE_LOGITNORMAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_adjacency<NHP_IMPULSE_LOGITNORMAL>), dim3((unsigned)N), dim3(NHP_BLOCK), lds, st, a, m->d_A,
-                           (const int64_t *)(base + o_off), (int32_t *)(base + o_k), (double *)(base + o_x), d_rho, rho, d_u, seed, step,
-                           max_children, d_links);
+        if (lds_pairs > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_pairs<NHP_IMPULSE_LOGITNORMAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pairs));
+        hipLaunchKernelGGL((k_adj_pairs<NHP_IMPULSE_LOGITNORMAL>), dim3((unsigned)N), dim3(NHP_BLOCK), lds_pairs, st, a, m->d_A,
+                           d_off, d_k, d_x, max_children, ds->group, d_start, d_lam);
     }
+    NHP_HIP(ctx, hipGetLastError());
+    if (lds_sweep > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sweep));
+    hipLaunchKernelGGL(k_adj_sweep, dim3((unsigned)N), dim3(64), lds_sweep, st, a, m->d_A, d_off, d_k, d_x, d_start, d_lam,
+                       d_rho, rho, d_u, seed, step, max_children, d_links);
     NHP_HIP(ctx, hipGetLastError());
     std::vector<double> links(N);
     NHP_HIP(ctx, hipMemcpyAsync(links.data(), d_links, 8 * N, hipMemcpyDeviceToHost, st));
