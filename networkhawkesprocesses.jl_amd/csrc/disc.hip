@@ -242,23 +242,51 @@ __global__ __launch_bounds__(256) void k_disc_colstats(const double *__restrict_
 }
 
 // Ŝ[t,n,b] = max(0, Σ_{l=1..min(L,t)} data[n,t-l]·ϕ_b[l])   (0-based t; lag 0 excluded by the
-// prepended 0.0 of the reference's conv kernel; direct form = the exact value its FFT approximates)
+// prepended 0.0 of the reference's conv kernel; direct form = the exact value its FFT approximates).
+// A workgroup owns 256 consecutive bins of one node: the 256+L counts it needs sit in LDS (zeros
+// before t = 0, which add exactly nothing), the basis is transposed to ϕT[l][b] so one lag is a
+// broadcast read, and each thread carries CB basis sums at once -- the counts are read once for all
+// bases instead of once per basis.  Per basis the sum still runs l = 1..L in order with separate
+// multiply and add, i.e. bit for bit the oracle's value.
+#define CONV_CB 8
 __global__ __launch_bounds__(256) void k_disc_convolve(const double *__restrict__ dataT, int N, int64_t T,
-                                                       const double *__restrict__ phi, int L,
+                                                       const double *__restrict__ phi, int L, int B,
                                                        double *__restrict__ conv)
 {
 #pragma clang fp contract(off)
-    extern __shared__ double sphi[];
-    const int b = blockIdx.z, n = blockIdx.y;
-    for (int l = threadIdx.x; l < L; l += 256) sphi[l] = phi[l + (size_t)b * L];
-    __syncthreads();
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= T) return;
+    extern __shared__ double csm[];
+    double *tile = csm;                                  // [256 + L]: data[n, t0-L .. t0+255]
+    double *phiT = csm + 256 + L;                        // [L][Bp], Bp = B rounded up to CONV_CB
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int Bp = (B + CONV_CB - 1) / CONV_CB * CONV_CB;
+    const int64_t t0 = (int64_t)blockIdx.x * 256;
     const double *d = dataT + (size_t)n * T;
-    const int lmax = (int)(t < L ? t : L);
-    double s = 0.0;
-    for (int l = 1; l <= lmax; ++l) s = s + d[t - l] * sphi[l - 1];
-    conv[(size_t)t + (size_t)n * T + (size_t)b * T * N] = s > 0.0 ? s : 0.0;
+    for (int i = tid; i < 256 + L; i += 256) {
+        const int64_t tt = t0 - L + i;
+        tile[i] = (tt >= 0 && tt < T) ? d[tt] : 0.0;
+    }
+    for (int i = tid; i < L * Bp; i += 256) {
+        const int l = i / Bp, b = i % Bp;
+        phiT[i] = b < B ? phi[l + (size_t)b * L] : 0.0;
+    }
+    __syncthreads();
+    const int64_t t = t0 + tid;
+    for (int b0 = 0; b0 < B; b0 += CONV_CB) {
+        double s[CONV_CB];
+#pragma unroll
+        for (int q = 0; q < CONV_CB; ++q) s[q] = 0.0;
+        for (int l = 1; l <= L; ++l) {
+            const double x = tile[tid + L - l];          // data[n, t - l]
+            const double *ph = phiT + (size_t)(l - 1) * Bp + b0;
+#pragma unroll
+            for (int q = 0; q < CONV_CB; ++q) s[q] = s[q] + x * ph[q];
+        }
+        if (t < T) {
+#pragma unroll
+            for (int q = 0; q < CONV_CB; ++q)
+                if (b0 + q < B) conv[(size_t)t + (size_t)n * T + (size_t)(b0 + q) * T * N] = s[q] > 0.0 ? s[q] : 0.0;
+        }
+    }
 }
 
 // E[k + c·K], k = p + b·N:  bump = ((a·)w·θ)·dt   (src/discrete.jl:381-385,511-516);  base[c] = λ0[c]·dt
@@ -456,8 +484,10 @@ extern "C" nhp_status nhp_disc_convolve(nhp_ctx *ctx, nhp_disc_dataset *ds, cons
     NHP_TRY(nhp_ctx_reserve_scratch(ctx, 8 * (size_t)L * B));
     double *d_phi = (double *)ctx->d_scratch;
     NHP_HIP(ctx, hipMemcpyAsync(d_phi, phi, 8 * (size_t)L * B, hipMemcpyHostToDevice, st));
-    dim3 grid((unsigned)((ds->T + 255) / 256), (unsigned)ds->N, (unsigned)B);
-    hipLaunchKernelGGL(k_disc_convolve, grid, dim3(256), 8 * (size_t)L, st, ds->d_dataT, ds->N, ds->T, d_phi, L, ds->d_conv);
+    dim3 grid((unsigned)((ds->T + 255) / 256), (unsigned)ds->N);
+    const size_t lds_conv = 8 * ((size_t)256 + L + (size_t)L * ((B + CONV_CB - 1) / CONV_CB * CONV_CB));
+    if (lds_conv > 64 * 1024) { nhp_set_error(ctx, "convolve: nlags * nbasis = %d * %d exceeds the LDS budget", L, B); return NHP_ENOTIMPL; }
+    hipLaunchKernelGGL(k_disc_convolve, grid, dim3(256), lds_conv, st, ds->d_dataT, ds->N, ds->T, d_phi, L, B, ds->d_conv);
     NHP_HIP(ctx, hipGetLastError());
     if (out) NHP_HIP(ctx, hipMemcpyAsync(out, ds->d_conv, 8 * TNB, hipMemcpyDeviceToHost, st));
     NHP_HIP(ctx, hipStreamSynchronize(st));
