@@ -228,6 +228,16 @@ nhp_status nhp_disc_vb_step(nhp_ctx *ctx, const nhp_disc_dataset *ds, double dt,
                             double alpha0, double beta0, double kappa, double nu, double gamma,
                             double *alpha_v, double *beta_v, double *kappa_v, double *nu_v,
                             double *gamma_v);
+/* Parent counts of one discrete Gibbs sweep: resample_parents(process, data, convolved)
+ * src/parents.jl:82-116 summed over time, counts[c + N*k] = Σ_t parents[t, c, k] with k = 0 the
+ * baseline and k = 1 + p*B + b (0-based p, b) parent node p through basis b -- the statistic the
+ * discrete resample! methods consume (src/baselines.jl:413-419, src/weights.jl:28-35,
+ * src/impulses.jl:337-353).  A bin's Multinomial draw is taken as n categorical draws through
+ * explicit Philox uniforms keyed (seed, step, bin, event): same distribution as Distributions.jl's
+ * sampler, reproducible, and equal to the oracle bit for bit.  counts: [N * (1 + N*B)] int64. */
+nhp_status nhp_disc_resample_parents(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
+                                     const double *W, const double *theta, const double *A, double dt,
+                                     uint64_t seed, uint64_t step, int64_t *counts);
 /* n_steps consecutive update! steps of vb! (src/inference.jl:153-181) with the variational parameters
  * resident on the device in between (one upload, one download) */
 nhp_status nhp_disc_vb_run(nhp_ctx *ctx, const nhp_disc_dataset *ds, double dt,

@@ -16,11 +16,13 @@ from .continuous import (ContinuousHawkesProcess, ContinuousNetworkHawkesProcess
 from . import continuous as _cont
 from .discrete import (DiscreteDataset, DiscreteGaussianImpulseResponse, DiscreteHawkesProcess,  # noqa: F401
                        DiscreteHomogeneousProcess, DiscreteNetworkHawkesProcess,
-                       DiscreteStandardHawkesProcess, VariationalInference, convolve, update_, vb_)
+                       DiscreteStandardHawkesProcess, VariationalInference, convolve, disc_parent_counts,
+                       resample_parent_counts, update_, vb_)
 from . import discrete as _disc
 from .parents import node_counts, parent_counts, resample_parents, uniform_stream  # noqa: F401
-from .inference import (MarkovChainMonteCarlo, MaximumLikelihood, logprior, mcmc_, mle_,  # noqa: F401
-                        resample_, resample_adjacency_matrix_)
+from .inference import (MarkovChainMonteCarlo, MaximumLikelihood, logprior, mle_,  # noqa: F401
+                        resample_adjacency_matrix_)
+from . import inference as _inf
 from . import synthetic  # noqa: F401
 
 
@@ -41,3 +43,19 @@ def intensity(process, data, *args, **kwargs):
             return _disc.disc_intensity(process, convolved=data, **kwargs)
         return _disc.disc_intensity(process, data, **kwargs)
     return _cont.intensity(process, data, *args, **kwargs)
+
+
+def mcmc_(process, data, *args, **kwargs):
+    """mcmc!(process, data; nsteps, log_freq, verbose) -- src/inference.jl:49-70, continuous or discrete."""
+    if isinstance(process, DiscreteHawkesProcess):
+        return _disc.disc_mcmc_(process, data, *args, **kwargs)
+    return _inf.mcmc_(process, data, *args, **kwargs)
+
+
+def resample_(process, data, *args, **kwargs):
+    """resample!(process, data) (src/continuous.jl:202-208,350-358) / resample!(process, data, convolved)
+    (src/discrete.jl:362-368): one Gibbs sweep."""
+    if isinstance(process, DiscreteHawkesProcess):
+        return _disc.disc_resample_(process, data, *args, **kwargs)
+    return _inf.resample_(process, data, *args, **kwargs)
+

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_disc_convolve(const double *__restrict_
 __global__ __launch_bounds__(256) void k_disc_bump(int N, int B, double dt, const double *__restrict__ lambda0,
                                                    const double *__restrict__ W, const double *__restrict__ theta,
                                                    const double *__restrict__ A, double *__restrict__ E,
-                                                   double *__restrict__ base)
+                                                   double *__restrict__ base, int cat_order)
 {
 #pragma clang fp contract(off)
     const size_t NN = (size_t)N * N, K = (size_t)N * B;
@@ -301,7 +301,8 @@ __global__ __launch_bounds__(256) void k_disc_bump(int N, int B, double dt, cons
     if (i < NN * B) {
         const size_t b = i / NN, pc = i % NN, p = pc % N, c = pc / N;
         const double w = A ? A[pc] * W[pc] : W[pc];
-        E[p + b * N + c * K] = (w * theta[i]) * dt;
+        // cat_order: row q = p·B + b, the reference's parent-category order (src/parents.jl:108-112)
+        E[(cat_order ? p * B + b : p + b * N) + c * K] = (w * theta[i]) * dt;
     }
     if (i < (size_t)N) base[i] = lambda0[i] * dt;
 }
@@ -507,7 +508,7 @@ static void launch_gemm(const gemm_args &g, int splits, hipStream_t st)
 // uploads the model pieces, builds E and base on the device; returns pointers into scratch
 static nhp_status stage_bump(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0, const double *W,
                              const double *theta, const double *A, double dt, double **E, double **base, size_t extra,
-                             double **extra_ptr)
+                             double **extra_ptr, int cat_order = 0)
 {
     if (!ds->d_conv) { nhp_set_error(ctx, "convolve(process, data) must run before intensity / loglikelihood"); return NHP_EINVAL; }
     if (!lambda0 || !W || !theta) return NHP_EINVAL;
@@ -528,7 +529,7 @@ static nhp_status stage_bump(nhp_ctx *ctx, const nhp_disc_dataset *ds, const dou
     NHP_HIP(ctx, hipMemcpyAsync(dth, theta, 8 * NN * B, hipMemcpyHostToDevice, st));
     if (A) NHP_HIP(ctx, hipMemcpyAsync(dA, A, 8 * NN, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_disc_bump, dim3((unsigned)((NN * B + 255) / 256)), dim3(256), 0, st, (int)N, (int)B, dt, dl0, dW,
-                       dth, A ? dA : nullptr, dE, dbase);
+                       dth, A ? dA : nullptr, dE, dbase, cat_order);
     NHP_HIP(ctx, hipGetLastError());
     *E = dE; *base = dbase;
     return NHP_OK;
@@ -648,3 +649,155 @@ extern "C" nhp_status nhp_disc_vb_run(nhp_ctx *ctx, const nhp_disc_dataset *ds, 
     NHP_HIP(ctx, hipStreamSynchronize(st));
     return NHP_OK;
 }
+
+// ---- discrete Gibbs parent counts (reference resample_parents / resample_parent
+// src/parents.jl:82-116 reduced over time to counts[c + N·k] = Σ_t parents[t, c, k], which is all the
+// discrete resample! methods read: src/baselines.jl:413-419, src/weights.jl:28-35,
+// src/impulses.jl:337-353).  Only occupied bins draw anything, and a bin's Multinomial(n, μ) is n
+// categorical draws over 1 + N·B categories, i.e. an inverse-CDF walk along the bin's row of
+// Z = base ⊕ G·E.  The reference materialises parents[T, N, 1+NB]; here a workgroup takes a 64-bin x
+// 128-node tile, lists its occupied bins, and walks the category axis twice in chunks staged through
+// LDS (G rows and E rows shared by all the tile's bins): once for the row total, once comparing the
+// running sum with the bin's ascending thresholds u_(1) < u_(2) < ... (order statistics generated one
+// at a time from Philox, so n events cost one walk).  One lane owns a bin's running sum, in the
+// reference's category order with separate multiply and add: counts equal the oracle's, bit for bit.
+#define RP_TT 64
+#define RP_CT 128
+#define RP_KC 16
+#define RP_SLOTS 4
+#define RP_KEY 0xD15C0DE5EEDC0FFEull
+
+__device__ __forceinline__ double rp_next_u(double u_prev, int remaining, uint64_t seed, uint64_t step, uint64_t bin, int j)
+{
+#pragma clang fp contract(off)
+    const double V = nhp_philox_uniform(seed ^ RP_KEY, step, (bin << 20) | (uint64_t)j);
+    const double r = nhp_exp(nhp_log(V) / (double)remaining);
+    const double w = 1.0 - r;
+    return u_prev + (1.0 - u_prev) * w;
+}
+
+__global__ __launch_bounds__(256) void k_disc_resample_parents(const double *__restrict__ dataT, const double *__restrict__ conv,
+                                                               const double *__restrict__ E2, const double *__restrict__ base,
+                                                               int64_t T, int N, int B, uint64_t seed, uint64_t step,
+                                                               int *__restrict__ counts)
+{
+#pragma clang fp contract(off)
+    __shared__ unsigned short list[RP_TT * RP_CT];
+    __shared__ double Gt[RP_KC][RP_TT];
+    __shared__ double Et[RP_KC][RP_CT + 1];
+    __shared__ int nb;
+    const int tid = threadIdx.x, K = N * B;
+    const int64_t t0 = (int64_t)blockIdx.x * RP_TT;
+    const int c0 = blockIdx.y * RP_CT;
+    if (tid == 0) nb = 0;
+    __syncthreads();
+    for (int i = tid; i < RP_TT * RP_CT; i += 256) {
+        const int64_t t = t0 + (i % RP_TT);
+        const int c = c0 + i / RP_TT;
+        if (t < T && c < N && dataT[(size_t)t + (size_t)T * c] > 0.0) list[atomicAdd(&nb, 1)] = (unsigned short)i;
+    }
+    __syncthreads();
+    const int nbins = nb;
+
+    auto stage = [&](int q0) {
+        for (int e = tid; e < RP_KC * RP_TT; e += 256) {
+            const int kk = e / RP_TT, tt = e % RP_TT, q = q0 + kk;
+            const int64_t t = t0 + tt;
+            // category q = p·B + b reads Ŝ[t, p, b]
+            Gt[kk][tt] = (q < K && t < T) ? conv[(size_t)t + (size_t)T * ((size_t)(q / B) + (size_t)N * (q % B))] : 0.0;
+        }
+        for (int e = tid; e < RP_KC * RP_CT; e += 256) {
+            const int cc = e / RP_KC, kk = e % RP_KC, q = q0 + kk, c = c0 + cc;
+            Et[kk][cc] = (q < K && c < N) ? E2[(size_t)q + (size_t)c * K] : 0.0;
+        }
+    };
+
+    for (int b0 = 0; b0 < nbins; b0 += 256 * RP_SLOTS) {
+        int tl[RP_SLOTS], cl[RP_SLOTS], n[RP_SLOTS], j[RP_SLOTS];
+        double cum[RP_SLOTS], total[RP_SLOTS], thr[RP_SLOTS], u[RP_SLOTS];
+#pragma unroll
+        for (int s = 0; s < RP_SLOTS; ++s) {
+            const int idx = b0 + tid + 256 * s;
+            const int e = idx < nbins ? list[idx] : 0;
+            tl[s] = e % RP_TT; cl[s] = e / RP_TT;
+            n[s] = idx < nbins ? (int)dataT[(size_t)(t0 + tl[s]) + (size_t)T * (c0 + cl[s])] : 0;
+            j[s] = 0;
+            cum[s] = n[s] > 0 ? base[c0 + cl[s]] : 0.0;
+            total[s] = 0.0; thr[s] = 0.0; u[s] = 0.0;
+        }
+        // ---- walk 1: row totals
+        for (int q0 = 0; q0 < K; q0 += RP_KC) {
+            __syncthreads();
+            stage(q0);
+            __syncthreads();
+#pragma unroll 4
+            for (int kk = 0; kk < RP_KC; ++kk) {
+#pragma unroll
+                for (int s = 0; s < RP_SLOTS; ++s) cum[s] = cum[s] + Gt[kk][tl[s]] * Et[kk][cl[s]];
+            }
+        }
+        // first thresholds; the baseline category
+#pragma unroll
+        for (int s = 0; s < RP_SLOTS; ++s) {
+            total[s] = cum[s];
+            if (n[s] > 0) {
+                const int c = c0 + cl[s];
+                const uint64_t bin = (uint64_t)(t0 + tl[s]) + (uint64_t)T * (uint64_t)c;
+                u[s] = rp_next_u(0.0, n[s], seed, step, bin, 0);
+                thr[s] = u[s] * total[s];
+                cum[s] = base[c];
+                while (j[s] < n[s] && cum[s] > thr[s]) {
+                    atomicAdd(&counts[c], 1);
+                    if (++j[s] < n[s]) { u[s] = rp_next_u(u[s], n[s] - j[s], seed, step, bin, j[s]); thr[s] = u[s] * total[s]; }
+                }
+            }
+        }
+        // ---- walk 2: categories by inverse CDF
+        for (int q0 = 0; q0 < K; q0 += RP_KC) {
+            __syncthreads();
+            stage(q0);
+            __syncthreads();
+            for (int kk = 0; kk < RP_KC; ++kk) {
+#pragma unroll
+                for (int s = 0; s < RP_SLOTS; ++s) {
+                    cum[s] = cum[s] + Gt[kk][tl[s]] * Et[kk][cl[s]];
+                    if (j[s] < n[s] && cum[s] > thr[s] && q0 + kk < K) {
+                        const int c = c0 + cl[s];
+                        const uint64_t bin = (uint64_t)(t0 + tl[s]) + (uint64_t)T * (uint64_t)c;
+                        do {
+                            atomicAdd(&counts[(size_t)c + (size_t)N * (1 + q0 + kk)], 1);
+                            if (++j[s] < n[s]) { u[s] = rp_next_u(u[s], n[s] - j[s], seed, step, bin, j[s]); thr[s] = u[s] * total[s]; }
+                        } while (j[s] < n[s] && cum[s] > thr[s]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < RP_SLOTS; ++s)                                    // capped at the last category
+            if (j[s] < n[s]) atomicAdd(&counts[(size_t)(c0 + cl[s]) + (size_t)N * K], n[s] - j[s]);
+    }
+}
+
+extern "C" nhp_status nhp_disc_resample_parents(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
+                                                const double *W, const double *theta, const double *A, double dt,
+                                                uint64_t seed, uint64_t step, int64_t *counts)
+{
+    if (!ctx || !ds || !counts) return NHP_EINVAL;
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t N = (size_t)ds->N, K = N * (size_t)ds->B, NC = N * (1 + K);
+    double *E2, *base, *extra;
+    NHP_TRY(stage_bump(ctx, ds, lambda0, W, theta, A, dt, &E2, &base, (NC + 1) / 2 + 1, &extra, 1));
+    int *d_counts = reinterpret_cast<int *>(extra);
+    hipStream_t st = ctx->stream;
+    NHP_HIP(ctx, hipMemsetAsync(d_counts, 0, sizeof(int) * NC, st));
+    dim3 grid((unsigned)((ds->T + RP_TT - 1) / RP_TT), (unsigned)((N + RP_CT - 1) / RP_CT));
+    hipLaunchKernelGGL(k_disc_resample_parents, grid, dim3(256), 0, st, ds->d_dataT, ds->d_conv, E2, base, ds->T, ds->N, ds->B,
+                       seed, step, d_counts);
+    NHP_HIP(ctx, hipGetLastError());
+    std::vector<int> h((size_t)NC);
+    NHP_HIP(ctx, hipMemcpyAsync(h.data(), d_counts, sizeof(int) * NC, hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipStreamSynchronize(st));
+    for (size_t i = 0; i < NC; ++i) counts[i] = h[i];
+    return NHP_OK;
+}
+

@@ -145,6 +145,7 @@ class DiscreteDataset:
             raise ValueError("data must be an N x T matrix")
         self.N, self.T = data.shape
         self.ctx = ctx
+        self.node_counts = data.sum(axis=1).astype(np.float64)    # node_counts(data): src/parents.jl:118-121
         d = np.asfortranarray(data.astype(np.int64, copy=False)).ravel(order="K")
         h = C.c_void_p()
         _lib.check(_lib.lib().nhp_disc_dataset_create(ctx.h, _lib.iptr(d), self.N, self.T, C.byref(h)), ctx.h)
@@ -246,6 +247,71 @@ def disc_loglikelihood(process, data=None, convolved=None, ctx=None):
     _lib.check(_lib.lib().nhp_disc_loglik(ctx.h, ds.h, _lib.dptr(l0), _lib.dptr(W), _lib.dptr(th), _lib.dptr(A),
                                           process.dt, C.byref(ll)), ctx.h)
     return ll.value
+
+
+def resample_parent_counts(process, data=None, convolved=None, seed=0, step=0, ctx=None):
+    """Σ_t resample_parents(process, data, convolved)[t, :, :] -> N x (1 + N·B) integer counts
+    (src/parents.jl:82-116): column 0 the baseline, column 1 + p·B + b parent node p through basis b
+    (0-based p, b) -- the reduction every discrete resample! applies to the T x N x (1+NB) array, which is
+    never materialised here.  Draws are keyed (seed, step), reproducible, and equal to the oracle."""
+    ctx = ctx or _lib.default_context()
+    ds = _convolved(process, data, convolved, ctx)
+    l0, W, th, A = process._lowered()
+    N, B = ds.N, ds.B
+    out = np.empty(N * (1 + N * B), dtype=np.int64)
+    _lib.check(_lib.lib().nhp_disc_resample_parents(ctx.h, ds.h, _lib.dptr(l0), _lib.dptr(W), _lib.dptr(th), _lib.dptr(A),
+                                                    process.dt, seed, step, _lib.iptr(out)), ctx.h)
+    return out.reshape((N, 1 + N * B), order="F")
+
+
+def disc_parent_counts(counts, ndims, nbasis):
+    """parent_counts(parents, ndims, nbasis) on the time-reduced array -- src/parents.jl:123-134"""
+    return counts[:, 1:].reshape((ndims, ndims, nbasis)).sum(axis=2).T.astype(np.float64)      # [parent, child]
+
+
+def disc_resample_(process, data, convolved, rng, seed=0, step=0, ctx=None):
+    """resample!(process::DiscreteStandardHawkesProcess, data, convolved) -- src/discrete.jl:362-368.
+
+    Parent counts come from the GPU; the conjugate draws are numpy (statistical, not bitwise, parity with
+    Julia's samplers).  The reference's baseline update is broken for the homogeneous process (it passes
+    the T x N slice to a helper that expects N x T: SURVEY D2); the intended update is applied:
+    λ ~ Gamma(α0 + Σ_t parents[t, c, 1], 1 / (β0 + T·dt))  (src/baselines.jl:413-419)."""
+    if not isinstance(process, DiscreteStandardHawkesProcess) or not isinstance(process.weights, DenseWeightModel):
+        raise NotImplementedError("discrete Gibbs is built for DiscreteStandardHawkesProcess + DenseWeightModel "
+                                  "(network variant: SURVEY 8f-3, adjacency sweep not built)")
+    ctx = ctx or _lib.default_context()
+    ds = _convolved(process, data, convolved, ctx)
+    N, B = ds.N, ds.B
+    counts = resample_parent_counts(process, convolved=ds, seed=seed, step=step, ctx=ctx)
+    b, w, imp = process.baseline, process.weights, process.impulses
+    b.λ = rng.gamma(b.α0 + counts[:, 0], 1.0 / (b.β0 + ds.T * b.dt))
+    Mnm = disc_parent_counts(counts, N, B)
+    w.W = rng.gamma(w.κ + Mnm, 1.0 / (w.ν + ds.node_counts)[:, None] * np.ones((N, N)))        # src/weights.jl:59-64
+    γ = imp.γ + counts[:, 1:].reshape((N, N, B)).transpose(1, 0, 2)                                  # [parent, child, basis]
+    g = rng.gamma(γ, 1.0)
+    imp.θ = g / g.sum(axis=2, keepdims=True)                                                         # Dirichlet: src/impulses.jl:337-353
+    return process.params()
+
+
+def disc_mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, ctx=None):
+    """mcmc!(process::DiscreteHawkesProcess, data) -- src/inference.jl:49-70: convolve once, then
+    resample!(process, data, convolved) per step."""
+    import time
+    from .inference import MarkovChainMonteCarlo
+    ctx = ctx or _lib.default_context()
+    ds = convolve(process, data, ctx)
+    rng = np.random.default_rng(seed)
+    res = MarkovChainMonteCarlo()
+    start = time.time()
+    while res.steps < nsteps:
+        res.samples.append(disc_resample_(process, None, ds, rng, seed=seed, step=res.steps, ctx=ctx))
+        res.steps += 1
+        if res.steps % log_freq == 0 and verbose:
+            res.elapsed = time.time() - start
+            print(f" > step: {res.steps}, elapsed: {res.elapsed}")
+    res.elapsed = time.time() - start
+    res.status = "complete"
+    return res
 
 
 def update_(process, data, convolved, ctx=None, n_steps=1):

@@ -761,3 +761,69 @@ int orc_lgcp_loglik(const double *times, const int64_t *nodes, const int64_t *pa
     return ORC_OK;
 }
 
+/* Discrete Gibbs parent counts: resample_parents / resample_parent src/parents.jl:82-116 reduced over
+ * time, counts[c + N*k] = sum_t parents[t, c, k] (what every discrete resample! consumes:
+ * src/baselines.jl:413-419, src/weights.jl:28-35, src/impulses.jl:337-353).  Bin (t, c) with
+ * n = data[c, t] events draws Multinomial(n, mu), mu = [lambda0_c dt, shat[t,p,b] bump(p,c,b) ...]
+ * normalised, categories in the reference's order k = 1 + p*B + b.
+ *
+ * [3P] Distributions' Multinomial sampler cannot be matched bit for bit (Julia RNG); the draw is
+ * restated as n iid categorical draws through explicit uniforms -- the same distribution: the n
+ * uniforms are produced in ascending order (order statistics, u_(j) = u_(j-1) + (1 - u_(j-1)) *
+ * (1 - V_j^(1/(n-j))), V_j = Philox(seed ^ ORC_DISC_KEY, step, (bin << 20) | j), bin = t + T*c) and
+ * each takes the smallest k whose cumulative sum exceeds u * total (capped at the last category),
+ * the rule of the continuous sampler.  det-math exp/log, separate multiply and add. */
+#define ORC_DISC_KEY 0xD15C0DE5EEDC0FFEull
+static double disc_next_u(double u_prev, int64_t remaining, uint64_t seed, uint64_t step, uint64_t bin, int64_t j)
+{
+    double V = nhp_uniform(seed ^ ORC_DISC_KEY, step, (bin << 20) | (uint64_t)j);
+    double r = nhp_det_exp(nhp_det_log(V) / (double)remaining);
+    double w = 1.0 - r;
+    return u_prev + (1.0 - u_prev) * w;
+}
+
+int orc_disc_resample_parents(const int64_t *data, const double *conv, int64_t T, int32_t N, int32_t B,
+                              const double *lambda0, const double *W, const double *theta, const double *A,
+                              double dt, uint64_t seed, uint64_t step, int64_t *counts)
+{
+    const int64_t K = (int64_t)N * B;
+    for (int64_t i = 0; i < (int64_t)N * (1 + K); ++i) counts[i] = 0;
+    double *bump = (double *)malloc(sizeof(double) * (size_t)K);
+    if (!bump) return ORC_ENOMEM;
+    for (int32_t c = 0; c < N; ++c) {
+        for (int32_t p = 0; p < N; ++p)
+            for (int32_t b = 0; b < B; ++b) {
+                double w = W[IDX(p, c, N)], th = theta[IDX(p, c, N) + (size_t)b * N * N];
+                bump[(size_t)p * B + b] = A ? A[IDX(p, c, N)] * w * th * dt : w * th * dt;
+            }
+        for (int64_t t = 0; t < T; ++t) {
+            const int64_t n = data[c + (size_t)t * N];
+            if (n <= 0) continue;
+            const double base = lambda0[c] * dt;
+            double total = base;
+            for (int32_t p = 0; p < N; ++p)
+                for (int32_t b = 0; b < B; ++b)
+                    total = total + conv[(size_t)t + (size_t)p * T + (size_t)b * T * N] * bump[(size_t)p * B + b];
+            const uint64_t bin = (uint64_t)t + (uint64_t)T * (uint64_t)c;
+            int64_t j = 0;
+            double u = disc_next_u(0.0, n, seed, step, bin, 0), thr = u * total;
+            double cum = base;
+            while (j < n && cum > thr) {
+                counts[c] += 1;
+                if (++j < n) { u = disc_next_u(u, n - j, seed, step, bin, j); thr = u * total; }
+            }
+            for (int32_t p = 0; p < N && j < n; ++p)
+                for (int32_t b = 0; b < B && j < n; ++b) {
+                    cum = cum + conv[(size_t)t + (size_t)p * T + (size_t)b * T * N] * bump[(size_t)p * B + b];
+                    while (j < n && cum > thr) {
+                        counts[c + (size_t)N * (1 + (size_t)p * B + b)] += 1;
+                        if (++j < n) { u = disc_next_u(u, n - j, seed, step, bin, j); thr = u * total; }
+                    }
+                }
+            counts[c + (size_t)N * K] += n - j;                  /* capped at the last category */
+        }
+    }
+    free(bump);
+    return ORC_OK;
+}
+

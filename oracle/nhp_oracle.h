@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-enum { ORC_OK = 0, ORC_EINVAL = 1, ORC_EDOMAIN = 2 };
+enum { ORC_OK = 0, ORC_EINVAL = 1, ORC_EDOMAIN = 2, ORC_ENOMEM = 4 };
 enum { ORC_BASELINE_HOMOGENEOUS = 0, ORC_BASELINE_LGCP = 1 };
 enum { ORC_IMPULSE_EXPONENTIAL = 0, ORC_IMPULSE_LOGITNORMAL = 1 };
 /* `flags` argument: bit0 selects the arithmetic (0 = libm, reference-faithful formulas;
@@ -93,6 +93,11 @@ void orc_log_duration_stats(const double *times, const int64_t *nodes, const int
  * ([3P] Distributions: rand(Bernoulli(q)) = rand() <= q); rho[p + c*N] the link probability. */
 int orc_cont_resample_adjacency(const orc_cont_model *m, const double *times, const int64_t *nodes,
                                 int64_t M, double duration, const double *rho, const double *u, double *A);
+
+/* ---- discrete Gibbs parent counts (src/parents.jl:82-134), counts[c + N*k], k = 0 baseline, 1 + p*B + b */
+int orc_disc_resample_parents(const int64_t *data, const double *conv, int64_t T, int32_t N, int32_t B,
+                              const double *lambda0, const double *W, const double *theta, const double *A,
+                              double dt, uint64_t seed, uint64_t step, int64_t *counts);
 
 /* ---- LGCP baseline likelihood inside the elliptical-slice sampler (src/baselines.jl:227-254) */
 int orc_lgcp_loglik(const double *times, const int64_t *nodes, const int64_t *parentnodes, int64_t M,

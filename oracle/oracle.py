@@ -277,6 +277,19 @@ def disc_intensity(conv, lambda0, W, theta, dt=1.0, A=None):
     return out.reshape((T, N), order="F")
 
 
+def disc_resample_parents(data, conv, lambda0, W, theta, dt=1.0, A=None, seed=0, step=0):
+    """Parent counts of one discrete Gibbs sweep, [N, 1 + N*B] (column 0 = baseline, 1 + p*B + b)."""
+    data = np.asarray(data, dtype=np.int64)
+    T, N, B = conv.shape
+    d = np.asfortranarray(data).ravel(order="K")
+    cv = np.asfortranarray(conv).ravel(order="K")
+    out = np.empty(N * (1 + N * B), dtype=np.int64)
+    _chk(lib().orc_disc_resample_parents(d.ctypes.data_as(_ip), _p(cv), C.c_int64(T), C.c_int32(N), C.c_int32(B),
+                                         _p(_f(lambda0)), _p(_col(W)), _p(_col(theta)), _p(_col(A)), C.c_double(dt),
+                                         C.c_uint64(seed), C.c_uint64(step), out.ctypes.data_as(_ip)))
+    return out.reshape((N, 1 + N * B), order="F")
+
+
 def disc_loglik(data, lam):
     data = np.asarray(data, dtype=np.int64)
     N, T = data.shape

@@ -1,0 +1,71 @@
+"""GPU parity: discrete Gibbs parent counts (nhp_disc_resample_parents) vs the oracle -- integer work,
+bit-exact -- and the discrete mcmc! built on it."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make(nhp, N, T, B, L, rate, seed, dt=1.0):
+    rng = np.random.default_rng(seed)
+    data = rng.poisson(rate, (N, T)).astype(np.int64)
+    th = rng.dirichlet(np.ones(B), (N, N))
+    th[:, :, -1] = 1.0 - th[:, :, :-1].sum(axis=2)
+    while not np.all(th.sum(axis=2) == 1.0):                    # the constructor checks the sum exactly
+        th = rng.dirichlet(np.ones(B), (N, N))
+        th[:, :, -1] = 1.0 - th[:, :, :-1].sum(axis=2)
+    proc = nhp.DiscreteStandardHawkesProcess(nhp.DiscreteHomogeneousProcess(rng.uniform(0.05, 0.3, N), dt),
+                                             nhp.DiscreteGaussianImpulseResponse(th, L, dt),
+                                             nhp.DenseWeightModel(rng.uniform(0.0, 0.5, (N, N)) / N), dt)
+    return proc, data
+
+
+@pytest.mark.parametrize("N,T,B,L,rate", [(3, 500, 4, 10, 0.3), (5, 3000, 3, 7, 2.5), (130, 700, 2, 5, 0.05),
+                                          (17, 129, 5, 9, 0.8), (2, 64, 2, 3, 40.0)])
+def test_counts_equal_the_oracle(nhp, orc, N, T, B, L, rate):
+    proc, data = make(nhp, N, T, B, L, rate, seed=N + T)
+    ds, conv = nhp.convolve(proc, data, fetch=True)
+    got = nhp.resample_parent_counts(proc, convolved=ds, seed=11, step=4)
+    want = orc.disc_resample_parents(data, conv, proc.baseline.λ, proc.weights.W, proc.impulses.θ, proc.dt, seed=11, step=4)
+    assert got.shape == (N, 1 + N * B)
+    assert np.array_equal(got.sum(axis=1), data.sum(axis=1))            # every event gets exactly one parent
+    assert np.array_equal(got, want)
+    again = nhp.resample_parent_counts(proc, convolved=ds, seed=11, step=4)
+    assert np.array_equal(got, again)                                   # keyed draws: reproducible
+    other = nhp.resample_parent_counts(proc, convolved=ds, seed=11, step=5)
+    assert not np.array_equal(got, other)
+
+
+def test_counts_follow_the_multinomial_mean(nhp):
+    # E[counts[c, k]] = Σ_t n[c,t]·μ_k(t, c): compare the baseline column and the per-parent totals
+    N, T, B, L = 4, 4000, 3, 8
+    proc, data = make(nhp, N, T, B, L, 0.4, seed=9)
+    ds = nhp.convolve(proc, data)
+    lam = nhp.intensity(proc, ds)                                        # T x N
+    exp0 = (data.T * (proc.baseline.λ * proc.dt)[None, :] / lam).sum(axis=0)
+    acc = np.zeros((N, 1 + N * B))
+    S = 60
+    for s in range(S):
+        acc += nhp.resample_parent_counts(proc, convolved=ds, seed=2, step=s)
+    mean0 = acc[:, 0] / S
+    assert np.all(np.abs(mean0 - exp0) < 5 * np.sqrt(exp0 / S) + 1.0)
+    assert np.allclose(acc.sum(axis=1) / S, data.sum(axis=1))
+
+
+def test_discrete_mcmc_recovers_the_baseline_when_there_is_no_excitation(nhp):
+    rng = np.random.default_rng(0)
+    N, T, B, L = 3, 20000, 3, 6
+    true = np.array([0.2, 0.5, 1.0])
+    data = rng.poisson(true[:, None] * np.ones((N, T))).astype(np.int64)
+    th = np.full((N, N, B), 1.0 / 4); th[:, :, -1] = 0.5
+    proc = nhp.DiscreteStandardHawkesProcess(nhp.DiscreteHomogeneousProcess(np.ones(N), 1.0),
+                                             nhp.DiscreteGaussianImpulseResponse(th, L, 1.0),
+                                             nhp.DenseWeightModel(np.full((N, N), 0.1)), 1.0)
+    res = nhp.mcmc_(proc, data, nsteps=60, seed=1)
+    assert res.steps == 60 and len(res.samples) == 60
+    lam = np.mean([s[:N] for s in res.samples[20:]], axis=0)
+    W = proc.weights.W
+    # the Gamma(1, 1) prior on W keeps a little excitation alive, so the baseline sits slightly below the rate
+    assert np.all(np.abs(lam - true) / true < 0.25) and np.all(np.diff(lam) > 0), lam
+    assert np.all(W < 0.2)                                               # independent Poisson data: weights shrink
+    assert np.allclose(proc.impulses.θ.sum(axis=2), 1.0)
