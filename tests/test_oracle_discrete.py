@@ -94,3 +94,27 @@ def test_vb_step_vs_bruteforce(orc):
     assert np.allclose(got[2], kap + want_g.sum(axis=2), rtol=1e-12)
     assert np.allclose(got[3], nu + data.sum(axis=1)[:, None] * np.ones((N, N)), rtol=1e-15)
     assert np.allclose(got[4], gam + want_g, rtol=1e-12)
+
+
+def test_gibbs_parent_counts_are_a_multinomial_draw(orc):
+    # src/parents.jl:82-116 reduced over time: every event gets exactly one parent; the mean of the
+    # counts is Σ_t n[c,t]·μ_k(t,c); a bin with weight only on one category puts all its events there
+    data, lam0, W, th, A, L, B, dt = case(N=3, T=300, B=3, L=6, seed=5)
+    N, T = data.shape
+    conv = orc.disc_convolve(data, orc.disc_basis(L, B, dt))
+    lam = orc.disc_intensity(conv, lam0, W, th, dt)
+    S = 150
+    acc = np.zeros((N, 1 + N * B))
+    for s in range(S):
+        c = orc.disc_resample_parents(data, conv, lam0, W, th, dt, seed=4, step=s)
+        assert np.array_equal(c.sum(axis=1), data.sum(axis=1))
+        acc += c
+    mu = np.zeros((N, 1 + N * B))
+    for c in range(N):
+        mu[c, 0] = (data[c] * lam0[c] * dt / lam[:, c]).sum()
+        for p in range(N):
+            for b in range(B):
+                mu[c, 1 + p * B + b] = (data[c] * conv[:, p, b] * W[p, c] * th[p, c, b] * dt / lam[:, c]).sum()
+    assert np.all(np.abs(acc / S - mu) < 5 * np.sqrt(mu / S) + 0.5)
+    none = orc.disc_resample_parents(data, conv, lam0, np.zeros((N, N)), th, dt, seed=1, step=0)
+    assert np.array_equal(none[:, 0], data.sum(axis=1)) and not none[:, 1:].any()      # W = 0: baseline takes all
