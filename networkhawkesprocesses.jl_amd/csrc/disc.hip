@@ -667,7 +667,7 @@ extern "C" nhp_status nhp_disc_vb_run(nhp_ctx *ctx, const nhp_disc_dataset *ds, 
 #define RP_SLOTS 4
 #define RP_KEY 0xD15C0DE5EEDC0FFEull
 
-__device__ __forceinline__ double rp_next_u(double u_prev, int remaining, uint64_t seed, uint64_t step, uint64_t bin, int j)
+__device__ __attribute__((noinline)) double rp_next_u(double u_prev, int remaining, uint64_t seed, uint64_t step, uint64_t bin, int j)
 {
 #pragma clang fp contract(off)
     const double V = nhp_philox_uniform(seed ^ RP_KEY, step, (bin << 20) | (uint64_t)j);
@@ -676,40 +676,87 @@ __device__ __forceinline__ double rp_next_u(double u_prev, int remaining, uint64
     return u_prev + (1.0 - u_prev) * w;
 }
 
-__global__ __launch_bounds__(256) void k_disc_resample_parents(const double *__restrict__ dataT, const double *__restrict__ conv,
+__global__ __launch_bounds__(256, 3) void k_disc_resample_parents(const double *__restrict__ dataT, const double *__restrict__ conv,
                                                                const double *__restrict__ E2, const double *__restrict__ base,
-                                                               int64_t T, int N, int B, uint64_t seed, uint64_t step,
-                                                               int *__restrict__ counts)
+                                                               int64_t T, int N, int B, unsigned b_magic, uint64_t seed,
+                                                               uint64_t step, int *__restrict__ counts)
 {
 #pragma clang fp contract(off)
     __shared__ unsigned short list[RP_TT * RP_CT];
     __shared__ double Gt[RP_KC][RP_TT];
     __shared__ double Et[RP_KC][RP_CT + 1];
-    __shared__ int nb;
+    __shared__ int nb, wcnt[4];
     const int tid = threadIdx.x, K = N * B;
     const int64_t t0 = (int64_t)blockIdx.x * RP_TT;
     const int c0 = blockIdx.y * RP_CT;
-    if (tid == 0) nb = 0;
-    __syncthreads();
+    // Occupied bins, listed bin-row by bin-row (entry = tl·RP_CT + cl): consecutive lanes then share a
+    // bin row, so a wave's reads of a G row collapse to a few broadcast addresses and its reads of an E
+    // row hit distinct banks.  Flags are gathered with coalesced loads (t fastest), then compacted in order.
+    unsigned char *occ = reinterpret_cast<unsigned char *>(&Et[0][0]);       // [RP_TT][RP_CT], before Et is used
     for (int i = tid; i < RP_TT * RP_CT; i += 256) {
-        const int64_t t = t0 + (i % RP_TT);
-        const int c = c0 + i / RP_TT;
-        if (t < T && c < N && dataT[(size_t)t + (size_t)T * c] > 0.0) list[atomicAdd(&nb, 1)] = (unsigned short)i;
+        const int tl_ = i % RP_TT, cl_ = i / RP_TT;
+        const int64_t t = t0 + tl_;
+        const int c = c0 + cl_;
+        occ[tl_ * RP_CT + cl_] = (t < T && c < N && dataT[(size_t)t + (size_t)T * c] > 0.0) ? 1 : 0;
+    }
+    __syncthreads();
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        constexpr int PER_WAVE = RP_TT * RP_CT / 4;
+        int cnt = 0;
+        for (int i = wave * PER_WAVE + lane; i < (wave + 1) * PER_WAVE; i += 64) cnt += __popcll(__ballot(occ[i] != 0));
+        if (lane == 0) wcnt[wave] = cnt;
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < wave; ++w) off += wcnt[w];
+        for (int i = wave * PER_WAVE + lane; i < (wave + 1) * PER_WAVE; i += 64) {
+            const bool f = occ[i] != 0;
+            const unsigned long long m = __ballot(f);
+            if (f) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
+            off += __popcll(m);
+        }
+        if (tid == 255) nb = off;
     }
     __syncthreads();
     const int nbins = nb;
 
-    auto stage = [&](int q0) {
-        for (int e = tid; e < RP_KC * RP_TT; e += 256) {
-            const int kk = e / RP_TT, tt = e % RP_TT, q = q0 + kk;
-            const int64_t t = t0 + tt;
-            // category q = p·B + b reads Ŝ[t, p, b]
-            Gt[kk][tt] = (q < K && t < T) ? conv[(size_t)t + (size_t)T * ((size_t)(q / B) + (size_t)N * (q % B))] : 0.0;
+    // A chunk of RP_KC categories is fetched into registers one chunk ahead (under the previous chunk's
+    // arithmetic) and written to LDS between two barriers.
+    constexpr int GN = RP_KC * RP_TT / 256, EN = RP_KC * RP_CT / 256;
+    static_assert(256 % RP_TT == 0 && 256 % RP_KC == 0, "staging coordinates below assume these");
+    double rg[GN], re[EN];
+    // staging coordinates are fixed per thread: G element r is (category row tid/RP_TT + (256/RP_TT)·r,
+    // bin tid % RP_TT), E element r is (category tid % RP_KC, node tid/RP_KC + (256/RP_KC)·r).
+    // Category q = p·B + b reads Ŝ[t, p, b]; q / B is a multiply-high by the host-made reciprocal.
+    const int g_tt = tid % RP_TT, g_k0 = tid / RP_TT, e_kk = tid % RP_KC, e_c0 = tid / RP_KC;
+    const bool g_ok = t0 + g_tt < T;
+    const double *g_base = conv + (size_t)(g_ok ? t0 + g_tt : 0);
+    const unsigned T32 = (unsigned)T;
+    // loads are unconditional from clamped (always valid) addresses and zeroed by a select afterwards:
+    // predicated loads compile to one exec-mask branch each, and twelve of them per chunk spill SGPRs
+    unsigned gmask = 0, emask = 0;            // which of the fetched values are real (applied when staged,
+    auto fetch = [&](int q0) {                // so that the loads stay in flight under the arithmetic)
+        gmask = 0; emask = 0;
+#pragma unroll
+        for (int r = 0; r < GN; ++r) {
+            const int qr = q0 + g_k0 + (256 / RP_TT) * r;
+            const unsigned q = (unsigned)(qr < K ? qr : K - 1);
+            const unsigned pq = B == 1 ? q : __umulhi(q, b_magic), bq = q - pq * (unsigned)B;
+            rg[r] = g_base[(size_t)T32 * (size_t)(pq + (unsigned)N * bq)];
+            gmask |= (qr < K && g_ok ? 1u : 0u) << r;
         }
-        for (int e = tid; e < RP_KC * RP_CT; e += 256) {
-            const int cc = e / RP_KC, kk = e % RP_KC, q = q0 + kk, c = c0 + cc;
-            Et[kk][cc] = (q < K && c < N) ? E2[(size_t)q + (size_t)c * K] : 0.0;
+#pragma unroll
+        for (int r = 0; r < EN; ++r) {
+            const int cr = c0 + e_c0 + (256 / RP_KC) * r, qr = q0 + e_kk;
+            re[r] = E2[(size_t)(qr < K ? qr : K - 1) + (size_t)(cr < N ? cr : N - 1) * K];
+            emask |= (qr < K && cr < N ? 1u : 0u) << r;
         }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int r = 0; r < GN; ++r) { const int e = tid + 256 * r; Gt[e / RP_TT][e % RP_TT] = (gmask >> r) & 1u ? rg[r] : 0.0; }
+#pragma unroll
+        for (int r = 0; r < EN; ++r) { const int e = tid + 256 * r; Et[e % RP_KC][e / RP_KC] = (emask >> r) & 1u ? re[r] : 0.0; }
     };
 
     for (int b0 = 0; b0 < nbins; b0 += 256 * RP_SLOTS) {
@@ -719,17 +766,19 @@ __global__ __launch_bounds__(256) void k_disc_resample_parents(const double *__r
         for (int s = 0; s < RP_SLOTS; ++s) {
             const int idx = b0 + tid + 256 * s;
             const int e = idx < nbins ? list[idx] : 0;
-            tl[s] = e % RP_TT; cl[s] = e / RP_TT;
+            tl[s] = e / RP_CT; cl[s] = e % RP_CT;
             n[s] = idx < nbins ? (int)dataT[(size_t)(t0 + tl[s]) + (size_t)T * (c0 + cl[s])] : 0;
             j[s] = 0;
             cum[s] = n[s] > 0 ? base[c0 + cl[s]] : 0.0;
             total[s] = 0.0; thr[s] = 0.0; u[s] = 0.0;
         }
         // ---- walk 1: row totals
+        fetch(0);
         for (int q0 = 0; q0 < K; q0 += RP_KC) {
             __syncthreads();
-            stage(q0);
+            stage();
             __syncthreads();
+            if (q0 + RP_KC < K) fetch(q0 + RP_KC);
 #pragma unroll 4
             for (int kk = 0; kk < RP_KC; ++kk) {
 #pragma unroll
@@ -753,10 +802,12 @@ __global__ __launch_bounds__(256) void k_disc_resample_parents(const double *__r
             }
         }
         // ---- walk 2: categories by inverse CDF
+        fetch(0);
         for (int q0 = 0; q0 < K; q0 += RP_KC) {
             __syncthreads();
-            stage(q0);
+            stage();
             __syncthreads();
+            if (q0 + RP_KC < K) fetch(q0 + RP_KC);
             for (int kk = 0; kk < RP_KC; ++kk) {
 #pragma unroll
                 for (int s = 0; s < RP_SLOTS; ++s) {
@@ -791,8 +842,11 @@ extern "C" nhp_status nhp_disc_resample_parents(nhp_ctx *ctx, const nhp_disc_dat
     hipStream_t st = ctx->stream;
     NHP_HIP(ctx, hipMemsetAsync(d_counts, 0, sizeof(int) * NC, st));
     dim3 grid((unsigned)((ds->T + RP_TT - 1) / RP_TT), (unsigned)((N + RP_CT - 1) / RP_CT));
+    if (ds->T >= ((int64_t)1 << 31) || K >= ((size_t)1 << 24)) { nhp_set_error(ctx, "resample_parents: T or N*B too large"); return NHP_ENOTIMPL; }
+    // q / B for q < 2^24 as a multiply-high: exact with magic = floor(2^32 / B) + 1 while q·B < 2^32
+    const unsigned b_magic = (unsigned)((((uint64_t)1 << 32) / (uint64_t)ds->B + 1) & 0xFFFFFFFFu);   // unused for B = 1
     hipLaunchKernelGGL(k_disc_resample_parents, grid, dim3(256), 0, st, ds->d_dataT, ds->d_conv, E2, base, ds->T, ds->N, ds->B,
-                       seed, step, d_counts);
+                       b_magic, seed, step, d_counts);
     NHP_HIP(ctx, hipGetLastError());
     std::vector<int> h((size_t)NC);
     NHP_HIP(ctx, hipMemcpyAsync(h.data(), d_counts, sizeof(int) * NC, hipMemcpyDeviceToHost, st));
