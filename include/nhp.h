@@ -238,6 +238,16 @@ nhp_status nhp_disc_vb_step(nhp_ctx *ctx, const nhp_disc_dataset *ds, double dt,
 nhp_status nhp_disc_resample_parents(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
                                      const double *W, const double *theta, const double *A, double dt,
                                      uint64_t seed, uint64_t step, int64_t *counts);
+/* resample_adjacency_matrix!(process::DiscreteNetworkHawkesProcess, data, convolved)
+ * src/discrete.jl:424-480: one Gibbs sweep over A [N*N] (host, updated in place), columns in parallel,
+ * entries of a column in sequence, each conditional on the current column.  Link probabilities
+ * (src/networks.jl:65-68): rho_matrix [N*N] if non-NULL, else the scalar rho; Bernoulli draws (u <= q, as
+ * Distributions.jl) from u [N*N] if non-NULL, else Philox keyed (seed, step, p + c*N).  n_links
+ * (nullable) receives ΣA for BernoulliNetworkModel's resample! (src/networks.jl:70-78). */
+nhp_status nhp_disc_resample_adjacency(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
+                                       const double *W, const double *theta, double *A, double dt,
+                                       const double *rho_matrix, double rho, const double *u,
+                                       uint64_t seed, uint64_t step, double *n_links);
 /* n_steps consecutive update! steps of vb! (src/inference.jl:153-181) with the variational parameters
  * resident on the device in between (one upload, one download) */
 nhp_status nhp_disc_vb_run(nhp_ctx *ctx, const nhp_disc_dataset *ds, double dt,

@@ -17,6 +17,7 @@ from . import continuous as _cont
 from .discrete import (DiscreteDataset, DiscreteGaussianImpulseResponse, DiscreteHawkesProcess,  # noqa: F401
                        DiscreteHomogeneousProcess, DiscreteNetworkHawkesProcess,
                        DiscreteStandardHawkesProcess, VariationalInference, convolve, disc_parent_counts,
+                       disc_resample_adjacency_matrix_,
                        resample_parent_counts, update_, vb_)
 from . import discrete as _disc
 from .parents import node_counts, parent_counts, resample_parents, uniform_stream  # noqa: F401

@@ -79,6 +79,7 @@ def _declare(lib):
     f("nhp_cont_model_get_params", i32, _vp, _vp, _dp, i64)
     f("nhp_cont_lgcp_loglik", i32, _vp, _vp, _ip, _dp, i32, _dp, _dp)
     f("nhp_disc_resample_parents", i32, _vp, _vp, _dp, _dp, _dp, _dp, dbl, u64, u64, _ip)
+    f("nhp_disc_resample_adjacency", i32, _vp, _vp, _dp, _dp, _dp, _dp, dbl, _dp, dbl, _dp, u64, u64, _dp)
     f("nhp_cont_resample_adjacency", i32, _vp, _vp, _vp, _dp, dbl, _dp, u64, u64, _dp, _dp)
     f("nhp_probe_math", i32, _vp, i32, _dp, _dp, i64, _dp)
     f("nhp_probe_rate", i32, _vp, i32, i32, i32, _dp)

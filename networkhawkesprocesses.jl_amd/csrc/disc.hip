@@ -21,6 +21,7 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+#define DA_TT 128       // bins per workgroup tile of the discrete adjacency sweep
 #define BM 128
 #define BN 128
 #ifndef BK
@@ -421,6 +422,17 @@ extern "C" nhp_status nhp_disc_basis(int32_t L, int32_t B, double dt, double *ph
     return NHP_OK;
 }
 
+// convsum[k] = Σ_t Ŝ[t, k]  (one workgroup per (p, b) column, fixed-order block reduction)
+__global__ __launch_bounds__(256) void k_disc_convsum(const double *__restrict__ conv, int64_t T, double *__restrict__ out)
+{
+    __shared__ double red[NHP_WAVES];
+    const double *col = conv + (size_t)blockIdx.x * (size_t)T;
+    double s = 0.0;
+    for (int64_t t = threadIdx.x; t < T; t += 256) s += col[t];
+    s = nhp_block_sum(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
 extern "C" nhp_status nhp_disc_dataset_create(nhp_ctx *ctx, const int64_t *data, int32_t N, int64_t T,
                                               nhp_disc_dataset **out)
 {
@@ -442,6 +454,31 @@ extern "C" nhp_status nhp_disc_dataset_create(nhp_ctx *ctx, const int64_t *data,
         return NHP_ENOMEM;
     }
     NHP_HIP(ctx, hipMemcpyAsync(d_raw, data, 8 * NT, hipMemcpyHostToDevice, st));
+    {   // occupied bins, time-major (data is N x T column-major: this is its memory order)
+        std::vector<int32_t> ot, oc, off((size_t)((T + DA_TT - 1) / DA_TT) + 1, 0);
+        std::vector<double> os;
+        for (int64_t t = 0; t < T; ++t) {
+            if (t % DA_TT == 0) off[(size_t)(t / DA_TT)] = (int32_t)ot.size();
+            for (int32_t n = 0; n < N; ++n) {
+                const int64_t v = data[(size_t)n + (size_t)t * N];
+                if (v > 0) { ot.push_back((int32_t)t); oc.push_back(n); os.push_back((double)v); }
+            }
+        }
+        off.back() = (int32_t)ot.size();
+        ds->nocc = (int64_t)ot.size();
+        if (ds->nocc >= ((int64_t)1 << 31)) { (void)hipFree(d_raw); nhp_set_error(ctx, "too many occupied bins"); nhp_disc_dataset_destroy(ds); return NHP_ENOTIMPL; }
+        const size_t no = ot.size() ? ot.size() : 1;
+        if (hipMalloc(&ds->d_occ_t, 4 * no) != hipSuccess || hipMalloc(&ds->d_occ_c, 4 * no) != hipSuccess ||
+            hipMalloc(&ds->d_occ_s, 8 * no) != hipSuccess || hipMalloc(&ds->d_occ_off, 4 * off.size()) != hipSuccess) {
+            (void)hipFree(d_raw); nhp_set_error(ctx, "out of device memory (occupied-bin list)"); nhp_disc_dataset_destroy(ds); return NHP_ENOMEM;
+        }
+        if (!ot.empty()) {
+            NHP_HIP(ctx, hipMemcpy(ds->d_occ_t, ot.data(), 4 * ot.size(), hipMemcpyHostToDevice));
+            NHP_HIP(ctx, hipMemcpy(ds->d_occ_c, oc.data(), 4 * oc.size(), hipMemcpyHostToDevice));
+            NHP_HIP(ctx, hipMemcpy(ds->d_occ_s, os.data(), 8 * os.size(), hipMemcpyHostToDevice));
+        }
+        NHP_HIP(ctx, hipMemcpy(ds->d_occ_off, off.data(), 4 * off.size(), hipMemcpyHostToDevice));
+    }
     dim3 tg((unsigned)((T + 31) / 32), (unsigned)((N + 31) / 32));
     hipLaunchKernelGGL(k_disc_transpose, tg, dim3(256), 0, st, d_raw, N, T, ds->d_dataT);
     hipLaunchKernelGGL(k_disc_colstats, dim3((unsigned)N), dim3(256), 0, st, ds->d_dataT, N, T, ds->d_colsum);
@@ -465,6 +502,8 @@ extern "C" void nhp_disc_dataset_destroy(nhp_disc_dataset *ds)
     (void)hipSetDevice(ds->ctx->device);
     (void)hipStreamSynchronize(ds->ctx->stream);
     (void)hipFree(ds->d_dataT); (void)hipFree(ds->d_conv); (void)hipFree(ds->d_colsum);
+    (void)hipFree(ds->d_occ_t); (void)hipFree(ds->d_occ_c); (void)hipFree(ds->d_occ_s); (void)hipFree(ds->d_occ_off);
+    (void)hipFree(ds->d_convsum);
     delete ds;
 }
 
@@ -489,6 +528,10 @@ extern "C" nhp_status nhp_disc_convolve(nhp_ctx *ctx, nhp_disc_dataset *ds, cons
     const size_t lds_conv = 8 * ((size_t)256 + L + (size_t)L * ((B + CONV_CB - 1) / CONV_CB * CONV_CB));
     if (lds_conv > 64 * 1024) { nhp_set_error(ctx, "convolve: nlags * nbasis = %d * %d exceeds the LDS budget", L, B); return NHP_ENOTIMPL; }
     hipLaunchKernelGGL(k_disc_convolve, grid, dim3(256), lds_conv, st, ds->d_dataT, ds->N, ds->T, d_phi, L, B, ds->d_conv);
+    NHP_HIP(ctx, hipGetLastError());
+    if (ds->d_convsum) { (void)hipFree(ds->d_convsum); ds->d_convsum = nullptr; }
+    if (hipMalloc(&ds->d_convsum, 8 * (size_t)ds->N * B) != hipSuccess) { nhp_set_error(ctx, "out of device memory"); return NHP_ENOMEM; }
+    hipLaunchKernelGGL(k_disc_convsum, dim3((unsigned)((size_t)ds->N * B)), dim3(256), 0, st, ds->d_conv, ds->T, ds->d_convsum);
     NHP_HIP(ctx, hipGetLastError());
     if (out) NHP_HIP(ctx, hipMemcpyAsync(out, ds->d_conv, 8 * TNB, hipMemcpyDeviceToHost, st));
     NHP_HIP(ctx, hipStreamSynchronize(st));
@@ -852,6 +895,178 @@ extern "C" nhp_status nhp_disc_resample_parents(nhp_ctx *ctx, const nhp_disc_dat
     NHP_HIP(ctx, hipMemcpyAsync(h.data(), d_counts, sizeof(int) * NC, hipMemcpyDeviceToHost, st));
     NHP_HIP(ctx, hipStreamSynchronize(st));
     for (size_t i = 0; i < NC; ++i) counts[i] = h[i];
+    return NHP_OK;
+}
+
+// ---- discrete adjacency Gibbs sweep (reference resample_adjacency_matrix! / resample_column!
+// / conditional_loglikelihood src/discrete.jl:424-480).  For entry (p, c) the reference evaluates two full
+// Poisson log-likelihoods of column c over all T bins and all N·B parent terms.  Their difference is
+//     ll1 - ll0 = Σ_{t: s>0} s_tc [log(λ⁰_tc + x_t) - log λ⁰_tc] - Σ_t x_t + log ρ - log(1-ρ),
+//     x_t = W[p,c] dt Σ_b Ŝ[t,p,b] θ[p,c,b],   λ⁰ = the intensity with A[p,c] = 0,
+// where only OCCUPIED bins need a log and Σ_t x_t = Σ_b (W θ dt)[p,c,b] · Σ_t Ŝ[t,p,b] uses per-dataset column
+// sums.  Columns are independent, entries of a column sequential in p -- so the sweep is N steps, each over
+// all occupied bins of all columns at once: k_dadj_accum (time-tiled: the Ŝ[·, p, ·] slice of the tile sits
+// in LDS, each lane owns occupied bins, per-column sums collect in LDS and leave as one row of partials per
+// tile) then k_dadj_decide (adds the tiles in fixed order, draws A[p, ·], and prepares step p+1).  λ of the
+// occupied bins is carried incrementally.
+__global__ __launch_bounds__(256) void k_dadj_gather(const double *__restrict__ lam, const int32_t *__restrict__ occ_t,
+                                                     const int32_t *__restrict__ occ_c, int64_t nocc, int64_t T,
+                                                     double *__restrict__ lam_occ, double *__restrict__ xprev)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nocc) { lam_occ[i] = lam[(size_t)occ_t[i] + (size_t)T * occ_c[i]]; xprev[i] = 0.0; }
+}
+
+// V[c*B + b] = W[p,c] θ[p,c,b] dt,  a_p[c] = A[p,c]   (row p of the tables, gathered once per step)
+__device__ __forceinline__ void dadj_prep_row(int p, int c, int N, int B, double dt, const double *W, const double *theta,
+                                              const double *A, double *V, double *a_p)
+{
+    const size_t pc = (size_t)p + (size_t)c * N;
+    for (int b = 0; b < B; ++b) V[(size_t)c * B + b] = (W[pc] * theta[pc + (size_t)b * N * N]) * dt;
+    a_p[c] = A[pc];
+}
+
+__global__ __launch_bounds__(256) void k_dadj_prep(int p, int N, int B, double dt, const double *__restrict__ W,
+                                                   const double *__restrict__ theta, const double *__restrict__ A,
+                                                   double *__restrict__ V, double *__restrict__ a_p, double *__restrict__ dprev)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < N) { dadj_prep_row(p, c, N, B, dt, W, theta, A, V, a_p); dprev[c] = 0.0; }
+}
+
+__global__ __launch_bounds__(256) void k_dadj_accum(int p, int N, int B, int64_t T, const double *__restrict__ conv,
+                                                    const int32_t *__restrict__ occ_t, const int32_t *__restrict__ occ_c,
+                                                    const double *__restrict__ occ_s, const int32_t *__restrict__ occ_off,
+                                                    const double *__restrict__ V, const double *__restrict__ a_p,
+                                                    const double *__restrict__ dprev, double *__restrict__ lam_occ,
+                                                    double *__restrict__ xprev, double *__restrict__ partial)
+{
+    extern __shared__ __align__(16) double dsm[];
+    double *Gt = dsm;                    // [B][DA_TT]
+    double *acc = dsm + (size_t)B * DA_TT;   // [N]
+    const int tid = threadIdx.x;
+    const int64_t t0 = (int64_t)blockIdx.x * DA_TT;
+    for (int e = tid; e < B * DA_TT; e += 256) {
+        const int b = e / DA_TT, tt = e % DA_TT;
+        const int64_t t = t0 + tt;
+        Gt[e] = t < T ? conv[(size_t)t + (size_t)T * ((size_t)p + (size_t)N * b)] : 0.0;
+    }
+    for (int c = tid; c < N; c += 256) acc[c] = 0.0;
+    __syncthreads();
+    for (int i = occ_off[blockIdx.x] + tid; i < occ_off[blockIdx.x + 1]; i += 256) {
+        const int c = occ_c[i], tt = occ_t[i] - (int)t0;
+        double lam = lam_occ[i];
+        const double dp = dprev[c];
+        if (dp != 0.0) { lam += dp * xprev[i]; lam_occ[i] = lam; }       // entry (p-1, c) flipped: carry it into λ
+        double x = 0.0;
+        const double *v = V + (size_t)c * B;
+        for (int b = 0; b < B; ++b) x += Gt[b * DA_TT + tt] * v[b];
+        xprev[i] = x;
+        if (x > 0.0) {
+            const double l0 = lam - a_p[c] * x;
+            atomicAdd(&acc[c], occ_s[i] * (nhp_log(l0 + x) - nhp_log(l0)));
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < N; c += 256) partial[(size_t)blockIdx.x * N + c] = acc[c];
+}
+
+__global__ __launch_bounds__(256) void k_dadj_decide(int p, int N, int B, int ntiles, double dt, const double *__restrict__ W,
+                                                     const double *__restrict__ theta, double *__restrict__ A,
+                                                     const double *__restrict__ partial, const double *__restrict__ convsum,
+                                                     const double *__restrict__ rho_mat, double rho_scalar,
+                                                     const double *__restrict__ u, uint64_t seed, uint64_t step,
+                                                     double *__restrict__ V, double *__restrict__ a_p, double *__restrict__ dprev)
+{
+    // 32 columns per workgroup, 8 lane-groups per column: group g adds tiles g, g+8, ... (four independent
+    // chains in flight), then the eight group sums are added in order -- a fixed summation tree
+    __shared__ double gsum[8][32];
+    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (c < N) {
+        int k = grp;
+        for (; k + 24 < ntiles; k += 32) {
+            s0 += partial[(size_t)k * N + c];
+            s1 += partial[(size_t)(k + 8) * N + c];
+            s2 += partial[(size_t)(k + 16) * N + c];
+            s3 += partial[(size_t)(k + 24) * N + c];
+        }
+        for (; k < ntiles; k += 8) s0 += partial[(size_t)k * N + c];
+    }
+    gsum[grp][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp != 0 || c >= N) return;
+    double delta = 0.0;
+    for (int g8 = 0; g8 < 8; ++g8) delta += gsum[g8][cl];
+    double sx = 0.0;                                                                // Σ_t x_t
+    for (int b = 0; b < B; ++b) sx += V[(size_t)c * B + b] * convsum[(size_t)p + (size_t)N * b];
+    const size_t pc = (size_t)p + (size_t)c * N;
+    const double rho = rho_mat ? rho_mat[pc] : rho_scalar;
+    const double d = (delta - sx) + nhp_log(rho) - nhp_log(1.0 - rho);              // ll1 - ll0
+    // rand(Bernoulli(exp(ll1 - logsumexp(ll0, ll1)))): u <= 1/(1 + e^{-d})  <=>  logit(u) <= d
+    const double uu = u ? u[pc] : nhp_philox_uniform(seed ^ 0xAD7AC3117D15C0DEull, step, pc);
+    const double anew = nhp_log(uu / (1.0 - uu)) <= d ? 1.0 : 0.0;
+    const double aold = a_p[c];
+    A[pc] = anew;
+    if (p + 1 < N) dadj_prep_row(p + 1, c, N, B, dt, W, theta, A, V, a_p);
+    dprev[c] = anew - aold;
+}
+
+extern "C" nhp_status nhp_disc_resample_adjacency(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
+                                                  const double *W, const double *theta, double *A, double dt,
+                                                  const double *rho_matrix, double rho, const double *u,
+                                                  uint64_t seed, uint64_t step, double *n_links)
+{
+    if (!ctx || !ds || !A) return NHP_EINVAL;
+    if (!rho_matrix && !(rho >= 0.0 && rho <= 1.0)) { nhp_set_error(ctx, "link probability must lie in [0, 1]"); return NHP_EDOMAIN; }
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t N = (size_t)ds->N, NN = N * N, B = (size_t)ds->B, TN = (size_t)ds->T * N;
+    const size_t nocc = (size_t)(ds->nocc > 0 ? ds->nocc : 1);
+    const int ntiles = (int)((ds->T + DA_TT - 1) / DA_TT);
+    const size_t lds = 8 * (B * DA_TT + N);
+    if (lds > 160 * 1024) { nhp_set_error(ctx, "resample_adjacency: N = %d, B = %d exceed the LDS budget", ds->N, ds->B); return NHP_ENOTIMPL; }
+    // scratch after stage_bump's own block: λ (T·N, for the initial gather) | λ_occ | xprev | partial | V | a_p | dprev | u | ρ
+    const size_t extra = TN + 2 * nocc + (size_t)ntiles * N + N * B + 2 * N + 2 * NN;
+    double *E, *base, *x;
+    NHP_TRY(stage_bump(ctx, ds, lambda0, W, theta, A, dt, &E, &base, extra, &x));
+    double *dlam = x; x += TN;
+    double *lam_occ = x; x += nocc;
+    double *xprev = x; x += nocc;
+    double *partial = x; x += (size_t)ntiles * N;
+    double *V = x; x += N * B;
+    double *a_p = x; x += N;
+    double *dprev = x; x += N;
+    double *d_u = x; x += NN;
+    double *d_rho = x;
+    // stage_bump left W, θ, A on the device just before the extra block: recover the pointers
+    double *dW = base + 2 * N, *dth = dW + NN, *dA = dth + NN * B;
+    hipStream_t st = ctx->stream;
+    if (u) NHP_HIP(ctx, hipMemcpyAsync(d_u, u, 8 * NN, hipMemcpyHostToDevice, st));
+    if (rho_matrix) NHP_HIP(ctx, hipMemcpyAsync(d_rho, rho_matrix, 8 * NN, hipMemcpyHostToDevice, st));
+    // λ under the current A (GEMM-1), gathered at the occupied bins
+    gemm_args g{};
+    g.A = ds->d_conv; g.lda = (size_t)ds->T; g.B = E; g.ldb = N * B;
+    g.M = (int)ds->T; g.N = ds->N; g.K = (int)(N * B); g.k_chunk = g.K;
+    g.base = base; g.out = dlam;
+    launch_gemm<true, EPI_INTENSITY>(g, 1, st);
+    NHP_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_dadj_gather, dim3((unsigned)((nocc + 255) / 256)), dim3(256), 0, st, dlam, ds->d_occ_t, ds->d_occ_c,
+                       ds->nocc, ds->T, lam_occ, xprev);
+    const unsigned cb = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(k_dadj_prep, dim3(cb), dim3(256), 0, st, 0, ds->N, ds->B, dt, dW, dth, dA, V, a_p, dprev);
+    NHP_HIP(ctx, hipGetLastError());
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_dadj_accum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int p = 0; p < ds->N; ++p) {
+        hipLaunchKernelGGL(k_dadj_accum, dim3((unsigned)ntiles), dim3(256), lds, st, p, ds->N, ds->B, ds->T, ds->d_conv, ds->d_occ_t,
+                           ds->d_occ_c, ds->d_occ_s, ds->d_occ_off, V, a_p, dprev, lam_occ, xprev, partial);
+        hipLaunchKernelGGL(k_dadj_decide, dim3((unsigned)((N + 31) / 32)), dim3(256), 0, st, p, ds->N, ds->B, ntiles, dt, dW, dth, dA, partial, ds->d_convsum,
+                           rho_matrix ? d_rho : nullptr, rho, u ? d_u : nullptr, seed, step, V, a_p, dprev);
+    }
+    NHP_HIP(ctx, hipGetLastError());
+    NHP_HIP(ctx, hipMemcpyAsync(A, dA, 8 * NN, hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipStreamSynchronize(st));
+    if (n_links) { double s = 0.0; for (size_t i = 0; i < NN; ++i) s += A[i]; *n_links = s; }
     return NHP_OK;
 }
 

@@ -117,6 +117,12 @@ struct nhp_disc_dataset {
     double *d_conv = nullptr;           // [T*N*B] t fastest
     double *d_colsum = nullptr;         // [2N] Σ_t data[n,t], then Σ_t loggamma(data[n,t]+1)
     double lgamma_sum = 0.0;            // Σ_{n,t} loggamma(data[n,t]+1): the data-only term of the Poisson ll
+    // occupied bins (count > 0) in time-major order, for the discrete adjacency sweep
+    int64_t nocc = 0;
+    int32_t *d_occ_t = nullptr, *d_occ_c = nullptr;   // [nocc] bin, node (0-based)
+    double *d_occ_s = nullptr;                        // [nocc] the count
+    int32_t *d_occ_off = nullptr;                     // [ntiles + 1] first occupied bin of each DA_TT-bin tile
+    double *d_convsum = nullptr;                      // [N*B] Σ_t Ŝ[t, p, b] (filled with the convolution)
 };
 
 // ---- error plumbing -------------------------------------------------------------------

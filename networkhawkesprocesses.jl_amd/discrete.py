@@ -269,16 +269,41 @@ def disc_parent_counts(counts, ndims, nbasis):
     return counts[:, 1:].reshape((ndims, ndims, nbasis)).sum(axis=2).T.astype(np.float64)      # [parent, child]
 
 
+def disc_resample_adjacency_matrix_(process, data=None, convolved=None, u=None, seed=0, step=0, ctx=None):
+    """resample_adjacency_matrix!(process, data, convolved) -- src/discrete.jl:424-480: one Gibbs sweep of
+    the adjacency matrix on the GPU.  `u` (N x N, [parent, child]) supplies the Bernoulli uniforms
+    explicitly; otherwise Philox keyed (seed, step).  Updates process.adjacency_matrix, returns ΣA."""
+    from .components import BernoulliNetworkModel, DenseNetworkModel
+    ctx = ctx or _lib.default_context()
+    ds = _convolved(process, data, convolved, ctx)
+    l0, W, th, _ = process._lowered()
+    N = ds.N
+    if isinstance(process.network, BernoulliNetworkModel):
+        scalar, rho_m = float(process.network.ρ), None
+    elif isinstance(process.network, DenseNetworkModel):
+        scalar, rho_m = 1.0, None
+    else:
+        scalar, rho_m = 0.5, _lib.colmajor(np.asarray(process.network.link_probability(), dtype=np.float64))
+    A = _lib.colmajor(process.adjacency_matrix).copy()
+    uu = None if u is None else _lib.colmajor(np.asarray(u, dtype=np.float64))
+    nl = C.c_double()
+    _lib.check(_lib.lib().nhp_disc_resample_adjacency(ctx.h, ds.h, _lib.dptr(l0), _lib.dptr(W), _lib.dptr(th), _lib.dptr(A),
+                                                      process.dt, _lib.dptr(rho_m), scalar, _lib.dptr(uu), seed, step,
+                                                      C.byref(nl)), ctx.h)
+    process.adjacency_matrix = A.reshape((N, N), order="F")
+    return nl.value
+
+
 def disc_resample_(process, data, convolved, rng, seed=0, step=0, ctx=None):
-    """resample!(process::DiscreteStandardHawkesProcess, data, convolved) -- src/discrete.jl:362-368.
+    """resample!(process::DiscreteStandardHawkesProcess, data, convolved) -- src/discrete.jl:362-368, and the
+    network twin :416-424 (adds the adjacency sweep and the network's ρ).
 
     Parent counts come from the GPU; the conjugate draws are numpy (statistical, not bitwise, parity with
     Julia's samplers).  The reference's baseline update is broken for the homogeneous process (it passes
     the T x N slice to a helper that expects N x T: SURVEY D2); the intended update is applied:
     λ ~ Gamma(α0 + Σ_t parents[t, c, 1], 1 / (β0 + T·dt))  (src/baselines.jl:413-419)."""
-    if not isinstance(process, DiscreteStandardHawkesProcess) or not isinstance(process.weights, DenseWeightModel):
-        raise NotImplementedError("discrete Gibbs is built for DiscreteStandardHawkesProcess + DenseWeightModel "
-                                  "(network variant: SURVEY 8f-3, adjacency sweep not built)")
+    if not isinstance(process.weights, DenseWeightModel):
+        raise NotImplementedError("discrete Gibbs is built for DenseWeightModel (SparseWeightModel: SURVEY 2.1)")
     ctx = ctx or _lib.default_context()
     ds = _convolved(process, data, convolved, ctx)
     N, B = ds.N, ds.B
@@ -290,6 +315,9 @@ def disc_resample_(process, data, convolved, rng, seed=0, step=0, ctx=None):
     γ = imp.γ + counts[:, 1:].reshape((N, N, B)).transpose(1, 0, 2)                                  # [parent, child, basis]
     g = rng.gamma(γ, 1.0)
     imp.θ = g / g.sum(axis=2, keepdims=True)                                                         # Dirichlet: src/impulses.jl:337-353
+    if isinstance(process, DiscreteNetworkHawkesProcess):
+        links = disc_resample_adjacency_matrix_(process, convolved=ds, seed=seed, step=step, ctx=ctx)
+        process.network.resample_links_(links, N * N, rng)
     return process.params()
 
 

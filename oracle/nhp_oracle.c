@@ -827,3 +827,48 @@ int orc_disc_resample_parents(const int64_t *data, const double *conv, int64_t T
     return ORC_OK;
 }
 
+/* Discrete adjacency Gibbs: resample_adjacency_matrix! / resample_column! / conditional_loglikelihood
+ * src/discrete.jl:424-480, restated literally -- for every entry two full passes over all T bins and all
+ * N*B parent terms of the child column (O(N^3 B T) per sweep: small cases only).
+ * [3P] pdf(Poisson(λ), s) = exp(xlogy(s, λ) - λ - loggamma(s+1)), then log(); rand(Bernoulli(q)) = u <= q;
+ * logsumexp src/utils/helpers.jl:13-16.  rho[p + c*N] = link_probability, u[p + c*N] the explicit uniforms;
+ * A is updated in place, column by column, parent by parent. */
+static double disc_conditional_ll(const int64_t *data, const double *conv, int64_t T, int32_t N, int32_t B,
+                                  const double *lambda0, const double *W, const double *theta, const double *A,
+                                  double dt, double value, int32_t pidx, int32_t cidx)
+{
+    double ll = 0.0;
+    for (int64_t t = 0; t < T; ++t) {
+        double lam = lambda0[cidx] * dt;                     /* intensity(process.baseline, 1:T)[t, cidx] */
+        for (int32_t p = 0; p < N; ++p) {
+            double w = W[IDX(p, cidx, N)];
+            double a = (p == pidx) ? value : A[IDX(p, cidx, N)];
+            for (int32_t b = 0; b < B; ++b) {
+                double shat = conv[(size_t)t + (size_t)p * T + (size_t)b * T * N];
+                double th = theta[IDX(p, cidx, N) + (size_t)b * N * N];
+                lam += shat * a * w * th * dt;
+            }
+        }
+        double sd = (double)data[cidx + (size_t)t * N];
+        double xlogy = (sd == 0.0) ? 0.0 : sd * log(lam);
+        ll += log(exp(xlogy - lam - lgamma(sd + 1.0)));
+    }
+    return ll;
+}
+
+int orc_disc_resample_adjacency(const int64_t *data, const double *conv, int64_t T, int32_t N, int32_t B,
+                                const double *lambda0, const double *W, const double *theta, double dt,
+                                const double *rho, const double *u, double *A)
+{
+    for (int32_t c = 0; c < N; ++c)
+        for (int32_t p = 0; p < N; ++p) {
+            size_t k = IDX(p, c, N);
+            double ll0 = disc_conditional_ll(data, conv, T, N, B, lambda0, W, theta, A, dt, 0.0, p, c) + log(1.0 - rho[k]);
+            double ll1 = disc_conditional_ll(data, conv, T, N, B, lambda0, W, theta, A, dt, 1.0, p, c) + log(rho[k]);
+            double mx = ll0 > ll1 ? ll0 : ll1;
+            double Z = mx + log(exp(ll0 - mx) + exp(ll1 - mx));
+            A[k] = (u[k] <= exp(ll1 - Z)) ? 1.0 : 0.0;
+        }
+    return ORC_OK;
+}
+

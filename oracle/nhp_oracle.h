@@ -99,6 +99,11 @@ int orc_disc_resample_parents(const int64_t *data, const double *conv, int64_t T
                               const double *lambda0, const double *W, const double *theta, const double *A,
                               double dt, uint64_t seed, uint64_t step, int64_t *counts);
 
+/* ---- discrete adjacency Gibbs sweep (src/discrete.jl:424-480), literal; A [N*N] in place */
+int orc_disc_resample_adjacency(const int64_t *data, const double *conv, int64_t T, int32_t N, int32_t B,
+                                const double *lambda0, const double *W, const double *theta, double dt,
+                                const double *rho, const double *u, double *A);
+
 /* ---- LGCP baseline likelihood inside the elliptical-slice sampler (src/baselines.jl:227-254) */
 int orc_lgcp_loglik(const double *times, const int64_t *nodes, const int64_t *parentnodes, int64_t M,
                     int32_t N, const double *grid_x, int32_t G, const double *lam, double *ll);

@@ -290,6 +290,19 @@ def disc_resample_parents(data, conv, lambda0, W, theta, dt=1.0, A=None, seed=0,
     return out.reshape((N, 1 + N * B), order="F")
 
 
+def disc_resample_adjacency(data, conv, lambda0, W, theta, A, rho, u, dt=1.0):
+    """One sweep of the discrete resample_adjacency_matrix!; rho, u, A: N x N indexed [parent, child]."""
+    data = np.asarray(data, dtype=np.int64)
+    T, N, B = conv.shape
+    d = np.asfortranarray(data).ravel(order="K")
+    cv = np.asfortranarray(conv).ravel(order="K")
+    Aw = _col(A).copy()
+    r, uu = _col(np.broadcast_to(rho, (N, N))), _col(u)
+    _chk(lib().orc_disc_resample_adjacency(d.ctypes.data_as(_ip), _p(cv), C.c_int64(T), C.c_int32(N), C.c_int32(B),
+                                           _p(_f(lambda0)), _p(_col(W)), _p(_col(theta)), C.c_double(dt), _p(r), _p(uu), _p(Aw)))
+    return Aw.reshape((N, N), order="F")
+
+
 def disc_loglik(data, lam):
     data = np.asarray(data, dtype=np.int64)
     N, T = data.shape

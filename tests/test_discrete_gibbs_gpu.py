@@ -69,3 +69,43 @@ def test_discrete_mcmc_recovers_the_baseline_when_there_is_no_excitation(nhp):
     assert np.all(np.abs(lam - true) / true < 0.25) and np.all(np.diff(lam) > 0), lam
     assert np.all(W < 0.2)                                               # independent Poisson data: weights shrink
     assert np.allclose(proc.impulses.θ.sum(axis=2), 1.0)
+
+
+def make_network(nhp, N, T, B, L, rate, seed):
+    proc, data = make(nhp, N, T, B, L, rate, seed)
+    rng = np.random.default_rng(seed + 50)
+    A = (rng.uniform(size=(N, N)) < 0.5).astype(np.float64)
+    net = nhp.DiscreteNetworkHawkesProcess(proc.baseline, proc.impulses, proc.weights, A,
+                                           nhp.BernoulliNetworkModel(0.3, N), proc.dt)
+    return net, data
+
+
+@pytest.mark.parametrize("N,T,B,L,rate", [(3, 300, 3, 6, 0.5), (5, 257, 2, 4, 1.5), (4, 1000, 4, 9, 0.1)])
+def test_adjacency_sweep_equals_the_literal_restatement(nhp, orc, N, T, B, L, rate):
+    # explicit uniforms: the decisions of the incremental GPU sweep vs the reference's two full
+    # conditional log-likelihoods per entry (src/discrete.jl:445-480)
+    proc, data = make_network(nhp, N, T, B, L, rate, seed=3 * N + T)
+    proc.weights.W = proc.weights.W * N * 1.5                       # links that matter
+    ds, conv = nhp.convolve(proc, data, fetch=True)
+    u = np.random.default_rng(7).uniform(size=(N, N))
+    A0 = proc.adjacency_matrix.copy()
+    want = orc.disc_resample_adjacency(data, conv, proc.baseline.λ, proc.weights.W, proc.impulses.θ, A0, 0.3, u, proc.dt)
+    links = nhp.disc_resample_adjacency_matrix_(proc, convolved=ds, u=u)
+    assert np.array_equal(proc.adjacency_matrix, want)
+    assert links == want.sum()
+    assert not np.array_equal(want, A0)                             # the sweep did something
+
+
+def test_network_counts_respect_the_mask_and_mcmc_runs(nhp, orc):
+    proc, data = make_network(nhp, 6, 2000, 3, 6, 0.4, seed=21)
+    ds, conv = nhp.convolve(proc, data, fetch=True)
+    got = nhp.resample_parent_counts(proc, convolved=ds, seed=5, step=0)
+    want = orc.disc_resample_parents(data, conv, proc.baseline.λ, proc.weights.W, proc.impulses.θ, proc.dt,
+                                     A=proc.adjacency_matrix, seed=5, step=0)
+    assert np.array_equal(got, want)
+    Mnm = nhp.disc_parent_counts(got, 6, 3)
+    assert not Mnm[proc.adjacency_matrix == 0].any()                # no parents through absent links
+    res = nhp.mcmc_(proc, data, nsteps=8, seed=2)
+    assert res.steps == 8 and all(np.all(np.isfinite(s)) for s in res.samples)
+    assert set(np.unique(proc.adjacency_matrix)) <= {0.0, 1.0}
+    assert 0.0 < proc.network.ρ < 1.0

@@ -118,3 +118,23 @@ def test_gibbs_parent_counts_are_a_multinomial_draw(orc):
     assert np.all(np.abs(acc / S - mu) < 5 * np.sqrt(mu / S) + 0.5)
     none = orc.disc_resample_parents(data, conv, lam0, np.zeros((N, N)), th, dt, seed=1, step=0)
     assert np.array_equal(none[:, 0], data.sum(axis=1)) and not none[:, 1:].any()      # W = 0: baseline takes all
+
+
+def test_discrete_adjacency_sweep_limits(orc):
+    # src/discrete.jl:445-480: with W = 0 the likelihood does not see A, so u <= ρ decides every entry;
+    # with a strongly excitatory, well-supported link the entry is kept whatever the prior odds
+    data, lam0, W, th, A, L, B, dt = case(N=3, T=200, B=2, L=5, seed=8)
+    N, T = data.shape
+    conv = orc.disc_convolve(data, orc.disc_basis(L, B, dt))
+    u = np.random.default_rng(2).uniform(size=(N, N))
+    got = orc.disc_resample_adjacency(data, conv, lam0, np.zeros((N, N)), th, np.ones((N, N)), 0.37, u, dt)
+    assert np.array_equal(got, (u <= 0.37).astype(float))
+    rng = np.random.default_rng(4)
+    data2 = np.zeros((2, 400), dtype=np.int64)
+    data2[0, ::10] = 1
+    data2[1, 1::10] = 3                                  # node 2 fires right after node 1, every time
+    conv2 = orc.disc_convolve(data2, orc.disc_basis(3, 2, 1.0))
+    th2 = np.full((2, 2, 2), 0.5)
+    got = orc.disc_resample_adjacency(data2, conv2, np.full(2, 0.01), np.full((2, 2), 2.0), th2, np.zeros((2, 2)), 0.5,
+                                      np.full((2, 2), 0.999), 1.0)
+    assert got[0, 1] == 1.0
