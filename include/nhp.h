@@ -222,6 +222,12 @@ nhp_status nhp_disc_intensity(nhp_ctx *ctx, const nhp_disc_dataset *ds, const do
 nhp_status nhp_disc_loglik(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
                            const double *W, const double *theta, const double *A, double dt,
                            double *ll);
+/* loglikelihood(process, data, convolved) and its gradient in mle!'s parameter vector
+ * [λ0 (N); vec(W .* θ) (N*N*B)]  (params / params! src/discrete.jl:174-201): what the 2P finite-difference
+ * objective calls per gradient inside mle! (src/discrete.jl:211-296) are replaced by */
+nhp_status nhp_disc_loglik_grad(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
+                                const double *W, const double *theta, double dt, double *ll, double *grad,
+                                int64_t grad_len);
 /* one update!(process, data, convolved) mean-field step  src/discrete.jl:369-375;
  * variational parameters are read and overwritten in place (host arrays) */
 nhp_status nhp_disc_vb_step(nhp_ctx *ctx, const nhp_disc_dataset *ds, double dt,

@@ -12,7 +12,7 @@ from .components import (BernoulliNetworkModel, DenseNetworkModel, DenseWeightMo
                          PeriodicKernel, SquaredExponentialKernel, split_extract)
 from .continuous import (ContinuousHawkesProcess, ContinuousNetworkHawkesProcess,  # noqa: F401
                          ContinuousStandardHawkesProcess, DeviceDataset, HawkesProcess, device_dataset,
-                         loglikelihood_gradient, total_intensity)
+                         total_intensity)
 from . import continuous as _cont
 from .discrete import (DiscreteDataset, DiscreteGaussianImpulseResponse, DiscreteHawkesProcess,  # noqa: F401
                        DiscreteHomogeneousProcess, DiscreteNetworkHawkesProcess,
@@ -21,7 +21,7 @@ from .discrete import (DiscreteDataset, DiscreteGaussianImpulseResponse, Discret
                        resample_parent_counts, update_, vb_)
 from . import discrete as _disc
 from .parents import node_counts, parent_counts, resample_parents, uniform_stream  # noqa: F401
-from .inference import (MarkovChainMonteCarlo, MaximumLikelihood, logprior, mle_,  # noqa: F401
+from .inference import (MarkovChainMonteCarlo, MaximumLikelihood, logprior,  # noqa: F401
                         resample_adjacency_matrix_)
 from . import inference as _inf
 from . import synthetic  # noqa: F401
@@ -44,6 +44,20 @@ def intensity(process, data, *args, **kwargs):
             return _disc.disc_intensity(process, convolved=data, **kwargs)
         return _disc.disc_intensity(process, data, **kwargs)
     return _cont.intensity(process, data, *args, **kwargs)
+
+
+def mle_(process, data, *args, **kwargs):
+    """mle!(process, data; ...) -- src/continuous.jl:144-198 / src/discrete.jl:211-296."""
+    if isinstance(process, DiscreteHawkesProcess):
+        return _disc.disc_mle_(process, data, *args, **kwargs)
+    return _inf.mle_(process, data, *args, **kwargs)
+
+
+def loglikelihood_gradient(process, data, *args, **kwargs):
+    """(ll, gradient) in the order of params(process): continuous [λ0; θ | μ; τ; W], discrete [λ0; vec(W .* θ)]."""
+    if isinstance(process, DiscreteHawkesProcess):
+        return _disc.disc_loglikelihood_gradient(process, data, *args, **kwargs)
+    return _cont.loglikelihood_gradient(process, data, *args, **kwargs)
 
 
 def mcmc_(process, data, *args, **kwargs):

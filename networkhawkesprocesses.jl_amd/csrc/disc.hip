@@ -619,6 +619,78 @@ extern "C" nhp_status nhp_disc_loglik(nhp_ctx *ctx, const nhp_disc_dataset *ds, 
     return nhp_ctx_fetch(ctx, 0, 1, ll);
 }
 
+// ---- gradient of the discrete log-likelihood in the reference's mle! parameters [λ0; η = W∘θ]
+// (params / params! src/discrete.jl:174-201; the reference hands Optim no gradient -- its d_loglikelihood
+// :298-314 is commented out of mle! -- so one gradient costs it 2(N + N²B) objective calls):
+//     ∂ll/∂λ0[c] = dt Σ_t (s_tc/λ_tc - 1),      ∂ll/∂η[p,c,b] = dt Σ_t (s_tc/λ_tc - 1) Ŝ[t,p,b]
+// i.e. with R = data/Z from GEMM-1:  dt (colsum R - T)  and  dt (Gᵀ·R - Σ_t Ŝ) -- the VB step's two GEMMs
+// with a different last kernel.
+__global__ __launch_bounds__(256) void k_disc_grad_finish(int N, int B, int splits, int row_blocks, double dt, double Tbins,
+                                                          const double *__restrict__ slabs, const double *__restrict__ colp,
+                                                          const double *__restrict__ convsum, double *__restrict__ grad)
+{
+    const size_t NN = (size_t)N * N, K = (size_t)N * B;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < NN * B) {
+        const size_t b = i / NN, pc = i % NN, p = pc % N, c = pc / N, k = p + b * N;
+        double g = 0.0;
+        for (int z = 0; z < splits; ++z) g += slabs[(size_t)z * K * N + k + c * K];      // fixed order
+        grad[N + i] = dt * (g - convsum[k]);
+    }
+    if (i < (size_t)N) {
+        double r = 0.0;
+        for (int rb = 0; rb < row_blocks; ++rb) r += colp[(size_t)rb * N + i];
+        grad[i] = dt * (r - Tbins);
+    }
+}
+
+extern "C" nhp_status nhp_disc_loglik_grad(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
+                                           const double *W, const double *theta, double dt, double *ll, double *grad,
+                                           int64_t grad_len)
+{
+    if (!ctx || !ds || !ll || !grad) return NHP_EINVAL;
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t N = (size_t)ds->N, NN = N * N, B = (size_t)ds->B, K = N * B, T = (size_t)ds->T;
+    if ((size_t)grad_len != N + NN * B) { nhp_set_error(ctx, "Parameter vector length does not match model parameter length."); return NHP_ESHAPE; }
+    if (!ds->d_convsum) { nhp_set_error(ctx, "convolve(process, data) must run before the gradient"); return NHP_EINVAL; }
+    const int row_blocks = (int)((T + BM - 1) / BM);
+    const int tiles2 = (int)(((K + BM - 1) / BM) * ((N + BN - 1) / BN));
+    int splits = (2 * ctx->cu_count + tiles2 - 1) / tiles2;
+    splits = std::max(1, std::min(splits, (int)((T + 4 * BK - 1) / (4 * BK))));
+    int k_chunk = (int)((T + splits - 1) / splits);
+    k_chunk = ((k_chunk + BK - 1) / BK) * BK;
+    splits = (int)((T + k_chunk - 1) / k_chunk);
+    double *E, *base, *x;
+    NHP_TRY(stage_bump(ctx, ds, lambda0, W, theta, nullptr, dt, &E, &base, T * N + (size_t)row_blocks * N + (size_t)splits * K * N + N + NN * B, &x));
+    double *dR = x; x += T * N;
+    double *dcolp = x; x += (size_t)row_blocks * N;
+    double *dslab = x; x += (size_t)splits * K * N;
+    double *dgrad = x;
+    hipStream_t st = ctx->stream;
+    // ll: GEMM-1 with the Poisson epilogue
+    gemm_args g{};
+    g.A = ds->d_conv; g.lda = T; g.B = E; g.ldb = K; g.M = (int)T; g.N = (int)N; g.K = (int)K; g.k_chunk = (int)K;
+    g.base = base; g.dataT = ds->d_dataT;
+    const int blocks = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)blocks));
+    g.partials = ctx->d_partials;
+    launch_gemm<true, EPI_LOGLIK>(g, 1, st);
+    hipLaunchKernelGGL(k_sum_pairs, dim3(1), dim3(256), 0, st, ctx->d_partials, blocks, ds->lgamma_sum, ctx->d_results);
+    // R = data / Z and its column sums, then Gᵀ·R in T-slabs
+    gemm_args g1 = g;
+    g1.out = dR; g1.partials = dcolp;
+    launch_gemm<true, EPI_VB_Z>(g1, 1, st);
+    gemm_args g2{};
+    g2.A = ds->d_conv; g2.lda = T; g2.B = dR; g2.ldb = T; g2.M = (int)K; g2.N = (int)N; g2.K = (int)T; g2.k_chunk = k_chunk;
+    g2.out = dslab;
+    launch_gemm<false, EPI_SLAB>(g2, splits, st);
+    hipLaunchKernelGGL(k_disc_grad_finish, dim3((unsigned)((NN * B + 255) / 256)), dim3(256), 0, st, (int)N, (int)B, splits, row_blocks,
+                       dt, (double)T, dslab, dcolp, ds->d_convsum, dgrad);
+    NHP_HIP(ctx, hipGetLastError());
+    NHP_HIP(ctx, hipMemcpyAsync(grad, dgrad, 8 * (N + NN * B), hipMemcpyDeviceToHost, st));
+    return nhp_ctx_fetch(ctx, 0, 1, ll);
+}
+
 // (nhp_disc_vb_run is declared in include/nhp.h)
 extern "C" nhp_status nhp_disc_vb_step(nhp_ctx *ctx, const nhp_disc_dataset *ds, double dt,
                                        double alpha0, double beta0, double kappa, double nu, double gamma,

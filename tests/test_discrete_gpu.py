@@ -108,3 +108,55 @@ def test_config4_shape_properties(nhp):
     from scipy.special import gammaln
     closed = (data.T * np.log(lam0)[None, :]).sum() - T * lam0.sum() - gammaln(data + 1.0).sum()
     assert abs(nhp.loglikelihood(proc, data, convolved=ds) - closed) < 1e-10 * abs(closed)
+
+
+def test_gradient_matches_finite_differences_of_the_oracle(nhp, orc):
+    # ∂ll/∂[λ0; vec(W .* θ)] (params order of src/discrete.jl:174-182) vs central differences of the oracle's ll
+    rng = np.random.default_rng(12)
+    N, T, B, L, dt = 3, 400, 2, 5, 0.5
+    data = rng.poisson(0.4, (N, T)).astype(np.int64)
+    th = rng.dirichlet(np.ones(B), (N, N))
+    th[:, :, -1] = 1.0 - th[:, :, :-1].sum(axis=2)
+    proc = nhp.DiscreteStandardHawkesProcess(nhp.DiscreteHomogeneousProcess(rng.uniform(0.3, 0.8, N), dt),
+                                             nhp.DiscreteGaussianImpulseResponse(th, L, dt),
+                                             nhp.DenseWeightModel(rng.uniform(0.05, 0.3, (N, N))), dt)
+    ds, conv = nhp.convolve(proc, data, fetch=True)
+    ll, g = nhp.loglikelihood_gradient(proc, data, convolved=ds)
+    assert abs(ll - nhp.loglikelihood(proc, data, convolved=ds)) < 1e-9 * abs(ll)
+    x = proc.params()
+    assert len(g) == len(x) == N + N * N * B
+
+    def f(v):
+        eta = v[N:].reshape((N, N, B), order="F")
+        W = eta.sum(axis=2)
+        return orc.disc_loglik(data, orc.disc_intensity(conv, v[:N], W, eta / W[:, :, None], dt))
+
+    for k in range(len(x)):
+        h = 1e-6 * max(1.0, abs(x[k]))
+        xp, xm = x.copy(), x.copy()
+        xp[k] += h
+        xm[k] -= h
+        fd = (f(xp) - f(xm)) / (2 * h)
+        assert abs(g[k] - fd) < 1e-5 * max(1.0, abs(fd)), (k, g[k], fd)
+
+
+def test_discrete_mle_finds_the_rates_of_independent_poisson_data(nhp):
+    rng = np.random.default_rng(3)
+    N, T, B, L = 2, 20000, 2, 4
+    true = np.array([0.2, 0.6])
+    data = rng.poisson(true[:, None] * np.ones((N, T))).astype(np.int64)
+    th = np.full((N, N, B), 0.5)
+    proc = nhp.DiscreteStandardHawkesProcess(nhp.DiscreteHomogeneousProcess(np.ones(N), 1.0),
+                                             nhp.DiscreteGaussianImpulseResponse(th, L, 1.0),
+                                             nhp.DenseWeightModel(np.full((N, N), 0.1)), 1.0)
+    ll0 = nhp.loglikelihood(proc, data)
+    res = nhp.mle_(proc, data, seed=1)
+    assert res.status == "success" and res.maximum > ll0
+    assert abs(res.maximum - nhp.loglikelihood(proc, data)) < 1e-6 * abs(res.maximum)    # process holds the estimate
+    W = proc.weights.W
+    # rate = λ0 / (1 - excitation) roughly; with no true excitation the fitted weights are small
+    assert np.all(W < 0.1), W
+    assert np.all(np.abs(proc.baseline.λ / (1 - W.sum(axis=0)) - true) / true < 0.1), (proc.baseline.λ, W)
+    assert np.allclose(proc.impulses.θ.sum(axis=2), 1.0)
+    with pytest.raises(NotImplementedError):
+        nhp.mle_(proc, data, regularize=True)
