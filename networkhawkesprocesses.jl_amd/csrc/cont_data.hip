@@ -290,20 +290,20 @@ extern "C" nhp_status nhp_cont_model_update(nhp_ctx *ctx, nhp_cont_model *m, con
 extern "C" nhp_status nhp_cont_model_set_params(nhp_ctx *ctx, nhp_cont_model *m, const double *x, int64_t len)
 {
     if (!ctx || !m || !x) return NHP_EINVAL;
-    if (m->baseline_kind != NHP_BASELINE_HOMOGENEOUS) { nhp_set_error(ctx, "set_params: homogeneous baseline only"); return NHP_ENOTIMPL; }
     size_t N = (size_t)m->N, NN = N * N;
+    const size_t nb = m->baseline_kind == NHP_BASELINE_HOMOGENEOUS ? N : N * (size_t)m->grid_n;   // λ or vcat(λ...)
     size_t nimp = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? NN : 2 * NN;
-    if ((size_t)len != N + nimp + NN) {
+    if ((size_t)len != nb + nimp + NN) {
         nhp_set_error(ctx, "Parameter vector length does not match model parameter length.");
         return NHP_ESHAPE;
     }
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    NHP_HIP(ctx, hipMemcpyAsync(m->d_lambda0, x, sizeof(double) * N, hipMemcpyHostToDevice, st));
-    NHP_HIP(ctx, hipMemcpyAsync(m->d_p1, x + N, sizeof(double) * NN, hipMemcpyHostToDevice, st));
+    NHP_HIP(ctx, hipMemcpyAsync(m->d_lambda0, x, sizeof(double) * nb, hipMemcpyHostToDevice, st));
+    NHP_HIP(ctx, hipMemcpyAsync(m->d_p1, x + nb, sizeof(double) * NN, hipMemcpyHostToDevice, st));
     if (m->impulse_kind == NHP_IMPULSE_LOGITNORMAL)
-        NHP_HIP(ctx, hipMemcpyAsync(m->d_p2, x + N + NN, sizeof(double) * NN, hipMemcpyHostToDevice, st));
-    NHP_HIP(ctx, hipMemcpyAsync(m->d_W, x + N + nimp, sizeof(double) * NN, hipMemcpyHostToDevice, st));
+        NHP_HIP(ctx, hipMemcpyAsync(m->d_p2, x + nb + NN, sizeof(double) * NN, hipMemcpyHostToDevice, st));
+    NHP_HIP(ctx, hipMemcpyAsync(m->d_W, x + nb + nimp, sizeof(double) * NN, hipMemcpyHostToDevice, st));
     NHP_HIP(ctx, hipStreamSynchronize(st));
     return NHP_OK;
 }

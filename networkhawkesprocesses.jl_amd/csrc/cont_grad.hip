@@ -26,18 +26,64 @@ __device__ __forceinline__ double ggroup_sum(double v)
     return v;
 }
 
-// grad <- the parameter-independent terms: -T, 0, -cnt[p]·mask
+__device__ __forceinline__ double grad_baseline_at(const nhp_cont_args &a, int c, double t)
+{
+#pragma clang fp contract(off)
+    if (a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) return a.lambda0[c];
+    const double *x = a.grid;
+    const double *y = a.lambda0 + (size_t)c * a.grid_n;
+    int lo = 0, hi = a.grid_n - 1;
+    if (!(t < x[hi])) return y[hi];
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (t >= x[mid]) lo = mid; else hi = mid;
+    }
+    return (y[lo + 1] * (t - x[lo]) + y[lo] * (x[lo + 1] - t)) / (x[lo + 1] - x[lo]);
+}
+
+// params(baseline) is λ (N) or vcat(λ...) (N·G grid intensities of the LGCP): src/baselines.jl:41,173
+__device__ __forceinline__ size_t grad_nbase(const nhp_cont_args &a)
+{
+    return a.baseline_kind == NHP_BASELINE_HOMOGENEOUS ? (size_t)a.N : (size_t)a.N * (size_t)a.grid_n;
+}
+
+// ∂ log λ_i / ∂(grid intensities of node c) for an event at time t: g = 1/λ_i spread over the two grid
+// neighbours with the interpolation weights (src/utils/interpolation.jl:26-35)
+__device__ __forceinline__ void grad_lgcp_scatter(const nhp_cont_args &a, int c, double t, double g, double *grad)
+{
+    const double *x = a.grid;
+    const int G = a.grid_n;
+    double *gc = grad + (size_t)c * G;
+    int lo = 0, hi = G - 1;
+    if (!(t < x[hi])) { atomicAdd(&gc[hi], g); return; }
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (t >= x[mid]) lo = mid; else hi = mid;
+    }
+    const double w = x[lo + 1] - x[lo];
+    atomicAdd(&gc[lo], g * (x[lo + 1] - t) / w);
+    atomicAdd(&gc[lo + 1], g * (t - x[lo]) / w);
+}
+
+// grad <- the parameter-independent terms: -T (or minus the trapezoid weights), 0, -cnt[p]·mask
 __global__ __launch_bounds__(256) void k_grad_init(nhp_cont_args a, int mask_integral, double *__restrict__ grad)
 {
     const size_t N = (size_t)a.N, NN = N * N;
     const size_t nimp = a.impulse_kind == NHP_IMPULSE_EXPONENTIAL ? NN : 2 * NN;
-    const size_t P = N + nimp + NN;
+    const size_t nb = grad_nbase(a);
+    const size_t P = nb + nimp + NN;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x) {
         double v = 0.0;
-        if (i < N) {
-            v = -a.duration;
-        } else if (i >= N + nimp) {
-            const size_t k = i - N - nimp;
+        if (i < nb) {
+            if (a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) {
+                v = -a.duration;
+            } else {                                             // d/dy_g of the trapezoid rule (ignores duration)
+                const int g = (int)(i % (size_t)a.grid_n), G = a.grid_n;
+                const double left = g > 0 ? a.grid[g] - a.grid[g - 1] : 0.0, right = g + 1 < G ? a.grid[g + 1] - a.grid[g] : 0.0;
+                v = -0.5 * (left + right);
+            }
+        } else if (i >= nb + nimp) {
+            const size_t k = i - nb - nimp;
             const double mk = (a.A && mask_integral) ? a.A[k] : 1.0;
             v = -a.cnt[k % N] * mk;
         }
@@ -73,7 +119,10 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_grad_windowed(nhp_cont_args a, co
     for (int k = it.kbeg + gid; k < it.kend; k += GROUPS) {
         const nhp_child ch = a.child[k];
         const double g = 1.0 / lambda[ch.idx];
-        if (gl == 0) gsum += g;
+        if (gl == 0) {
+            if (a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) gsum += g;
+            else grad_lgcp_scatter(a, c, ch.t, g, grad);
+        }
         for (int j = ch.idx - 1 - gl; j >= ch.first; j -= G) {
             const double dt = ch.t - a.times[j];
             const int p = a.nodes[j];
@@ -96,7 +145,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_grad_windowed(nhp_cont_args a, co
         }
     }
     __syncthreads();
-    const size_t Nn = (size_t)N, NN = Nn * Nn;
+    const size_t Nn = grad_nbase(a), NN = (size_t)N * (size_t)N;      // Nn: offset of the impulse block
     const size_t nimp = IMP == NHP_IMPULSE_EXPONENTIAL ? NN : 2 * NN;
     for (int p = tid; p < N; p += NHP_BLOCK) {
         const size_t k = (size_t)p + (size_t)c * N;
@@ -111,7 +160,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_grad_windowed(nhp_cont_args a, co
         }
     }
     const double gs = nhp_block_sum(gsum, red);
-    if (tid == 0 && gs != 0.0) atomicAdd(&grad[c], gs);
+    if (tid == 0 && gs != 0.0 && a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) atomicAdd(&grad[c], gs);
 }
 
 // ---- recursive exponential: ll and gradient in one pass ---------------------------------------
@@ -139,7 +188,6 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_grad_recursive(nhp_cont_args a, d
     }
     __syncthreads();
     const int kb = a.boff[c], ke = a.boff[c + 1];
-    const double lam0 = a.lambda0[c];                            // homogeneous baseline only
     int prev_idx = 0;
     double prev_t = 0.0, logsum = 0.0, gsum = 0.0;
     for (int k = kb; k < ke; ++k) {
@@ -172,16 +220,20 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_grad_recursive(nhp_cont_args a, d
         part = nhp_wave_sum(part);
         if (lane == 0) wpart[wave] = part;
         __syncthreads();
-        double lam = lam0;
+        double lam = grad_baseline_at(a, c, ch.t);
         for (int w = 0; w < NHP_WAVES; ++w) lam += wpart[w];
         const double g = 1.0 / lam;
         for (int p = tid; p < N; p += NHP_BLOCK) { GS[p] += g * S[p]; GR[p] += g * R[p]; }
-        if (tid == 0) { logsum += nhp_log(lam); gsum += g; }
+        if (tid == 0) {
+            logsum += nhp_log(lam);
+            if (a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) gsum += g;
+            else grad_lgcp_scatter(a, c, ch.t, g, grad);
+        }
         prev_idx = ch.idx;
         prev_t = ch.t;
     }
     __syncthreads();
-    const size_t Nn = (size_t)N, NN = Nn * Nn;
+    const size_t Nn = grad_nbase(a), NN = (size_t)N * (size_t)N;
     for (int p = tid; p < N; p += NHP_BLOCK) {
         const size_t k = (size_t)p + (size_t)c * N;
         const double av = a.A ? a.A[k] : 1.0, w = a.W[k], t = th[p];
@@ -193,7 +245,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_grad_recursive(nhp_cont_args a, d
     if (tid == 0) {
         partials[2 * (size_t)c] = blk;
         partials[2 * (size_t)c + 1] = blk_int;
-        grad[c] = -a.duration + gsum;
+        if (a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) grad[c] = -a.duration + gsum;
     }
 }
 
@@ -222,10 +274,10 @@ extern "C" nhp_status nhp_cont_loglik_grad(nhp_ctx *ctx, const nhp_cont_dataset 
 {
     NHP_TRY(nhp_check_pair(ctx, ds, m));
     if (!ll || !grad) return NHP_EINVAL;
-    if (m->baseline_kind != NHP_BASELINE_HOMOGENEOUS) { nhp_set_error(ctx, "gradient: homogeneous baseline only"); return NHP_ENOTIMPL; }
     const size_t N = (size_t)ds->N, NN = N * N;
     const bool exp_imp = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
-    const size_t P = N + (exp_imp ? 2 : 3) * NN;
+    const bool lgcp = m->baseline_kind != NHP_BASELINE_HOMOGENEOUS;
+    const size_t P = (lgcp ? N * (size_t)m->grid_n : N) + (exp_imp ? 2 : 3) * NN;
     if ((size_t)grad_len != P) { nhp_set_error(ctx, "Parameter vector length does not match model parameter length."); return NHP_ESHAPE; }
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t M = (size_t)(ds->M > 0 ? ds->M : 1);
@@ -239,6 +291,10 @@ extern "C" nhp_status nhp_cont_loglik_grad(nhp_ctx *ctx, const nhp_cont_dataset 
         if (lds > 64 * 1024)
             NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_grad_recursive, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * N));
+        if (lgcp) {      // the grid-intensity block is accumulated with atomics: start it from the integral's derivative
+            hipLaunchKernelGGL(k_grad_init, dim3(1024), dim3(256), 0, st, a, 0, d_grad);
+            NHP_HIP(ctx, hipGetLastError());
+        }
         hipLaunchKernelGGL(k_grad_recursive, dim3((unsigned)N), dim3(NHP_BLOCK), lds, st, a, ctx->d_partials, d_grad);
         NHP_HIP(ctx, hipGetLastError());
         NHP_TRY(nhp_launch_finalize(ctx, a, (int)N, ctx->d_results));

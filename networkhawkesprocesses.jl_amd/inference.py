@@ -85,6 +85,8 @@ def mle_(process, data, optimizer="L-BFGS-B", verbose=False, f_abstol=1e-6, regu
     analytic gradient computed on the GPU, so iterates differ while the optimum is the same."""
     if not isinstance(process, ContinuousStandardHawkesProcess):
         raise TypeError("mle! is defined for ContinuousStandardHawkesProcess (src/continuous.jl:144)")
+    if regularize and not isinstance(process.baseline, HomogeneousProcess):
+        raise NotImplementedError("logprior is not defined for LogGaussianCoxProcess in the reference (src/baselines.jl)")
     ctx = ctx or _lib.default_context()
     ds = device_dataset(process, data, ctx)
     rng = np.random.default_rng(seed)

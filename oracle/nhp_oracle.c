@@ -514,21 +514,32 @@ int orc_cont_resample_adjacency(const orc_cont_model *m, const double *times, co
 int orc_cont_loglik_grad(const orc_cont_model *m, const double *times, const int64_t *nodes,
                          int64_t M, double duration, int recursive, double *ll_out, double *grad)
 {
-    if (m->baseline_kind != ORC_BASELINE_HOMOGENEOUS) return ORC_EINVAL;
     if (recursive && m->impulse_kind != ORC_IMPULSE_EXPONENTIAL) return ORC_EINVAL;
     int rc = validate_data(m, times, nodes, M);
     if (rc) return rc;
     int32_t N = m->n_nodes;
     size_t NN = (size_t)N * N;
     int lognorm = m->impulse_kind == ORC_IMPULSE_LOGITNORMAL;
-    size_t P = (size_t)N + NN * (lognorm ? 3 : 2);
+    const int lgcp = m->baseline_kind != ORC_BASELINE_HOMOGENEOUS;
+    const int32_t G = m->grid_n;
+    const size_t nb = lgcp ? (size_t)N * G : (size_t)N;            /* params(baseline): λ or vcat(λ...) */
+    size_t P = nb + NN * (lognorm ? 3 : 2);
     for (size_t k = 0; k < P; ++k) grad[k] = 0.0;
-    double *g0 = grad, *g1 = grad + N, *g2 = lognorm ? grad + N + NN : NULL;
-    double *gW = grad + N + NN * (lognorm ? 2 : 1);
+    double *g0 = grad, *g1 = grad + nb, *g2 = lognorm ? grad + nb + NN : NULL;
+    double *gW = grad + nb + NN * (lognorm ? 2 : 1);
     double ll;
     rc = integral_terms(m, nodes, M, duration, recursive ? 0 : 1, 0, &ll);
     if (rc) return rc;
-    for (int32_t c = 0; c < N; ++c) g0[c] = -duration;
+    if (!lgcp) {
+        for (int32_t c = 0; c < N; ++c) g0[c] = -duration;
+    } else {                                                       /* d/dy_g of the trapezoid rule */
+        const double *x = m->grid_x;
+        for (int32_t c = 0; c < N; ++c)
+            for (int32_t g = 0; g < G; ++g) {
+                double left = g > 0 ? x[g] - x[g - 1] : 0.0, right = g + 1 < G ? x[g + 1] - x[g] : 0.0;
+                g0[(size_t)c * G + g] = -0.5 * (left + right);
+            }
+    }
     for (int64_t i = 0; i < M; ++i) {
         int32_t p = (int32_t)(nodes[i] - 1);
         for (int32_t c = 0; c < N; ++c)
@@ -540,7 +551,9 @@ int orc_cont_loglik_grad(const orc_cont_model *m, const double *times, const int
     for (int64_t i = 0; i < M; ++i) {
         double t = times[i];
         int32_t c = (int32_t)(nodes[i] - 1);
-        double lam = m->lambda0[c];
+        double lam;
+        rc = orc_baseline_intensity(m, c + 1, t, &lam);
+        if (rc) { free(dW); free(d1); free(d2); return rc; }
         for (int32_t p = 0; p < N; ++p) { dW[p] = 0.0; d1[p] = 0.0; d2[p] = 0.0; }
         double thr = recursive ? -INFINITY : t - m->dt_max;
         for (int64_t j = i - 1; j >= 0 && times[j] > thr; --j) {
@@ -567,7 +580,19 @@ int orc_cont_loglik_grad(const orc_cont_model *m, const double *times, const int
         }
         ll += log(lam);
         double g = 1.0 / lam;
-        g0[c] += g;
+        if (!lgcp) {
+            g0[c] += g;
+        } else {                                                   /* interpolation weights of the two grid neighbours */
+            const double *x = m->grid_x;
+            int32_t lo = G - 1;
+            for (int32_t q = 0; q + 1 < G; ++q) if (t >= x[q] && t < x[q + 1]) { lo = q; break; }
+            if (lo == G - 1) {
+                g0[(size_t)c * G + G - 1] += g;
+            } else {
+                g0[(size_t)c * G + lo] += g * (x[lo + 1] - t) / (x[lo + 1] - x[lo]);
+                g0[(size_t)c * G + lo + 1] += g * (t - x[lo]) / (x[lo + 1] - x[lo]);
+            }
+        }
         for (int32_t p = 0; p < N; ++p) {
             size_t k = IDX(p, c, N);
             gW[k] += g * dW[p];

@@ -241,7 +241,8 @@ def lgcp_loglik(times, nodes, parentnodes, N, grid_x, lam):
 def loglik_grad(model, times, nodes, duration, recursive=False):
     t, n, tp, np_, M = _data(times, nodes)
     N = model.N
-    P = N + N * N * (2 if model.impulse_kind == EXPONENTIAL else 3)
+    nb = N if model.grid_x is None else N * len(model.grid_x)
+    P = nb + N * N * (2 if model.impulse_kind == EXPONENTIAL else 3)
     g = np.empty(P)
     out = C.c_double()
     _chk(lib().orc_cont_loglik_grad(C.byref(model.c), tp, np_, M, C.c_double(duration), int(recursive), C.byref(out), _p(g)))

@@ -180,3 +180,44 @@ def test_network_mcmc_recovers_structure(nhp):
     eff = A_mean * W_mean
     eff[0, 1] = 0.0
     assert eff.max() < 0.15
+
+
+@pytest.mark.parametrize("kind", ["exponential", "logitnormal"])
+def test_gradient_with_lgcp_baseline(nhp, orc, kind):
+    # params order [vcat(λ...); θ | μ; τ; W] (src/baselines.jl:173, src/continuous.jl:116-119): GPU vs oracle,
+    # and the oracle itself vs central differences of its log-likelihood
+    from helpers import random_case
+    c = random_case(4, 1500, 60.0, kind, 1.5, lgcp=True, seed=31, nhp=nhp, orc=orc)
+    proc, om = c["proc"], c["om"]
+    for rec in ((False, True) if kind == "exponential" else (False,)):
+        ll, g = nhp.loglikelihood_gradient(proc, c["data"], recursive=rec)
+        wll, wg = orc.loglik_grad(om, c["times"], c["nodes"], c["T"], recursive=rec)
+        assert len(g) == len(proc.params()) == len(wg)
+        assert abs(ll - wll) < 1e-10 * abs(wll)
+        assert np.max(np.abs(g - wg) / np.maximum(1.0, np.abs(wg))) < 1e-9
+    G = len(proc.baseline.x)
+    lam = np.vstack(proc.baseline.λ)
+    for (node, k) in ((0, 0), (1, 5), (3, G - 1), (2, 9)):
+        h = 1e-6
+        vals = []
+        for sgn in (+1, -1):
+            l2 = lam.copy()
+            l2[node, k] += sgn * h
+            m2 = orc.ContModel(l2, proc.weights.W, theta=getattr(proc.impulses, "θ", None), mu=getattr(proc.impulses, "μ", None),
+                               tau=getattr(proc.impulses, "τ", None), dt_max=1.5, grid_x=proc.baseline.x)
+            vals.append(orc.loglik_windowed(m2, c["times"], c["nodes"], c["T"]))
+        fd = (vals[0] - vals[1]) / (2 * h)
+        _, wg = orc.loglik_grad(om, c["times"], c["nodes"], c["T"], recursive=False)
+        assert abs(wg[node * G + k] - fd) < 1e-5 * max(1.0, abs(fd))
+
+
+def test_mle_with_lgcp_baseline_improves_the_likelihood(nhp):
+    # examples/continuous-logit-normal-standard-hawkes-gp.jl:38 runs mle! on an LGCP-baseline process
+    from helpers import random_case
+    c = random_case(3, 1200, 40.0, "exponential", 1.0, lgcp=True, seed=5, nhp=nhp)
+    proc = c["proc"]
+    ll0 = nhp.loglikelihood(proc, c["data"])
+    res = nhp.mle_(proc, c["data"], guess=np.clip(proc.params(), 1e-3, 5.0), max_steps=60)
+    assert res.maximum > ll0
+    assert abs(nhp.loglikelihood(proc, c["data"]) - res.maximum) < 1e-8 * abs(res.maximum)
+    assert len(res.maximizer) == len(proc.params())
