@@ -74,3 +74,8 @@ def resample_(process, data, *args, **kwargs):
         return _disc.disc_resample_(process, data, *args, **kwargs)
     return _inf.resample_(process, data, *args, **kwargs)
 
+
+
+def isstable(process):
+    """isstable(process): spectral radius of (A .*) W below one -- src/continuous.jl:58, src/discrete.jl:172,404"""
+    return process.isstable()
