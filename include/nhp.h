@@ -254,6 +254,17 @@ nhp_status nhp_disc_resample_adjacency(nhp_ctx *ctx, const nhp_disc_dataset *ds,
                                        const double *W, const double *theta, double *A, double dt,
                                        const double *rho_matrix, double rho, const double *u,
                                        uint64_t seed, uint64_t step, double *n_links);
+/* DiscreteLogGaussianCoxProcess(x, λ, Σ, m, dt) as this dataset's baseline (src/baselines.jl:461-509): lam
+ * [grid_n * N] (λ[:, n] at n*grid_n) on grid_x [grid_n].  The per-bin baseline intensity(p, 1:T)
+ * (src/discrete.jl:117, src/baselines.jl:531-537) is built on the device and kept with the dataset; the other
+ * nhp_disc_* calls use it when their lambda0 argument is NULL (nhp_disc_loglik_grad then returns the gradient
+ * in [vec(λ) (grid_n*N); vec(W .* θ)] order).  NHP_EDOMAIN if a bin time 1..T lies outside the grid. */
+nhp_status nhp_disc_set_lgcp_baseline(nhp_ctx *ctx, nhp_disc_dataset *ds, const double *grid_x, int32_t grid_n,
+                                      const double *lam, double dt);
+/* loglikelihood(p::DiscreteLogGaussianCoxProcess, data, node, y)  src/baselines.jl:571-584 for all nodes:
+ * data = parents[:, :, 1] of the latest nhp_disc_resample_parents on this dataset (kept on the device),
+ * cand [grid_n * N] = exp.(m .+ y) per node -- the body of every elliptical_slice round (:640-679). */
+nhp_status nhp_disc_lgcp_loglik(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *cand, double dt, double *ll);
 /* n_steps consecutive update! steps of vb! (src/inference.jl:153-181) with the variational parameters
  * resident on the device in between (one upload, one download) */
 nhp_status nhp_disc_vb_run(nhp_ctx *ctx, const nhp_disc_dataset *ds, double dt,

@@ -15,7 +15,7 @@ from .continuous import (ContinuousHawkesProcess, ContinuousNetworkHawkesProcess
                          total_intensity)
 from . import continuous as _cont
 from .discrete import (DiscreteDataset, DiscreteGaussianImpulseResponse, DiscreteHawkesProcess,  # noqa: F401
-                       DiscreteHomogeneousProcess, DiscreteNetworkHawkesProcess,
+                       DiscreteHomogeneousProcess, DiscreteLogGaussianCoxProcess, DiscreteNetworkHawkesProcess,
                        DiscreteStandardHawkesProcess, VariationalInference, convolve, disc_parent_counts,
                        disc_resample_adjacency_matrix_,
                        resample_parent_counts, update_, vb_)

@@ -78,6 +78,8 @@ def _declare(lib):
     f("nhp_cont_gibbs_step", i32, _vp, _vp, _vp, C.POINTER(GibbsPriors), u64, u64)
     f("nhp_cont_model_get_params", i32, _vp, _vp, _dp, i64)
     f("nhp_cont_lgcp_loglik", i32, _vp, _vp, _ip, _dp, i32, _dp, _dp)
+    f("nhp_disc_set_lgcp_baseline", i32, _vp, _vp, _dp, i32, _dp, dbl)
+    f("nhp_disc_lgcp_loglik", i32, _vp, _vp, _dp, dbl, _dp)
     f("nhp_disc_loglik_grad", i32, _vp, _vp, _dp, _dp, _dp, dbl, _dp, _dp, i64)
     f("nhp_disc_resample_parents", i32, _vp, _vp, _dp, _dp, _dp, _dp, dbl, u64, u64, _ip)
     f("nhp_disc_resample_adjacency", i32, _vp, _vp, _dp, _dp, _dp, _dp, dbl, _dp, dbl, _dp, u64, u64, _dp)

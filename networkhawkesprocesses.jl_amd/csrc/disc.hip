@@ -41,6 +41,7 @@ struct gemm_args {
     int k_chunk;              // reduction elements per grid.z slice
     // epilogue operands
     const double *base;       // [N]   additive per-column term (λ0·dt or e0)
+    const double *baseT;      // [M x N] additive per-element term (time-varying baseline); overrides base if non-null
     const double *dataT;      // [M x N] counts as f64, t fastest
     double *out;              // EPI_INTENSITY: λ [M x N]; EPI_VB_Z: R [M x N]; EPI_SLAB: slabs [z][M x N]
     double *partials;         // EPI_LOGLIK: [2 * blocks]; EPI_VB_Z: column partials [rowBlocks][N]
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = n0 + wn * 64 + j * 16 + r16;
-        const double base = (EPI != EPI_SLAB && col < g.N) ? g.base[col] : 0.0;
+        const double base_c = (EPI != EPI_SLAB && col < g.N && !g.baseT) ? g.base[col] : 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
                 if (row < g.M && col < g.N) {
                     const size_t o = (size_t)row + (size_t)col * g.M;
                     const double v = acc[i][j][r];
+                    const double base = (EPI != EPI_SLAB && g.baseT) ? g.baseT[o] : base_c;
                     if (EPI == EPI_INTENSITY) {
                         g.out[o] = base + v;
                     } else if (EPI == EPI_LOGLIK) {
@@ -503,7 +505,7 @@ extern "C" void nhp_disc_dataset_destroy(nhp_disc_dataset *ds)
     (void)hipStreamSynchronize(ds->ctx->stream);
     (void)hipFree(ds->d_dataT); (void)hipFree(ds->d_conv); (void)hipFree(ds->d_colsum);
     (void)hipFree(ds->d_occ_t); (void)hipFree(ds->d_occ_c); (void)hipFree(ds->d_occ_s); (void)hipFree(ds->d_occ_off);
-    (void)hipFree(ds->d_convsum);
+    (void)hipFree(ds->d_convsum); (void)hipFree(ds->d_baseT); (void)hipFree(ds->d_base_counts);
     delete ds;
 }
 
@@ -554,7 +556,8 @@ static nhp_status stage_bump(nhp_ctx *ctx, const nhp_disc_dataset *ds, const dou
                              double **extra_ptr, int cat_order = 0)
 {
     if (!ds->d_conv) { nhp_set_error(ctx, "convolve(process, data) must run before intensity / loglikelihood"); return NHP_EINVAL; }
-    if (!lambda0 || !W || !theta) return NHP_EINVAL;
+    if (!W || !theta) return NHP_EINVAL;
+    if (!lambda0 && !ds->d_baseT) { nhp_set_error(ctx, "lambda0 is NULL and the dataset has no LGCP baseline (nhp_disc_set_lgcp_baseline)"); return NHP_EINVAL; }
     const size_t N = (size_t)ds->N, NN = N * N, B = (size_t)ds->B, K = N * B;
     const size_t need = 8 * (K * N + N + N + NN + NN * B + NN + extra);
     NHP_TRY(nhp_ctx_reserve_scratch(ctx, need));
@@ -567,7 +570,8 @@ static nhp_status stage_bump(nhp_ctx *ctx, const nhp_disc_dataset *ds, const dou
     double *dA = p; p += NN;
     *extra_ptr = p;
     hipStream_t st = ctx->stream;
-    NHP_HIP(ctx, hipMemcpyAsync(dl0, lambda0, 8 * N, hipMemcpyHostToDevice, st));
+    if (lambda0) NHP_HIP(ctx, hipMemcpyAsync(dl0, lambda0, 8 * N, hipMemcpyHostToDevice, st));
+    else NHP_HIP(ctx, hipMemsetAsync(dl0, 0, 8 * N, st));          // per-bin baseline comes from ds->d_baseT
     NHP_HIP(ctx, hipMemcpyAsync(dW, W, 8 * NN, hipMemcpyHostToDevice, st));
     NHP_HIP(ctx, hipMemcpyAsync(dth, theta, 8 * NN * B, hipMemcpyHostToDevice, st));
     if (A) NHP_HIP(ctx, hipMemcpyAsync(dA, A, 8 * NN, hipMemcpyHostToDevice, st));
@@ -590,7 +594,7 @@ extern "C" nhp_status nhp_disc_intensity(nhp_ctx *ctx, const nhp_disc_dataset *d
     gemm_args g{};
     g.A = ds->d_conv; g.lda = (size_t)ds->T; g.B = E; g.ldb = (size_t)ds->N * ds->B;
     g.M = (int)ds->T; g.N = ds->N; g.K = ds->N * ds->B; g.k_chunk = g.K;
-    g.base = base; g.out = dlam;
+    g.base = base; g.baseT = lambda0 ? nullptr : ds->d_baseT; g.out = dlam;
     launch_gemm<true, EPI_INTENSITY>(g, 1, ctx->stream);
     NHP_HIP(ctx, hipGetLastError());
     NHP_HIP(ctx, hipMemcpyAsync(lam, dlam, 8 * TN, hipMemcpyDeviceToHost, ctx->stream));
@@ -608,7 +612,7 @@ extern "C" nhp_status nhp_disc_loglik(nhp_ctx *ctx, const nhp_disc_dataset *ds, 
     gemm_args g{};
     g.A = ds->d_conv; g.lda = (size_t)ds->T; g.B = E; g.ldb = (size_t)ds->N * ds->B;
     g.M = (int)ds->T; g.N = ds->N; g.K = ds->N * ds->B; g.k_chunk = g.K;
-    g.base = base; g.dataT = ds->d_dataT;
+    g.base = base; g.baseT = lambda0 ? nullptr : ds->d_baseT; g.dataT = ds->d_dataT;
     const int blocks = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)blocks));
     g.partials = ctx->d_partials;
@@ -617,6 +621,74 @@ extern "C" nhp_status nhp_disc_loglik(nhp_ctx *ctx, const nhp_disc_dataset *ds, 
     hipLaunchKernelGGL(k_sum_pairs, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, blocks, ds->lgamma_sum, ctx->d_results);
     NHP_HIP(ctx, hipGetLastError());
     return nhp_ctx_fetch(ctx, 0, 1, ll);
+}
+
+// ---- DiscreteLogGaussianCoxProcess baseline (reference src/baselines.jl:461-609).  intensity(p, ts) is the
+// piecewise-linear interpolation of (x, λ[:, n]·dt); the process intensity evaluates it at ts = 1..T
+// (src/discrete.jl:117), the baseline's own likelihood at range(p) = x[1] : dt : x[end]-dt (:553-584).
+__device__ __forceinline__ void disc_interp_cell(const double *x, int G, double t, int *lo, double *wlo, double *whi)
+{
+    // src/utils/interpolation.jl:26-35: x0 in [x[i], x[i+1]) -> cell i; x0 >= x[end] -> last value
+    int a = 0, b = G - 1;
+    if (!(t < x[b])) { *lo = b; *wlo = 1.0; *whi = 0.0; return; }
+    while (b - a > 1) { const int mid = (a + b) >> 1; if (t >= x[mid]) a = mid; else b = mid; }
+    const double w = x[a + 1] - x[a];
+    *lo = a; *wlo = (x[a + 1] - t) / w; *whi = (t - x[a]) / w;
+}
+
+// baseT[t + T·c] = interp(x, lam[:, c]·dt)(t + 1)
+__global__ __launch_bounds__(256) void k_disc_base_interp(const double *__restrict__ x, int G, const double *__restrict__ lam,
+                                                          double dt, int64_t T, double *__restrict__ baseT)
+{
+#pragma clang fp contract(off)
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (t >= T) return;
+    const double time = (double)(t + 1);
+    const double *y = lam + (size_t)c * G;
+    int lo; double wlo, whi;
+    disc_interp_cell(x, G, time, &lo, &wlo, &whi);
+    double v;
+    if (lo == G - 1) v = y[G - 1] * dt;
+    else v = ((y[lo + 1] * dt) * (time - x[lo]) + (y[lo] * dt) * (x[lo + 1] - time)) / (x[lo + 1] - x[lo]);
+    baseT[(size_t)t + (size_t)T * c] = v;
+}
+
+// grad[g + G·c] += dt Σ_t (R[t,c] - 1) w_g(t + 1)
+__global__ __launch_bounds__(256) void k_disc_grad_lgcp(const double *__restrict__ R, int64_t T, int G, const double *__restrict__ x,
+                                                        double dt, double *__restrict__ grad)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (t >= T) return;
+    const double r = (R[(size_t)t + (size_t)T * c] - 1.0) * dt;
+    int lo; double wlo, whi;
+    disc_interp_cell(x, G, (double)(t + 1), &lo, &wlo, &whi);
+    atomicAdd(&grad[(size_t)c * G + lo], r * wlo);
+    if (whi != 0.0) atomicAdd(&grad[(size_t)c * G + lo + 1], r * whi);
+}
+
+// ll[c] = Σ_t log pdf(Poisson(λ_t), s0[t,c]),  λ_t = interp(x, cand[:, c]·dt)(x[0] + t·dt)   (src/baselines.jl:571-584)
+__global__ __launch_bounds__(256) void k_disc_lgcp_ll(const int *__restrict__ s0, int64_t T, int G, const double *__restrict__ x,
+                                                      const double *__restrict__ cand, double dt, double *__restrict__ ll)
+{
+#pragma clang fp contract(off)
+    __shared__ double red[NHP_WAVES];
+    const int c = blockIdx.x;
+    const double *y = cand + (size_t)c * G;
+    double acc = 0.0;
+    for (int64_t t = threadIdx.x; t < T; t += 256) {
+        const double time = x[0] + (double)t * dt;
+        int lo; double wlo, whi;
+        disc_interp_cell(x, G, time, &lo, &wlo, &whi);
+        double lam;
+        if (lo == G - 1) lam = y[G - 1] * dt;
+        else lam = ((y[lo + 1] * dt) * (time - x[lo]) + (y[lo] * dt) * (x[lo + 1] - time)) / (x[lo + 1] - x[lo]);
+        const double s = (double)s0[(size_t)t + (size_t)T * c];
+        acc += (s == 0.0 ? 0.0 : s * nhp_log(lam)) - lam - lgamma(s + 1.0);
+    }
+    acc = nhp_block_sum(acc, red);
+    if (threadIdx.x == 0) ll[c] = acc;
 }
 
 // ---- gradient of the discrete log-likelihood in the reference's mle! parameters [λ0; η = W∘θ]
@@ -651,7 +723,9 @@ extern "C" nhp_status nhp_disc_loglik_grad(nhp_ctx *ctx, const nhp_disc_dataset 
     if (!ctx || !ds || !ll || !grad) return NHP_EINVAL;
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t N = (size_t)ds->N, NN = N * N, B = (size_t)ds->B, K = N * B, T = (size_t)ds->T;
-    if ((size_t)grad_len != N + NN * B) { nhp_set_error(ctx, "Parameter vector length does not match model parameter length."); return NHP_ESHAPE; }
+    const size_t G = lambda0 ? 0 : ds->h_grid_x.size();
+    const size_t nbase = lambda0 ? N : G * N;                    // params(baseline): λ or vec(λ) (G x N)
+    if ((size_t)grad_len != nbase + NN * B) { nhp_set_error(ctx, "Parameter vector length does not match model parameter length."); return NHP_ESHAPE; }
     if (!ds->d_convsum) { nhp_set_error(ctx, "convolve(process, data) must run before the gradient"); return NHP_EINVAL; }
     const int row_blocks = (int)((T + BM - 1) / BM);
     const int tiles2 = (int)(((K + BM - 1) / BM) * ((N + BN - 1) / BN));
@@ -661,7 +735,7 @@ extern "C" nhp_status nhp_disc_loglik_grad(nhp_ctx *ctx, const nhp_disc_dataset 
     k_chunk = ((k_chunk + BK - 1) / BK) * BK;
     splits = (int)((T + k_chunk - 1) / k_chunk);
     double *E, *base, *x;
-    NHP_TRY(stage_bump(ctx, ds, lambda0, W, theta, nullptr, dt, &E, &base, T * N + (size_t)row_blocks * N + (size_t)splits * K * N + N + NN * B, &x));
+    NHP_TRY(stage_bump(ctx, ds, lambda0, W, theta, nullptr, dt, &E, &base, T * N + (size_t)row_blocks * N + (size_t)splits * K * N + nbase + NN * B + G, &x));
     double *dR = x; x += T * N;
     double *dcolp = x; x += (size_t)row_blocks * N;
     double *dslab = x; x += (size_t)splits * K * N;
@@ -670,7 +744,7 @@ extern "C" nhp_status nhp_disc_loglik_grad(nhp_ctx *ctx, const nhp_disc_dataset 
     // ll: GEMM-1 with the Poisson epilogue
     gemm_args g{};
     g.A = ds->d_conv; g.lda = T; g.B = E; g.ldb = K; g.M = (int)T; g.N = (int)N; g.K = (int)K; g.k_chunk = (int)K;
-    g.base = base; g.dataT = ds->d_dataT;
+    g.base = base; g.baseT = lambda0 ? nullptr : ds->d_baseT; g.dataT = ds->d_dataT;
     const int blocks = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)blocks));
     g.partials = ctx->d_partials;
@@ -685,9 +759,18 @@ extern "C" nhp_status nhp_disc_loglik_grad(nhp_ctx *ctx, const nhp_disc_dataset 
     g2.out = dslab;
     launch_gemm<false, EPI_SLAB>(g2, splits, st);
     hipLaunchKernelGGL(k_disc_grad_finish, dim3((unsigned)((NN * B + 255) / 256)), dim3(256), 0, st, (int)N, (int)B, splits, row_blocks,
-                       dt, (double)T, dslab, dcolp, ds->d_convsum, dgrad);
+                       dt, (double)T, dslab, dcolp, ds->d_convsum, dgrad + (nbase - N));
+    if (!lambda0) {
+        // LGCP: ∂λ_base[t,c]/∂λgrid[g,c] = dt·w_g(t) (interpolation weights at bin time t+1), so the baseline block
+        // is dt Σ_t (R - 1)[t,c] w_g -- it overwrites the N homogeneous entries k_disc_grad_finish left at its end
+        double *dgx = dgrad + nbase + NN * B;
+        NHP_HIP(ctx, hipMemcpyAsync(dgx, ds->h_grid_x.data(), 8 * G, hipMemcpyHostToDevice, st));
+        NHP_HIP(ctx, hipMemsetAsync(dgrad, 0, 8 * nbase, st));
+        hipLaunchKernelGGL(k_disc_grad_lgcp, dim3((unsigned)((T + 255) / 256), (unsigned)N), dim3(256), 0, st, dR, (int64_t)T, (int)G,
+                           dgx, dt, dgrad);
+    }
     NHP_HIP(ctx, hipGetLastError());
-    NHP_HIP(ctx, hipMemcpyAsync(grad, dgrad, 8 * (N + NN * B), hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipMemcpyAsync(grad, dgrad, 8 * (nbase + NN * B), hipMemcpyDeviceToHost, st));
     return nhp_ctx_fetch(ctx, 0, 1, ll);
 }
 
@@ -793,8 +876,9 @@ __device__ __attribute__((noinline)) double rp_next_u(double u_prev, int remaini
 
 __global__ __launch_bounds__(256, 3) void k_disc_resample_parents(const double *__restrict__ dataT, const double *__restrict__ conv,
                                                                const double *__restrict__ E2, const double *__restrict__ base,
-                                                               int64_t T, int N, int B, unsigned b_magic, uint64_t seed,
-                                                               uint64_t step, int *__restrict__ counts)
+                                                               const double *__restrict__ baseT, int64_t T, int N, int B,
+                                                               unsigned b_magic, uint64_t seed, uint64_t step,
+                                                               int *__restrict__ counts, int *__restrict__ base_counts)
 {
 #pragma clang fp contract(off)
     __shared__ unsigned short list[RP_TT * RP_CT];
@@ -884,7 +968,7 @@ __global__ __launch_bounds__(256, 3) void k_disc_resample_parents(const double *
             tl[s] = e / RP_CT; cl[s] = e % RP_CT;
             n[s] = idx < nbins ? (int)dataT[(size_t)(t0 + tl[s]) + (size_t)T * (c0 + cl[s])] : 0;
             j[s] = 0;
-            cum[s] = n[s] > 0 ? base[c0 + cl[s]] : 0.0;
+            cum[s] = n[s] > 0 ? (baseT ? baseT[(size_t)(t0 + tl[s]) + (size_t)T * (c0 + cl[s])] : base[c0 + cl[s]]) : 0.0;
             total[s] = 0.0; thr[s] = 0.0; u[s] = 0.0;
         }
         // ---- walk 1: row totals
@@ -909,9 +993,10 @@ __global__ __launch_bounds__(256, 3) void k_disc_resample_parents(const double *
                 const uint64_t bin = (uint64_t)(t0 + tl[s]) + (uint64_t)T * (uint64_t)c;
                 u[s] = rp_next_u(0.0, n[s], seed, step, bin, 0);
                 thr[s] = u[s] * total[s];
-                cum[s] = base[c];
+                cum[s] = baseT ? baseT[(size_t)(t0 + tl[s]) + (size_t)T * c] : base[c];
                 while (j[s] < n[s] && cum[s] > thr[s]) {
                     atomicAdd(&counts[c], 1);
+                    if (base_counts) atomicAdd(&base_counts[(size_t)(t0 + tl[s]) + (size_t)T * c], 1);
                     if (++j[s] < n[s]) { u[s] = rp_next_u(u[s], n[s] - j[s], seed, step, bin, j[s]); thr[s] = u[s] * total[s]; }
                 }
             }
@@ -960,8 +1045,10 @@ extern "C" nhp_status nhp_disc_resample_parents(nhp_ctx *ctx, const nhp_disc_dat
     if (ds->T >= ((int64_t)1 << 31) || K >= ((size_t)1 << 24)) { nhp_set_error(ctx, "resample_parents: T or N*B too large"); return NHP_ENOTIMPL; }
     // q / B for q < 2^24 as a multiply-high: exact with magic = floor(2^32 / B) + 1 while q·B < 2^32
     const unsigned b_magic = (unsigned)((((uint64_t)1 << 32) / (uint64_t)ds->B + 1) & 0xFFFFFFFFu);   // unused for B = 1
-    hipLaunchKernelGGL(k_disc_resample_parents, grid, dim3(256), 0, st, ds->d_dataT, ds->d_conv, E2, base, ds->T, ds->N, ds->B,
-                       b_magic, seed, step, d_counts);
+    if (ds->d_base_counts) NHP_HIP(ctx, hipMemsetAsync(ds->d_base_counts, 0, sizeof(int) * (size_t)ds->T * N, st));
+    hipLaunchKernelGGL(k_disc_resample_parents, grid, dim3(256), 0, st, ds->d_dataT, ds->d_conv, E2, base,
+                       lambda0 ? nullptr : ds->d_baseT, ds->T, ds->N, ds->B, b_magic, seed, step, d_counts, ds->d_base_counts);
+    if (ds->d_base_counts) const_cast<nhp_disc_dataset *>(ds)->base_counts_valid = true;
     NHP_HIP(ctx, hipGetLastError());
     std::vector<int> h((size_t)NC);
     NHP_HIP(ctx, hipMemcpyAsync(h.data(), d_counts, sizeof(int) * NC, hipMemcpyDeviceToHost, st));
@@ -1120,7 +1207,7 @@ extern "C" nhp_status nhp_disc_resample_adjacency(nhp_ctx *ctx, const nhp_disc_d
     gemm_args g{};
     g.A = ds->d_conv; g.lda = (size_t)ds->T; g.B = E; g.ldb = N * B;
     g.M = (int)ds->T; g.N = ds->N; g.K = (int)(N * B); g.k_chunk = g.K;
-    g.base = base; g.out = dlam;
+    g.base = base; g.baseT = lambda0 ? nullptr : ds->d_baseT; g.out = dlam;
     launch_gemm<true, EPI_INTENSITY>(g, 1, st);
     NHP_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_dadj_gather, dim3((unsigned)((nocc + 255) / 256)), dim3(256), 0, st, dlam, ds->d_occ_t, ds->d_occ_c,
@@ -1139,6 +1226,58 @@ extern "C" nhp_status nhp_disc_resample_adjacency(nhp_ctx *ctx, const nhp_disc_d
     NHP_HIP(ctx, hipMemcpyAsync(A, dA, 8 * NN, hipMemcpyDeviceToHost, st));
     NHP_HIP(ctx, hipStreamSynchronize(st));
     if (n_links) { double s = 0.0; for (size_t i = 0; i < NN; ++i) s += A[i]; *n_links = s; }
+    return NHP_OK;
+}
+
+// DiscreteLogGaussianCoxProcess(x, λ, Σ, m, dt) as the baseline of this dataset's process (src/baselines.jl:461-509):
+// builds the per-bin baseline intensity on the device; later calls that pass lambda0 = NULL use it.
+extern "C" nhp_status nhp_disc_set_lgcp_baseline(nhp_ctx *ctx, nhp_disc_dataset *ds, const double *grid_x, int32_t grid_n,
+                                                 const double *lam, double dt)
+{
+    if (!ctx || !ds || !grid_x || !lam || grid_n < 2) return NHP_EINVAL;
+    for (int g = 0; g + 1 < grid_n; ++g)
+        if (!(grid_x[g + 1] > grid_x[g])) { nhp_set_error(ctx, "grid points must be strictly increasing"); return NHP_EDOMAIN; }
+    // the interpolator throws outside [x[1], x[end]] (src/utils/interpolation.jl:27); bins are evaluated at 1..T
+    if (grid_x[0] > 1.0 || grid_x[grid_n - 1] < (double)ds->T) {
+        nhp_set_error(ctx, "bin times 1..%lld fall outside the grid support [%g, %g]", (long long)ds->T, grid_x[0], grid_x[grid_n - 1]);
+        return NHP_EDOMAIN;
+    }
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t N = (size_t)ds->N, T = (size_t)ds->T, G = (size_t)grid_n;
+    if (!ds->d_baseT && hipMalloc(&ds->d_baseT, 8 * T * N) != hipSuccess) { nhp_set_error(ctx, "out of device memory (baseline matrix)"); return NHP_ENOMEM; }
+    if (!ds->d_base_counts && hipMalloc(&ds->d_base_counts, 4 * T * N) != hipSuccess) { nhp_set_error(ctx, "out of device memory (baseline counts)"); return NHP_ENOMEM; }
+    ds->h_grid_x.assign(grid_x, grid_x + grid_n);
+    NHP_TRY(nhp_ctx_reserve_scratch(ctx, 8 * (G + G * N)));
+    double *dx = (double *)ctx->d_scratch, *dl = dx + G;
+    hipStream_t st = ctx->stream;
+    NHP_HIP(ctx, hipMemcpyAsync(dx, grid_x, 8 * G, hipMemcpyHostToDevice, st));
+    NHP_HIP(ctx, hipMemcpyAsync(dl, lam, 8 * G * N, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_disc_base_interp, dim3((unsigned)((T + 255) / 256), (unsigned)N), dim3(256), 0, st, dx, grid_n, dl, dt, ds->T, ds->d_baseT);
+    NHP_HIP(ctx, hipGetLastError());
+    NHP_HIP(ctx, hipStreamSynchronize(st));
+    return NHP_OK;
+}
+
+// loglikelihood(p::DiscreteLogGaussianCoxProcess, data, node, y) for all nodes (src/baselines.jl:571-584), data =
+// the per-bin baseline counts parents[:, :, 1] of the latest nhp_disc_resample_parents on this dataset; cand [G*N]
+// holds exp.(m .+ y) per node.
+extern "C" nhp_status nhp_disc_lgcp_loglik(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *cand, double dt, double *ll)
+{
+    if (!ctx || !ds || !cand || !ll) return NHP_EINVAL;
+    if (!ds->d_base_counts || !ds->base_counts_valid) { nhp_set_error(ctx, "lgcp_loglik: run resample_parents with the LGCP baseline first"); return NHP_EINVAL; }
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t N = (size_t)ds->N, G = ds->h_grid_x.size();
+    // range(p) = x[1] : dt : x[end] - dt must have T points inside the support
+    if (ds->h_grid_x[0] + (double)(ds->T - 1) * dt > ds->h_grid_x[G - 1]) { nhp_set_error(ctx, "lgcp_loglik: bins fall outside the grid support"); return NHP_EDOMAIN; }
+    NHP_TRY(nhp_ctx_reserve_scratch(ctx, 8 * (G + G * N + N)));
+    double *dx = (double *)ctx->d_scratch, *dc = dx + G, *dll = dc + G * N;
+    hipStream_t st = ctx->stream;
+    NHP_HIP(ctx, hipMemcpyAsync(dx, ds->h_grid_x.data(), 8 * G, hipMemcpyHostToDevice, st));
+    NHP_HIP(ctx, hipMemcpyAsync(dc, cand, 8 * G * N, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_disc_lgcp_ll, dim3((unsigned)N), dim3(256), 0, st, ds->d_base_counts, ds->T, (int)G, dx, dc, dt, dll);
+    NHP_HIP(ctx, hipGetLastError());
+    NHP_HIP(ctx, hipMemcpyAsync(ll, dll, 8 * N, hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipStreamSynchronize(st));
     return NHP_OK;
 }
 

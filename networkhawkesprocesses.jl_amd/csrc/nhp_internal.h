@@ -123,6 +123,11 @@ struct nhp_disc_dataset {
     double *d_occ_s = nullptr;                        // [nocc] the count
     int32_t *d_occ_off = nullptr;                     // [ntiles + 1] first occupied bin of each DA_TT-bin tile
     double *d_convsum = nullptr;                      // [N*B] Σ_t Ŝ[t, p, b] (filled with the convolution)
+    // time-varying baseline of a DiscreteLogGaussianCoxProcess (nhp_disc_set_lgcp_baseline); used when a call passes lambda0 = NULL
+    double *d_baseT = nullptr;                        // [T*N] baseline intensity per bin, t fastest
+    int32_t *d_base_counts = nullptr;                 // [T*N] events attributed to the baseline by the latest parent sweep
+    bool base_counts_valid = false;
+    std::vector<double> h_grid_x;                     // the LGCP grid [G]
 };
 
 // ---- error plumbing -------------------------------------------------------------------

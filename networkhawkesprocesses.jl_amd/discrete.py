@@ -100,6 +100,112 @@ class DiscreteHomogeneousProcess(DiscreteBaseline):
         return self.αv.copy(), self.βv.copy()
 
 
+class DiscreteLogGaussianCoxProcess(DiscreteBaseline):
+    """DiscreteLogGaussianCoxProcess(x, λ, Σ | kernel, m, dt) -- src/baselines.jl:461-509: λ is G x N
+    (λ[i, n] = λ_n(x[i])), intensity = linear interpolation of (x, λ[:, n]·dt)."""
+
+    def __init__(self, x, λ, Σ, m, dt):
+        from .components import Kernel
+        x = np.asarray(x, dtype=np.float64)
+        if isinstance(Σ, Kernel):
+            if x[0] != 0.0:
+                raise ValueError("Grid points must start at 0.")            # src/baselines.jl:493
+            Σ = Σ(x)
+        self.x = x
+        self.λ = np.array(λ, dtype=np.float64)
+        if self.λ.ndim != 2 or self.λ.shape[0] != len(x):
+            raise ValueError("λ must be a (grid points) x (nodes) matrix")
+        self.Σ = None if Σ is None else np.asarray(Σ, dtype=np.float64)
+        self.m, self.dt = float(m), float(dt)
+
+    @classmethod
+    def from_gp(cls, gp, m, T, n, k, dt, rng):
+        """DiscreteLogGaussianCoxProcess(gp, m, T, n, k, dt) -- src/baselines.jl:497-505"""
+        if T % n != 0:
+            raise ValueError("Duration must be divisible by number of steps.")
+        x = np.linspace(0.0, T, n + 1)
+        Σ = gp.cov(x)
+        return cls(x, np.column_stack([np.exp(m + gp.rand(x, rng, sigma=Σ)) for _ in range(k)]), Σ, m, dt)
+
+    def ndims(self):
+        return self.λ.shape[1]
+
+    def range(self):
+        """range(p) = x[1] : dt : x[end] - dt  -- src/baselines.jl:509"""
+        return self.x[0] + self.dt * np.arange(self.nsteps())
+
+    def nsteps(self):
+        return int(np.floor((self.x[-1] - self.dt - self.x[0]) / self.dt + 1e-9)) + 1
+
+    def params(self):
+        return self.λ.ravel(order="F").copy()
+
+    def params_(self, x):
+        """params!: src/baselines.jl:514-520"""
+        if len(x) != self.λ.size:
+            raise ValueError("Parameter vector length does not match model parameter length.")
+        self.λ = np.asarray(x, dtype=np.float64).reshape(self.λ.shape, order="F").copy()
+
+    def intensity(self, *args):
+        """intensity(p, times) -> len(times) x N, intensity(p, node, times): src/baselines.jl:523-541
+        (piecewise-linear through (x, λ[:, n]·dt); DomainError outside the grid, last value at x[end])"""
+        if len(args) == 2:
+            node, ts = args
+            return self.intensity(ts)[:, node - 1] if np.ndim(ts) else self.intensity(np.array([ts]))[0, node - 1]
+        ts = np.atleast_1d(np.asarray(args[0], dtype=np.float64))
+        if np.any(ts < self.x[0]) or np.any(ts > self.x[-1]):
+            raise DomainError("Value is outside interpolation support")
+        return np.column_stack([np.interp(ts, self.x, self.λ[:, n] * self.dt) for n in range(self.ndims())])
+
+    def integrated_intensity(self, duration=None):
+        """src/baselines.jl:543"""
+        return self.intensity(self.range()).sum(axis=0)
+
+    def attach(self, ds):
+        """Put intensity(p, 1:T) on the device with the dataset (calls then pass lambda0 = NULL)."""
+        lam = np.asfortranarray(self.λ).ravel(order="K")
+        _lib.check(_lib.lib().nhp_disc_set_lgcp_baseline(ds.ctx.h, ds.h, _lib.dptr(self.x), len(self.x), _lib.dptr(lam), self.dt),
+                   ds.ctx.h)
+
+    def candidate_loglikelihood(self, ds, Y):
+        """loglikelihood(p, data, node, y) (src/baselines.jl:571-584) of latent curves Y [G, N], one per node, in
+        one GPU call, on the baseline counts parents[:, :, 1] the latest parent sweep left on the device."""
+        cand = np.asfortranarray(np.exp(self.m + np.asarray(Y, dtype=np.float64))).ravel(order="K")
+        out = np.empty(self.ndims())
+        _lib.check(_lib.lib().nhp_disc_lgcp_loglik(ds.ctx.h, ds.h, _lib.dptr(cand), self.dt, _lib.dptr(out)), ds.ctx.h)
+        return out
+
+    def resample_(self, ds, rng, max_attempts=100):
+        """resample!(process, parents; sampler=elliptical_slice) -- src/baselines.jl:589-609,640-679; the N slice
+        loops advance in lock step, one GPU likelihood call per round (as for the continuous LGCP)."""
+        if self.Σ is None:
+            raise ValueError("DiscreteLogGaussianCoxProcess needs Σ to be resampled")
+        G, N = self.λ.shape
+        L = np.linalg.cholesky(self.Σ)
+        Y = np.log(self.λ) - self.m
+        V = L @ rng.standard_normal((G, N))
+        lly = self.candidate_loglikelihood(ds, Y) + np.log(rng.uniform(size=N))
+        θ = 2 * np.pi * rng.uniform(size=N)
+        θmin, θmax = θ - 2 * np.pi, θ.copy()
+        Ynew = Y * np.cos(θ)[None, :] + V * np.sin(θ)[None, :]
+        done = self.candidate_loglikelihood(ds, Ynew) >= lly
+        attempts = 1
+        while not done.all():
+            if attempts >= max_attempts:
+                raise RuntimeError("Elliptical slice sampling reached maximum attempts.")
+            attempts += 1
+            todo = ~done
+            neg = θ < 0.0
+            θmin = np.where(todo & neg, θ, θmin)
+            θmax = np.where(todo & ~neg, θ, θmax)
+            θ = np.where(todo, θmin + (θmax - θmin) * rng.uniform(size=N), θ)
+            cand = Y * np.cos(θ)[None, :] + V * np.sin(θ)[None, :]
+            Ynew = np.where(todo[None, :], cand, Ynew)
+            done = done | (todo & (self.candidate_loglikelihood(ds, Ynew) >= lly))
+        self.λ = np.exp(self.m + Ynew)
+        return self.λ.copy()
+
+
 class DiscreteImpulseResponse:
     pass
 
@@ -163,7 +269,8 @@ class DiscreteHawkesProcess(HawkesProcess):
 
     def _lowered(self):
         A = getattr(self, "adjacency_matrix", None)
-        return (_lib.f64(self.baseline.λ), _lib.colmajor(self.weights.W), _lib.colmajor(self.impulses.θ),
+        l0 = None if isinstance(self.baseline, DiscreteLogGaussianCoxProcess) else _lib.f64(self.baseline.λ)
+        return (l0, _lib.colmajor(self.weights.W), _lib.colmajor(self.impulses.θ),
                 None if A is None else _lib.colmajor(A))
 
 
@@ -222,9 +329,10 @@ def convolve(process, data, ctx=None, fetch=False):
 
 
 def _convolved(process, data, convolved, ctx):
-    if convolved is not None:
-        return convolved
-    return convolve(process, data, ctx)
+    ds = convolved if convolved is not None else convolve(process, data, ctx)
+    if isinstance(process.baseline, DiscreteLogGaussianCoxProcess):
+        process.baseline.attach(ds)           # intensity(baseline, 1:T) follows the current grid values
+    return ds
 
 
 def disc_intensity(process, data=None, convolved=None, ctx=None):
@@ -255,7 +363,7 @@ def disc_loglikelihood_gradient(process, data=None, convolved=None, ctx=None):
     ctx = ctx or _lib.default_context()
     ds = _convolved(process, data, convolved, ctx)
     l0, W, th, _ = process._lowered()
-    P = ds.N + ds.N * ds.N * ds.B
+    P = len(process.baseline.params()) + ds.N * ds.N * ds.B
     g = np.empty(P)
     ll = C.c_double()
     _lib.check(_lib.lib().nhp_disc_loglik_grad(ctx.h, ds.h, _lib.dptr(l0), _lib.dptr(W), _lib.dptr(th), process.dt,
@@ -267,11 +375,15 @@ def disc_params_(process, x):
     """params!(process::DiscreteStandardHawkesProcess, x): x = [λ0; vec(W .* θ)], W = Σ_b η, θ = η ./ W
     -- src/discrete.jl:183-201"""
     N, B = process.ndims(), process.impulses.nbasis()
-    if len(x) != N + N * N * B:
+    nb = len(process.baseline.params())
+    if len(x) != nb + N * N * B:
         raise ValueError("Parameter vector length does not match model parameter length.")
-    η = np.asarray(x[N:], dtype=np.float64).reshape((N, N, B), order="F")
+    η = np.asarray(x[nb:], dtype=np.float64).reshape((N, N, B), order="F")
     W = η.sum(axis=2)
-    process.baseline.λ = np.array(x[:N], dtype=np.float64)
+    if isinstance(process.baseline, DiscreteLogGaussianCoxProcess):
+        process.baseline.params_(x[:nb])
+    else:
+        process.baseline.λ = np.array(x[:nb], dtype=np.float64)
     process.weights.W = np.asfortranarray(W)
     process.impulses.θ = np.asfortranarray(η / W[:, :, None])
     return process.params()
@@ -299,8 +411,9 @@ def disc_mle_(process, data, optimizer="L-BFGS-B", verbose=False, f_abstol=1e-6,
     if guess is None:                                    # _rand_init_: src/discrete.jl:346-360
         for _ in range(100):
             x0 = rng.uniform(size=len(process.params()))
-            x0[N:] /= 10
-            W0 = x0[N:].reshape((N, N, -1), order="F").sum(axis=2)
+            nb = len(process.baseline.params())
+            x0[nb:] /= 10
+            W0 = x0[nb:].reshape((N, N, -1), order="F").sum(axis=2)
             if np.max(np.abs(np.linalg.eigvals(W0))) < 1.0:
                 break
         else:
@@ -394,7 +507,10 @@ def disc_resample_(process, data, convolved, rng, seed=0, step=0, ctx=None):
     N, B = ds.N, ds.B
     counts = resample_parent_counts(process, convolved=ds, seed=seed, step=step, ctx=ctx)
     b, w, imp = process.baseline, process.weights, process.impulses
-    b.λ = rng.gamma(b.α0 + counts[:, 0], 1.0 / (b.β0 + ds.T * b.dt))
+    if isinstance(b, DiscreteLogGaussianCoxProcess):
+        b.resample_(ds, rng)              # elliptical slice on parents[:, :, 1], left on the device by the sweep above
+    else:
+        b.λ = rng.gamma(b.α0 + counts[:, 0], 1.0 / (b.β0 + ds.T * b.dt))
     Mnm = disc_parent_counts(counts, N, B)
     w.W = rng.gamma(w.κ + Mnm, 1.0 / (w.ν + ds.node_counts)[:, None] * np.ones((N, N)))        # src/weights.jl:59-64
     γ = imp.γ + counts[:, 1:].reshape((N, N, B)).transpose(1, 0, 2)                                  # [parent, child, basis]
@@ -434,6 +550,8 @@ def update_(process, data, convolved, ctx=None, n_steps=1):
     if not isinstance(process, DiscreteStandardHawkesProcess) or not isinstance(process.weights, DenseWeightModel):
         raise NotImplementedError("VB exists only for DiscreteStandardHawkesProcess + DenseWeightModel "
                                   "(the reference's network / sparse variants are broken: SURVEY D6)")
+    if not isinstance(process.baseline, DiscreteHomogeneousProcess):
+        raise NotImplementedError("update! is defined for DiscreteHomogeneousProcess baselines only (src/baselines.jl:444-456)")
     ctx = ctx or _lib.default_context()
     ds = _convolved(process, data, convolved, ctx)
     b, w, imp = process.baseline, process.weights, process.impulses

@@ -652,12 +652,13 @@ void orc_disc_convolve(const int64_t *data, int32_t N, int64_t T, const double *
 
 /* intensity(process, convolved): src/discrete.jl:115-129; bump :381-385 (w*θ*dt) and
  * :511-516 (a*w*θ*dt); baseline src/baselines.jl:402-405 (λ .* dt). */
-void orc_disc_intensity(const double *conv, int64_t T, int32_t N, int32_t B, const double *lambda0,
-                        const double *W, const double *theta, const double *A, double dt, double *lam)
+void orc_disc_intensity_b(const double *conv, int64_t T, int32_t N, int32_t B, const double *lambda0,
+                          const double *base_tn, const double *W, const double *theta, const double *A, double dt,
+                          double *lam)
 {
     for (int64_t t = 0; t < T; ++t)
         for (int32_t c = 0; c < N; ++c) {
-            double v = lambda0[c] * dt;
+            double v = base_tn ? base_tn[(size_t)t + (size_t)c * T] : lambda0[c] * dt;
             for (int32_t p = 0; p < N; ++p)
                 for (int32_t b = 0; b < B; ++b) {
                     double shat = conv[(size_t)t + (size_t)p * T + (size_t)b * T * N];
@@ -668,6 +669,30 @@ void orc_disc_intensity(const double *conv, int64_t T, int32_t N, int32_t B, con
                 }
             lam[(size_t)t + (size_t)c * T] = v;
         }
+}
+
+void orc_disc_intensity(const double *conv, int64_t T, int32_t N, int32_t B, const double *lambda0,
+                        const double *W, const double *theta, const double *A, double dt, double *lam)
+{
+    orc_disc_intensity_b(conv, T, N, B, lambda0, NULL, W, theta, A, dt, lam);
+}
+
+/* intensity(p::DiscreteLogGaussianCoxProcess, times): src/baselines.jl:531-537 -- column n is the linear
+ * interpolation of (x, λ[:, n] * dt); lam is G x N column-major; out[i + n*ntimes]. */
+int orc_disc_lgcp_intensity(const double *x, int32_t G, const double *lam, int32_t N, double dt,
+                            const double *times, int64_t ntimes, double *out)
+{
+    double *y = (double *)malloc(sizeof(double) * (size_t)G);
+    if (!y) return ORC_ENOMEM;
+    for (int32_t n = 0; n < N; ++n) {
+        for (int32_t g = 0; g < G; ++g) y[g] = lam[(size_t)g + (size_t)n * G] * dt;
+        for (int64_t i = 0; i < ntimes; ++i) {
+            int rc = orc_linear_interpolate(x, y, G, times[i], &out[(size_t)i + (size_t)n * ntimes]);
+            if (rc) { free(y); return rc; }
+        }
+    }
+    free(y);
+    return ORC_OK;
 }
 
 /* loglikelihood(process, data, convolved): src/discrete.jl:91-102.
@@ -807,12 +832,14 @@ static double disc_next_u(double u_prev, int64_t remaining, uint64_t seed, uint6
     return u_prev + (1.0 - u_prev) * w;
 }
 
-int orc_disc_resample_parents(const int64_t *data, const double *conv, int64_t T, int32_t N, int32_t B,
-                              const double *lambda0, const double *W, const double *theta, const double *A,
-                              double dt, uint64_t seed, uint64_t step, int64_t *counts)
+int orc_disc_resample_parents_b(const int64_t *data, const double *conv, int64_t T, int32_t N, int32_t B,
+                                const double *lambda0, const double *base_tn, const double *W, const double *theta,
+                                const double *A, double dt, uint64_t seed, uint64_t step, int64_t *counts,
+                                int64_t *base_counts /* nullable: [T*N] parents[t, c, 1] */)
 {
     const int64_t K = (int64_t)N * B;
     for (int64_t i = 0; i < (int64_t)N * (1 + K); ++i) counts[i] = 0;
+    if (base_counts) for (int64_t i = 0; i < T * N; ++i) base_counts[i] = 0;
     double *bump = (double *)malloc(sizeof(double) * (size_t)K);
     if (!bump) return ORC_ENOMEM;
     for (int32_t c = 0; c < N; ++c) {
@@ -824,7 +851,7 @@ int orc_disc_resample_parents(const int64_t *data, const double *conv, int64_t T
         for (int64_t t = 0; t < T; ++t) {
             const int64_t n = data[c + (size_t)t * N];
             if (n <= 0) continue;
-            const double base = lambda0[c] * dt;
+            const double base = base_tn ? base_tn[(size_t)t + (size_t)c * T] : lambda0[c] * dt;
             double total = base;
             for (int32_t p = 0; p < N; ++p)
                 for (int32_t b = 0; b < B; ++b)
@@ -835,6 +862,7 @@ int orc_disc_resample_parents(const int64_t *data, const double *conv, int64_t T
             double cum = base;
             while (j < n && cum > thr) {
                 counts[c] += 1;
+                if (base_counts) base_counts[(size_t)t + (size_t)c * T] += 1;
                 if (++j < n) { u = disc_next_u(u, n - j, seed, step, bin, j); thr = u * total; }
             }
             for (int32_t p = 0; p < N && j < n; ++p)
@@ -849,6 +877,38 @@ int orc_disc_resample_parents(const int64_t *data, const double *conv, int64_t T
         }
     }
     free(bump);
+    return ORC_OK;
+}
+
+int orc_disc_resample_parents(const int64_t *data, const double *conv, int64_t T, int32_t N, int32_t B,
+                              const double *lambda0, const double *W, const double *theta, const double *A,
+                              double dt, uint64_t seed, uint64_t step, int64_t *counts)
+{
+    return orc_disc_resample_parents_b(data, conv, T, N, B, lambda0, NULL, W, theta, A, dt, seed, step, counts, NULL);
+}
+
+/* loglikelihood(p::DiscreteLogGaussianCoxProcess, data, node, y) for every node: src/baselines.jl:571-584.
+ * s0 [T*N] (t fastest) = the baseline-attributed counts; cand [G*N] = exp.(m .+ y) per node;
+ * times = range(p) = x[1] : dt : x[end] - dt. */
+int orc_disc_lgcp_loglik(const int64_t *s0, int64_t T, int32_t N, const double *x, int32_t G, const double *cand,
+                         double dt, double *ll)
+{
+    double *y = (double *)malloc(sizeof(double) * (size_t)G);
+    if (!y) return ORC_ENOMEM;
+    for (int32_t n = 0; n < N; ++n) {
+        for (int32_t g = 0; g < G; ++g) y[g] = cand[(size_t)g + (size_t)n * G] * dt;
+        double acc = 0.0;
+        for (int64_t t = 0; t < T; ++t) {
+            double lam;
+            int rc = orc_linear_interpolate(x, y, G, x[0] + (double)t * dt, &lam);
+            if (rc) { free(y); return rc; }
+            double sd = (double)s0[(size_t)t + (size_t)n * T];
+            double xlogy = (sd == 0.0) ? 0.0 : sd * log(lam);
+            acc += log(exp(xlogy - lam - lgamma(sd + 1.0)));
+        }
+        ll[n] = acc;
+    }
+    free(y);
     return ORC_OK;
 }
 

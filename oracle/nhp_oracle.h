@@ -99,6 +99,19 @@ int orc_disc_resample_parents(const int64_t *data, const double *conv, int64_t T
                               const double *lambda0, const double *W, const double *theta, const double *A,
                               double dt, uint64_t seed, uint64_t step, int64_t *counts);
 
+/* ---- DiscreteLogGaussianCoxProcess baseline (src/baselines.jl:461-609) */
+void orc_disc_intensity_b(const double *conv, int64_t T, int32_t N, int32_t B, const double *lambda0,
+                          const double *base_tn, const double *W, const double *theta, const double *A, double dt,
+                          double *lam);
+int orc_disc_lgcp_intensity(const double *x, int32_t G, const double *lam, int32_t N, double dt,
+                            const double *times, int64_t ntimes, double *out);
+int orc_disc_resample_parents_b(const int64_t *data, const double *conv, int64_t T, int32_t N, int32_t B,
+                                const double *lambda0, const double *base_tn, const double *W, const double *theta,
+                                const double *A, double dt, uint64_t seed, uint64_t step, int64_t *counts,
+                                int64_t *base_counts);
+int orc_disc_lgcp_loglik(const int64_t *s0, int64_t T, int32_t N, const double *x, int32_t G, const double *cand,
+                         double dt, double *ll);
+
 /* ---- discrete adjacency Gibbs sweep (src/discrete.jl:424-480), literal; A [N*N] in place */
 int orc_disc_resample_adjacency(const int64_t *data, const double *conv, int64_t T, int32_t N, int32_t B,
                                 const double *lambda0, const double *W, const double *theta, double dt,

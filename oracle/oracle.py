@@ -291,6 +291,53 @@ def disc_resample_parents(data, conv, lambda0, W, theta, dt=1.0, A=None, seed=0,
     return out.reshape((N, 1 + N * B), order="F")
 
 
+def disc_lgcp_intensity(x, lam, dt, times):
+    """intensity(p::DiscreteLogGaussianCoxProcess, times) -> len(times) x N; lam is G x N."""
+    lam = np.asarray(lam, dtype=np.float64)
+    G, N = lam.shape
+    tt = _f(times)
+    out = np.empty(len(tt) * N)
+    _chk(lib().orc_disc_lgcp_intensity(_p(_f(x)), C.c_int32(G), _p(_col(lam)), C.c_int32(N), C.c_double(dt), _p(tt),
+                                       C.c_int64(len(tt)), _p(out)))
+    return out.reshape((len(tt), N), order="F")
+
+
+def disc_intensity_b(conv, base_tn, W, theta, dt=1.0, A=None):
+    """Process intensity with a per-bin baseline base_tn (T x N)."""
+    T, N, B = conv.shape
+    cv = np.asfortranarray(conv).ravel(order="K")
+    out = np.empty(T * N)
+    lib().orc_disc_intensity_b(_p(cv), C.c_int64(T), C.c_int32(N), C.c_int32(B), None, _p(_col(base_tn)), _p(_col(W)),
+                               _p(_col(theta)), _p(_col(A)), C.c_double(dt), _p(out))
+    return out.reshape((T, N), order="F")
+
+
+def disc_resample_parents_b(data, conv, base_tn, W, theta, dt=1.0, A=None, seed=0, step=0):
+    """Parent counts with a per-bin baseline; returns (counts [N, 1+NB], baseline counts per bin [T, N])."""
+    data = np.asarray(data, dtype=np.int64)
+    T, N, B = conv.shape
+    d = np.asfortranarray(data).ravel(order="K")
+    cv = np.asfortranarray(conv).ravel(order="K")
+    out = np.empty(N * (1 + N * B), dtype=np.int64)
+    bc = np.empty(T * N, dtype=np.int64)
+    _chk(lib().orc_disc_resample_parents_b(d.ctypes.data_as(_ip), _p(cv), C.c_int64(T), C.c_int32(N), C.c_int32(B), None,
+                                           _p(_col(base_tn)), _p(_col(W)), _p(_col(theta)), _p(_col(A)), C.c_double(dt),
+                                           C.c_uint64(seed), C.c_uint64(step), out.ctypes.data_as(_ip), bc.ctypes.data_as(_ip)))
+    return out.reshape((N, 1 + N * B), order="F"), bc.reshape((T, N), order="F")
+
+
+def disc_lgcp_loglik(s0, x, cand, dt):
+    """ll[n] of baseline counts s0 (T x N) under candidate grid intensities cand (G x N)."""
+    s0 = np.asarray(s0, dtype=np.int64)
+    T, N = s0.shape
+    cand = np.asarray(cand, dtype=np.float64)
+    s = np.asfortranarray(s0).ravel(order="K")
+    out = np.empty(N)
+    _chk(lib().orc_disc_lgcp_loglik(s.ctypes.data_as(_ip), C.c_int64(T), C.c_int32(N), _p(_f(x)), C.c_int32(cand.shape[0]),
+                                    _p(_col(cand)), C.c_double(dt), _p(out)))
+    return out
+
+
 def disc_resample_adjacency(data, conv, lambda0, W, theta, A, rho, u, dt=1.0):
     """One sweep of the discrete resample_adjacency_matrix!; rho, u, A: N x N indexed [parent, child]."""
     data = np.asarray(data, dtype=np.int64)

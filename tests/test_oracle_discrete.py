@@ -138,3 +138,32 @@ def test_discrete_adjacency_sweep_limits(orc):
     got = orc.disc_resample_adjacency(data2, conv2, np.full(2, 0.01), np.full((2, 2), 2.0), th2, np.zeros((2, 2)), 0.5,
                                       np.full((2, 2), 0.999), 1.0)
     assert got[0, 1] == 1.0
+
+
+def test_discrete_lgcp_baseline_pieces(orc, nhp):
+    # intensity(p::DiscreteLogGaussianCoxProcess, times) = interpolation of (x, λ[:, n]·dt): src/baselines.jl:531-537;
+    # its likelihood on range(p): :571-584 -- vs numpy / scipy
+    from scipy.special import gammaln
+    rng = np.random.default_rng(6)
+    G, N, T, dt = 9, 3, 64, 0.5
+    x = np.linspace(0.0, T * dt, G)
+    lam = np.exp(rng.normal(0, 0.5, (G, N)))
+    times = np.arange(1, 17, dtype=np.float64)
+    got = orc.disc_lgcp_intensity(x, lam, dt, times)
+    want = np.column_stack([np.interp(times, x, lam[:, n] * dt) for n in range(N)])
+    assert np.allclose(got, want, rtol=1e-14)
+    with pytest.raises(Exception):
+        orc.disc_lgcp_intensity(x, lam, dt, np.array([T * dt + 1.0]))            # outside the support: DomainError
+    s0 = rng.poisson(0.7, (T, N))
+    ll = orc.disc_lgcp_loglik(s0, x, lam, dt)
+    ts = x[0] + dt * np.arange(T)
+    for n in range(N):
+        l = np.interp(ts, x, lam[:, n] * dt)
+        assert np.isclose(ll[n], np.sum(s0[:, n] * np.log(l) - l - gammaln(s0[:, n] + 1.0)), rtol=1e-12)
+    b = nhp.DiscreteLogGaussianCoxProcess(x, lam, nhp.SquaredExponentialKernel(1.0, 4.0), 0.0, dt)
+    assert b.ndims() == N and b.nsteps() == T and np.allclose(b.range(), ts)
+    assert np.allclose(b.intensity(times), want) and np.isclose(b.intensity(2, 3.0), want[2, 1])
+    v = b.params()
+    b.params_(2 * v)
+    assert np.allclose(b.params(), 2 * v)
+    assert np.allclose(b.integrated_intensity(), b.intensity(ts).sum(axis=0))
