@@ -130,6 +130,17 @@ struct nhp_disc_dataset {
     std::vector<double> h_grid_x;                     // the LGCP grid [G]
 };
 
+#define NHP_DA_TT 128    // bins per workgroup tile of the discrete adjacency sweep (also the granularity of d_occ_off)
+
+// disc.hip pieces shared with disc_gibbs.hip: upload W, θ, A (and λ0) and build the bump table E [N·B x N] on the device
+// (GEMM order k = p + b·N, or the reference's category order p·B + b with cat_order) plus base[c] = λ0[c]·dt; `extra`
+// doubles of scratch follow at *extra_ptr.  Layout after E: base (N) | λ0 (N) | W (N²) | θ (N²B) | A (N²) | extra.
+nhp_status nhp_disc_stage_bump(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0, const double *W,
+                               const double *theta, const double *A, double dt, double **E, double **base, size_t extra,
+                               double **extra_ptr, int cat_order = 0);
+nhp_status nhp_disc_launch_intensity(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *E, const double *base,
+                                     bool per_bin_baseline, double *dlam);
+
 // ---- error plumbing -------------------------------------------------------------------
 void nhp_set_error(nhp_ctx *ctx, const char *fmt, ...);
 #define NHP_HIP(ctx, call)                                                                   \
