@@ -221,3 +221,20 @@ def test_mle_with_lgcp_baseline_improves_the_likelihood(nhp):
     assert res.maximum > ll0
     assert abs(nhp.loglikelihood(proc, c["data"]) - res.maximum) < 1e-8 * abs(res.maximum)
     assert len(res.maximizer) == len(proc.params())
+
+
+def test_gibbs_entry_points_on_empty_data(nhp):
+    # zero events: the sweep must still run (statistics all zero, adjacency decided by the prior alone)
+    N = 3
+    proc = nhp.ContinuousNetworkHawkesProcess(nhp.HomogeneousProcess(np.ones(N)),
+                                              nhp.ExponentialImpulseResponse(np.ones((N, N)), 1.0, 1.0, 1.0),
+                                              nhp.DenseWeightModel(np.full((N, N), 0.2)), np.ones((N, N)),
+                                              nhp.BernoulliNetworkModel(0.4, N))
+    data = (np.array([]), np.array([], dtype=np.int64), 5.0)
+    p, pn, st = nhp.resample_parents(proc, data, with_stats=True)
+    assert len(p) == 0 and not st["Mnm"].any() and not st["cnt0"].any()
+    u = np.random.default_rng(1).uniform(size=(N, N))
+    nhp.resample_adjacency_matrix_(proc, data, u=u)
+    assert np.array_equal(proc.adjacency_matrix, (u <= 0.4).astype(float))
+    res = nhp.mcmc_(proc, data, nsteps=3, seed=0)
+    assert res.steps == 3 and all(np.all(np.isfinite(s)) for s in res.samples)

@@ -109,3 +109,26 @@ def test_network_counts_respect_the_mask_and_mcmc_runs(nhp, orc):
     assert res.steps == 8 and all(np.all(np.isfinite(s)) for s in res.samples)
     assert set(np.unique(proc.adjacency_matrix)) <= {0.0, 1.0}
     assert 0.0 < proc.network.ρ < 1.0
+
+
+def test_empty_and_tiny_data(nhp, orc):
+    # no events at all; a single occupied bin; one node
+    N, T, B, L = 3, 50, 2, 4
+    proc, _ = make_network(nhp, N, T, B, L, 0.5, seed=1)
+    zero = np.zeros((N, T), dtype=np.int64)
+    ds = nhp.convolve(proc, zero)
+    assert not nhp.resample_parent_counts(proc, convolved=ds, seed=1, step=0).any()
+    u = np.random.default_rng(0).uniform(size=(N, N))
+    nhp.disc_resample_adjacency_matrix_(proc, convolved=ds, u=u)
+    assert np.array_equal(proc.adjacency_matrix, (u <= 0.3).astype(float))          # no data: the prior decides
+    one = zero.copy()
+    one[1, 7] = 4
+    ds1, conv1 = nhp.convolve(proc, one, fetch=True)
+    got = nhp.resample_parent_counts(proc, convolved=ds1, seed=1, step=0)
+    want = orc.disc_resample_parents(one, conv1, proc.baseline.λ, proc.weights.W, proc.impulses.θ, proc.dt,
+                                     A=proc.adjacency_matrix, seed=1, step=0)
+    assert np.array_equal(got, want) and got.sum() == 4
+    p1, d1 = make(nhp, 1, 300, 2, 4, 0.8, seed=2)
+    dsa, conva = nhp.convolve(p1, d1, fetch=True)
+    assert np.array_equal(nhp.resample_parent_counts(p1, convolved=dsa, seed=2, step=3),
+                          orc.disc_resample_parents(d1, conva, p1.baseline.λ, p1.weights.W, p1.impulses.θ, p1.dt, seed=2, step=3))
