@@ -203,6 +203,10 @@ nhp_status nhp_probe_math(nhp_ctx *ctx, int32_t op, const double *x, const doubl
 /* throughput calibration on register operands: mode 0 = exponential pair terms per second (the
  * fp64-VALU ceiling of the windowed kernels), mode 1 = fp64 fma per second */
 nhp_status nhp_probe_rate(nhp_ctx *ctx, int32_t mode, int32_t iters, int32_t blocks, double *ops_per_s);
+/* gather calibration: n_windows scattered windows of `recs` 16-byte records out of an array of array_recs records,
+ * 8 lanes per window, no arithmetic -- microseconds per launch (the floor of the short-window kernels) */
+nhp_status nhp_probe_gather(nhp_ctx *ctx, int32_t n_windows, int32_t recs, int64_t array_recs, int32_t blocks,
+                            double *us_per_launch);
 
 /* ---- discrete data: N x T counts  src/discrete.jl:18,80 -------------------------------- */
 nhp_status nhp_disc_dataset_create(nhp_ctx *ctx, const int64_t *data, int32_t n_nodes, int64_t n_bins,

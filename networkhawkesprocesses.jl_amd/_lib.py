@@ -86,6 +86,7 @@ def _declare(lib):
     f("nhp_cont_resample_adjacency", i32, _vp, _vp, _vp, _dp, dbl, _dp, u64, u64, _dp, _dp)
     f("nhp_probe_math", i32, _vp, i32, _dp, _dp, i64, _dp)
     f("nhp_probe_rate", i32, _vp, i32, i32, i32, _dp)
+    f("nhp_probe_gather", i32, _vp, i32, i32, i64, i32, _dp)
     for name, args in (
         ("nhp_cont_loglik_grad", (_vp, _vp, _vp, i32, _dp, _dp, i64)),
         ("nhp_cont_intensity", (_vp, _vp, _vp, _dp, i64, _dp)),

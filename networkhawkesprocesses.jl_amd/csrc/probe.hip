@@ -80,3 +80,50 @@ extern "C" nhp_status nhp_probe_rate(nhp_ctx *ctx, int32_t mode, int32_t iters, 
     *ops_per_s = (double)blocks * 256.0 * (double)iters / ((double)ms * 1e-3);
     return NHP_OK;
 }
+
+// Gather calibration for the short-window regime: `n_windows` windows of `recs` consecutive
+// 16-byte records at pseudo-random positions of an `array_recs`-record array, 8 lanes per window and four
+// windows per lane group in flight -- the windowed kernel's access pattern with the arithmetic removed
+// (one add per record).  Reports microseconds per launch.
+__global__ __launch_bounds__(256) void k_probe_gather(const double2 *__restrict__ arr, unsigned array_recs, int recs,
+                                                      int n_windows, double *__restrict__ sink)
+{
+    const int gid = (blockIdx.x * 256 + threadIdx.x) >> 3, gl = threadIdx.x & 7, ngroups = (gridDim.x * 256) >> 3;
+    double acc = 0.0;
+    for (int w0 = gid * 4; w0 < n_windows; w0 += ngroups * 4) {
+        double2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            unsigned h = (unsigned)(w0 + u) * 2654435761u;               // Knuth hash: a scattered start per window
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            const unsigned start = h % (array_recs - (unsigned)recs);
+            v[u] = make_double2(0.0, 0.0);
+            for (int r = gl; r < recs; r += 8) { const double2 q = arr[start + r]; v[u].x += q.x; v[u].y += q.y; }
+        }
+        acc += (v[0].x + v[1].x) + (v[2].x + v[3].x) + (v[0].y + v[1].y) + (v[2].y + v[3].y);
+    }
+    if (acc == 12345.678) sink[0] = acc;                                // keep the loads alive
+}
+
+extern "C" nhp_status nhp_probe_gather(nhp_ctx *ctx, int32_t n_windows, int32_t recs, int64_t array_recs, int32_t blocks,
+                                       double *us_per_launch)
+{
+    if (!ctx || !us_per_launch || n_windows < 1 || recs < 1 || array_recs <= recs || blocks < 1) return NHP_EINVAL;
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    NHP_TRY(nhp_ctx_reserve_scratch(ctx, 16 * (size_t)array_recs + 64));
+    double2 *arr = (double2 *)ctx->d_scratch;
+    double *sink = (double *)(arr + array_recs);
+    NHP_HIP(ctx, hipMemsetAsync(arr, 0, 16 * (size_t)array_recs, ctx->stream));
+    const int reps = 20;
+    hipLaunchKernelGGL(k_probe_gather, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, arr, (unsigned)array_recs, recs, n_windows, sink);
+    NHP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL(k_probe_gather, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, arr, (unsigned)array_recs, recs, n_windows, sink);
+    NHP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    NHP_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    NHP_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *us_per_launch = 1e3 * (double)ms / reps;
+    return NHP_OK;
+}
+
