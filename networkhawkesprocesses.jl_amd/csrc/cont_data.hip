@@ -98,14 +98,16 @@ extern "C" nhp_status nhp_cont_dataset_create(nhp_ctx *ctx, const double *events
     const char *env = getenv("NHP_CHUNK");
     if (env && atoi(env) > 0) chunk = std::min(atoi(env), 4096);
     std::vector<nhp_item> items;
-    // XCD-aware layout (NHP_XCD=TP, TP in {2,4}; off by default until it wins): workgroups are dealt
-    // round-robin over the 8 XCDs, so item b runs on XCD b % 8.  Giving XCD x = s*(8/TP) + g the
-    // children of time part s on the nodes with c % (8/TP) == g makes every XCD touch only 1/TP of
-    // the event array (its 4 MiB L2 no longer streams all 16 MB) at the price of staging each
-    // column TP times.  Speed heuristic only: any placement gives the same result.
+    // XCD-aware layout: workgroups are dealt round-robin over the 8 XCDs, so item b runs on XCD b % 8.
+    // Giving XCD x = s*(8/TP) + g the children of time part s on the nodes with c % (8/TP) == g makes
+    // every XCD touch only 1/TP of the event array (its 4 MiB L2 no longer streams all of it) at the
+    // price of staging each column TP times.  That price decides: at mean window 8 the staging eats the
+    // gain (tools/xcd.sh), at 64 two time parts win 6 %, at 512 four win 12 % (profiles/README.md).
+    // NHP_XCD = 0 | 2 | 4 | 8 overrides.  Speed heuristic only: any placement gives the same result.
     const char *xenv = getenv("NHP_XCD");
-    const int TP = xenv ? atoi(xenv) : 0;
-    if ((TP == 2 || TP == 4) && N >= 8 && M >= 16 * (int64_t)N) {
+    const double kbar = M > 0 ? (double)pairs / (double)M : 0.0;
+    const int TP = xenv ? atoi(xenv) : (kbar >= 192.0 ? 4 : (kbar >= 24.0 ? 2 : 0));
+    if ((TP == 2 || TP == 4 || TP == 8) && N >= 8 && M >= 16 * (int64_t)N) {
         const int NG = 8 / TP;
         for (int32_t c0 = 0; c0 < N; c0 += NG)
             for (int s = 0; s < TP; ++s)
