@@ -82,3 +82,93 @@ def readme_case(seed=0):
                                               DenseWeightModel(0.1 * np.ones((N, N))))
     data = branching_sample(np.ones(N), 0.1 * np.ones((N, N)), np.ones((N, N)), T, seed)
     return process, data
+
+
+# ---- rand(process, duration): host-side simulators of the generative models -------------------------
+# The reference's `rand` methods (src/continuous.jl:16-48,131-142,335-348; src/discrete.jl:31-68,
+# src/baselines.jl:189-210,521-527) are host data generators outside the hot path; these are independent
+# numpy implementations of the same models (generation-wise branching in continuous time, bin-by-bin
+# Poisson autoregression in discrete time), drawn from numpy's PCG64 -- not Julia's streams.
+def _baseline_events(baseline, duration, rng):
+    from .components import LogGaussianCoxProcess
+    out = []
+    for c in range(baseline.ndims()):
+        if isinstance(baseline, LogGaussianCoxProcess):
+            if baseline.length() != duration:
+                raise ValueError("Sample duration does not match process duration.")       # src/baselines.jl:190
+            y = baseline.λ[c]
+            top = float(np.max(y))
+            cand = rng.uniform(0.0, duration, rng.poisson(top * duration))                   # thinning
+            keep = rng.uniform(0.0, top, len(cand)) < np.interp(cand, baseline.x, y)
+            out.append(cand[keep])
+        else:
+            out.append(rng.uniform(0.0, duration, rng.poisson(baseline.λ[c] * duration)))
+    return out
+
+
+def _delays(impulses, p, c, n, rng):
+    if isinstance(impulses, ExponentialImpulseResponse):
+        return rng.exponential(1.0 / impulses.θ[p, c], n)
+    z = impulses.μ[p, c] + rng.standard_normal(n) / np.sqrt(impulses.τ[p, c])                # logit-normal on (0, Δtmax)
+    return impulses.Δtmax / (1.0 + np.exp(-z))
+
+
+def rand_continuous(process, duration, seed=0, max_events=5_000_000):
+    """rand(process::ContinuousHawkesProcess, duration) -> (events, nodes, duration)."""
+    rng = np.random.default_rng(seed)
+    N = process.ndims()
+    W = process.weights.W * getattr(process, "adjacency_matrix", np.ones((N, N)))
+    base = _baseline_events(process.baseline, duration, rng)
+    gen_t = np.concatenate(base)
+    gen_n = np.concatenate([np.full(len(b), c) for c, b in enumerate(base)]).astype(np.int64)
+    times, nodes, total = [], [], 0
+    while len(gen_t):
+        times.append(gen_t)
+        nodes.append(gen_n)
+        total += len(gen_t)
+        if total > max_events:
+            raise RuntimeError("branching process exploded (unstable weights?)")
+        nt, nn = [], []
+        for p in range(N):
+            tp = gen_t[gen_n == p]
+            for c in range(N):
+                k = rng.poisson(W[p, c], len(tp))
+                child = np.repeat(tp, k) + _delays(process.impulses, p, c, int(k.sum()), rng)
+                child = child[child <= duration]
+                nt.append(child)
+                nn.append(np.full(len(child), c, dtype=np.int64))
+        gen_t, gen_n = np.concatenate(nt), np.concatenate(nn)
+    times, nodes = np.concatenate(times), np.concatenate(nodes)
+    order = np.argsort(times, kind="stable")
+    return times[order], (nodes[order] + 1).astype(np.int64), float(duration)
+
+
+def rand_discrete(process, duration, seed=0):
+    """rand(process::DiscreteHawkesProcess, T) -> N x T count matrix: bin t is Poisson with the
+    intensity of src/discrete.jl:115-129 given the bins before it."""
+    rng = np.random.default_rng(seed)
+    N, T, dt = process.ndims(), int(duration), process.dt
+    phi = process.impulses.basis()                        # L x B
+    L, B = phi.shape
+    A = getattr(process, "adjacency_matrix", None)
+    eta = process.weights.W[:, :, None] * process.impulses.θ * dt
+    if A is not None:
+        eta = eta * A[:, :, None]
+    b = process.baseline
+    base = b.intensity(np.arange(1, T + 1, dtype=np.float64))                                # T x N (λ·dt per bin)
+    data = np.zeros((N, T), dtype=np.int64)
+    for t in range(T):
+        lo = max(0, t - L)
+        hist = data[:, lo:t][:, ::-1]                                                        # lag 1 first
+        shat = hist @ phi[: t - lo]                                                          # N x B
+        lam = base[t] + np.einsum("pb,pcb->c", shat, eta)
+        data[:, t] = rng.poisson(lam)
+    return data
+
+
+def rand(process, duration, seed=0):
+    """rand(process, duration): simulate data from a continuous or a discrete process."""
+    from .discrete import DiscreteHawkesProcess
+    if isinstance(process, DiscreteHawkesProcess):
+        return rand_discrete(process, duration, seed)
+    return rand_continuous(process, duration, seed)

@@ -145,3 +145,28 @@ def test_branching_simulator_statistics(nhp):
     want = np.linalg.solve(np.eye(2) - W.T, lam0)
     got = np.bincount(n - 1) / T
     assert np.all(np.abs(got - want) / want < 0.08)
+
+
+def test_simulators_have_the_right_first_moments(nhp):
+    # synthetic.rand: stationary rate of a Hawkes process = (I - Wᵀ)⁻¹ λ0 (continuous), and of the discrete
+    # autoregression λ0·dt / (1 - Σ column weights) per bin when the excitation is the same on every link
+    W = np.array([[0.2, 0.1], [0.0, 0.3]])
+    lam0 = np.array([0.5, 1.0])
+    proc = nhp.ContinuousStandardHawkesProcess(nhp.HomogeneousProcess(lam0), nhp.ExponentialImpulseResponse(2 * np.ones((2, 2))),
+                                               nhp.DenseWeightModel(W))
+    t, n, T = nhp.synthetic.rand(proc, 4000.0, seed=1)
+    assert np.all(np.diff(t) >= 0) and set(np.unique(n)) == {1, 2}
+    rate = np.linalg.solve(np.eye(2) - W.T, lam0)
+    got = np.bincount(n - 1, minlength=2) / T
+    assert np.all(np.abs(got - rate) / rate < 0.08), (got, rate)
+    th = np.full((2, 2, 2), 0.5)
+    dproc = nhp.DiscreteStandardHawkesProcess.__new__(nhp.DiscreteStandardHawkesProcess)
+    dproc.baseline = nhp.DiscreteHomogeneousProcess(np.array([0.2, 0.4]), 1.0)
+    dproc.impulses = nhp.DiscreteGaussianImpulseResponse.__new__(nhp.DiscreteGaussianImpulseResponse)
+    dproc.impulses.θ, dproc.impulses.nlags, dproc.impulses.dt = th, 4, 1.0
+    dproc.impulses.basis = lambda: np.full((4, 2), 0.25)          # unit-mass bases without touching the GPU library
+    dproc.weights, dproc.dt = nhp.DenseWeightModel(np.full((2, 2), 0.2)), 1.0
+    data = nhp.synthetic.rand(dproc, 20000, seed=2)
+    assert data.shape == (2, 20000) and data.min() >= 0
+    drate = np.linalg.solve(np.eye(2) - np.full((2, 2), 0.2), np.array([0.2, 0.4]))
+    assert np.all(np.abs(data.mean(axis=1) - drate) / drate < 0.08), (data.mean(axis=1), drate)
