@@ -22,6 +22,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+EXP_TERM_CEILING = 1.45e12     # exponential pair terms/s on register operands, measured (profiles/README.md)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 WORKLOADS = {
@@ -285,8 +286,12 @@ def main():
                 o = run_workload(nhp, ctx, name, args.nodes, args.events, steps, 2, sync)
                 Bo = algorithmic_bytes(o["N"], o["M"], o["kind"])
                 mk = o["dev_ms"] / steps
+                # exponential pair terms/s against the calibrated fp64-VALU ceiling (nhp_probe_rate, tools/rate.py);
+                # the recursive path evaluates 2·M·N exponentials per call
+                terms = 2.0 * o["M"] * o["N"] if name == "recursive" else float(o["pairs"])
                 others.append({"workload": name, "value": steps / o["wall"], "kernel_ms": mk, "steps": steps,
                                "pairs_per_eval": o["pairs"], "hbm_frac": Bo / (mk * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "exp_terms_per_s": terms / (mk * 1e-3), "fp64_valu_frac": terms / (mk * 1e-3) / EXP_TERM_CEILING,
                                "loglik": o["ll"]})
             out["other_workloads"] = others
         if world == 1 and args.configs:
