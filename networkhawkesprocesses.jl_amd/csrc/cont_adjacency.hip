@@ -36,39 +36,24 @@ __device__ __forceinline__ double adj_baseline(const nhp_cont_args &a, int c, do
     return (y[lo + 1] * (t - x[lo]) + y[lo] * (x[lo + 1] - t)) / (x[lo + 1] - x[lo]);
 }
 
-template <int IMP>
-__global__ __launch_bounds__(NHP_BLOCK) void k_adj_pairs(nhp_cont_args a, const double *__restrict__ A,
-                                                         const int64_t *__restrict__ pair_off,
-                                                         int32_t *__restrict__ ent_k, double *__restrict__ ent_x,
-                                                         int max_children, int group, int32_t *__restrict__ col_start,
-                                                         double *__restrict__ lam_g)
+// The pair lists depend on the DATA only -- which (parent, child) pairs exist, their delays, the parent's
+// node -- so they are built once per dataset (k_adj_build) and kept: per column, entries sorted by parent
+// node, each {child slot, parent node, Δt}, plus the per-column offsets by parent node.
+__global__ __launch_bounds__(NHP_BLOCK) void k_adj_build(nhp_cont_args a, const int64_t *__restrict__ pair_off, int group,
+                                                         int32_t *__restrict__ ent_k, int32_t *__restrict__ ent_p,
+                                                         double *__restrict__ ent_dt, int32_t *__restrict__ col_start)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = a.N, c = blockIdx.x, tid = threadIdx.x;
     // `group` lanes share a child (the dataset's lanes-per-child width, a power of two <= 64), so a wave
     // has 64/group windows in flight instead of one
     const int gl = tid & (group - 1), gid = tid / group, ngroups = NHP_BLOCK / group;
-    double2 *col = reinterpret_cast<double2 *>(smem + 64);                 // [N] exp {θ, W}; logit {μ, √τ}
-    double *colw = reinterpret_cast<double *>(col + N);                    // [N] logit: W
-    double *lam = colw + (IMP == NHP_IMPULSE_EXPONENTIAL ? 0 : N);         // [max_children] current λ_k
-    int *start = reinterpret_cast<int *>(lam + max_children);              // [N + 1] pair-list offsets by p
+    int *start = reinterpret_cast<int *>(smem);                            // [N + 1] pair-list offsets by p
     int *cursor = start + N + 1;                                           // [N]
     int *scan_tmp = cursor + N;                                            // [NHP_BLOCK]
-
     const int kb = a.boff[c], ke = a.boff[c + 1], nchild = ke - kb;
-    for (int p = tid; p < N; p += NHP_BLOCK) {
-        const size_t k = (size_t)p + (size_t)c * N;
-        if (IMP == NHP_IMPULSE_EXPONENTIAL) {
-            col[p] = make_double2(a.p1[k], a.W[k]);
-        } else {
-            col[p] = make_double2(a.p1[k], __builtin_sqrt(a.p2[k]));
-            colw[p] = a.W[k];
-        }
-        cursor[p] = 0;
-    }
-    for (int k = tid; k < nchild; k += NHP_BLOCK) lam[k] = adj_baseline(a, c, a.child[kb + k].t);
+    for (int p = tid; p < N; p += NHP_BLOCK) cursor[p] = 0;
     __syncthreads();
-
     // ---- pairs per parent node
     for (int k = gid; k < nchild; k += ngroups) {
         const nhp_child ch = a.child[kb + k];
@@ -97,28 +82,62 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_pairs(nhp_cont_args a, const 
     __syncthreads();
     for (int p = tid; p < N; p += NHP_BLOCK) cursor[p] = 0;
     __syncthreads();
-
-    // ---- evaluate every pair once, scatter by parent node, accumulate λ_k
+    // ---- scatter by parent node
     const int64_t base = pair_off[c];
     for (int k = gid; k < nchild; k += ngroups) {
         const nhp_child ch = a.child[kb + k];
         for (int j = ch.first + gl; j < ch.idx; j += group) {
             const nhp_event e = a.ev[j];
-            const int p = e.node;
-            const double dt = ch.t - e.t;
-            const double2 q = col[p];
-            double x;
-            if (IMP == NHP_IMPULSE_EXPONENTIAL) x = q.y * nhp_pdf_exponential(q.x, dt);
-            else x = colw[p] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
-            const int pos = start[p] + atomicAdd(&cursor[p], 1);
+            const int pos = start[e.node] + atomicAdd(&cursor[e.node], 1);
             ent_k[base + pos] = k;
-            ent_x[base + pos] = x;
-            const double av = A[(size_t)p + (size_t)c * N];
-            if (av != 0.0) atomicAdd(&lam[k], av * x);
+            ent_p[base + pos] = e.node;
+            ent_dt[base + pos] = ch.t - e.t;
         }
     }
-    __syncthreads();
     for (int p = tid; p <= N; p += NHP_BLOCK) col_start[(size_t)c * (N + 1) + p] = start[p];
+}
+
+// Per sweep: x = W[p,c]·ħ(Δt) for every cached entry of column c (a streaming pass: coalesced reads of
+// {k, p, Δt}, the column of the tables in LDS) and λ_k = λ0 + Σ A[p,c]·x per child.
+template <int IMP>
+__global__ __launch_bounds__(NHP_BLOCK) void k_adj_eval(nhp_cont_args a, const double *__restrict__ A,
+                                                        const int64_t *__restrict__ pair_off,
+                                                        const int32_t *__restrict__ ent_k, const int32_t *__restrict__ ent_p,
+                                                        const double *__restrict__ ent_dt, double *__restrict__ ent_x,
+                                                        int max_children, double *__restrict__ lam_g)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int N = a.N, c = blockIdx.x, tid = threadIdx.x;
+    double2 *col = reinterpret_cast<double2 *>(smem);                      // [N] exp {θ, W}; logit {μ, √τ}
+    double *colw = reinterpret_cast<double *>(col + N);                    // [N] logit: W
+    double *acol = colw + (IMP == NHP_IMPULSE_EXPONENTIAL ? 0 : N);        // [N] A[·, c]
+    double *lam = acol + N;                                                // [max_children] λ_k
+    const int kb = a.boff[c], nchild = a.boff[c + 1] - kb;
+    for (int p = tid; p < N; p += NHP_BLOCK) {
+        const size_t k = (size_t)p + (size_t)c * N;
+        if (IMP == NHP_IMPULSE_EXPONENTIAL) {
+            col[p] = make_double2(a.p1[k], a.W[k]);
+        } else {
+            col[p] = make_double2(a.p1[k], __builtin_sqrt(a.p2[k]));
+            colw[p] = a.W[k];
+        }
+        acol[p] = A[k];
+    }
+    for (int k = tid; k < nchild; k += NHP_BLOCK) lam[k] = adj_baseline(a, c, a.child[kb + k].t);
+    __syncthreads();
+    const int64_t e0 = pair_off[c], e1 = pair_off[c + 1];
+    for (int64_t e = e0 + tid; e < e1; e += NHP_BLOCK) {
+        const int p = ent_p[e];
+        const double dt = ent_dt[e];
+        const double2 q = col[p];
+        double x;
+        if (IMP == NHP_IMPULSE_EXPONENTIAL) x = q.y * nhp_pdf_exponential(q.x, dt);
+        else x = colw[p] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
+        ent_x[e] = x;
+        const double av = acol[p];
+        if (av != 0.0) atomicAdd(&lam[ent_k[e]], av * x);
+    }
+    __syncthreads();
     for (int k = tid; k < nchild; k += NHP_BLOCK) lam_g[kb + k] = lam[k];
 }
 
@@ -265,39 +284,54 @@ extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_d
     int max_children = 1;
     for (size_t c = 0; c < N; ++c) max_children = std::max(max_children, ds->h_boff[c + 1] - ds->h_boff[c]);
     const bool expo = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
-    const size_t lds_pairs = 64 + (expo ? 16 : 24) * N + 8 * (size_t)max_children + 4 * (2 * N + 2 + NHP_BLOCK);
+    const size_t lds_build = 4 * (2 * N + 2 + NHP_BLOCK);
+    const size_t lds_eval = (expo ? 16 : 24) * N + 8 * N + 8 * (size_t)max_children;
     const size_t lds_sweep = 20 * (size_t)max_children + 4 * (N + 2);
-    if (lds_pairs > 160 * 1024 || lds_sweep > 160 * 1024) {
+    if (lds_build > 160 * 1024 || lds_eval > 160 * 1024 || lds_sweep > 160 * 1024) {
         nhp_set_error(ctx, "resample_adjacency: a node with %d events (N = %d) exceeds the 160 KiB LDS column state", max_children, ds->N);
         return NHP_ENOTIMPL;
+    }
+    hipStream_t st = ctx->stream;
+    nhp_cont_args a = nhp_make_args(ds, m);
+    // ---- the data-only pair lists, built on first use and kept with the dataset
+    if (!ds->d_adj_k) {
+        nhp_cont_dataset *mds = const_cast<nhp_cont_dataset *>(ds);
+        if (hipMalloc((void **)&mds->d_adj_k, 4 * P) != hipSuccess || hipMalloc((void **)&mds->d_adj_p, 4 * P) != hipSuccess ||
+            hipMalloc((void **)&mds->d_adj_dt, 8 * P) != hipSuccess || hipMalloc((void **)&mds->d_adj_start, 4 * N * (N + 1)) != hipSuccess ||
+            hipMalloc((void **)&mds->d_adj_off, 8 * (N + 1)) != hipSuccess) {
+            (void)hipFree(mds->d_adj_k); (void)hipFree(mds->d_adj_p); (void)hipFree(mds->d_adj_dt); (void)hipFree(mds->d_adj_start); (void)hipFree(mds->d_adj_off);
+            mds->d_adj_k = nullptr; mds->d_adj_p = nullptr; mds->d_adj_dt = nullptr; mds->d_adj_start = nullptr; mds->d_adj_off = nullptr;
+            nhp_set_error(ctx, "resample_adjacency: out of device memory for %zu cached pairs", P);
+            return NHP_ENOMEM;
+        }
+        NHP_HIP(ctx, hipMemcpyAsync(mds->d_adj_off, ds->h_pair_off.data(), 8 * (N + 1), hipMemcpyHostToDevice, st));
+        if (lds_build > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
+        hipLaunchKernelGGL(k_adj_build, dim3((unsigned)N), dim3(NHP_BLOCK), lds_build, st, a, ds->d_adj_off, ds->group, mds->d_adj_k,
+                           mds->d_adj_p, mds->d_adj_dt, mds->d_adj_start);
+        NHP_HIP(ctx, hipGetLastError());
     }
     const size_t M1 = (size_t)(ds->M > 0 ? ds->M : 1);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t r = off; off += (bytes + 255) & ~(size_t)255; return r; };
-    const size_t o_k = carve(4 * P), o_x = carve(8 * P), o_off = carve(8 * (N + 1)), o_u = carve(8 * NN), o_rho = carve(8 * NN), o_links = carve(8 * N);
-    const size_t o_start = carve(4 * N * (N + 1)), o_lam = carve(8 * M1);
-    if (off > ((size_t)48 << 30)) { nhp_set_error(ctx, "resample_adjacency: %zu pairs need too much scratch", P); return NHP_ENOMEM; }
+    const size_t o_x = carve(8 * P), o_u = carve(8 * NN), o_rho = carve(8 * NN), o_links = carve(8 * N), o_lam = carve(8 * M1);
     NHP_TRY(nhp_ctx_reserve_scratch(ctx, off));
     char *base = (char *)ctx->d_scratch;
-    hipStream_t st = ctx->stream;
-    NHP_HIP(ctx, hipMemcpyAsync(base + o_off, ds->h_pair_off.data(), 8 * (N + 1), hipMemcpyHostToDevice, st));
     if (u) NHP_HIP(ctx, hipMemcpyAsync(base + o_u, u, 8 * NN, hipMemcpyHostToDevice, st));
     if (rho_matrix) NHP_HIP(ctx, hipMemcpyAsync(base + o_rho, rho_matrix, 8 * NN, hipMemcpyHostToDevice, st));
-    nhp_cont_args a = nhp_make_args(ds, m);
     const double *d_u = u ? (const double *)(base + o_u) : nullptr;
     const double *d_rho = rho_matrix ? (const double *)(base + o_rho) : nullptr;
     double *d_links = (double *)(base + o_links);
-    const int64_t *d_off = (const int64_t *)(base + o_off);
-    int32_t *d_k = (int32_t *)(base + o_k), *d_start = (int32_t *)(base + o_start);
+    const int64_t *d_off = ds->d_adj_off;
+    const int32_t *d_k = ds->d_adj_k, *d_start = ds->d_adj_start;
     double *d_x = (double *)(base + o_x), *d_lam = (double *)(base + o_lam);
     if (expo) {
-        if (lds_pairs > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_pairs<NHP_IMPULSE_EXPONENTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pairs));
-        hipLaunchKernelGGL((k_adj_pairs<NHP_IMPULSE_EXPONENTIAL>), dim3((unsigned)N), dim3(NHP_BLOCK), lds_pairs, st, a, m->d_A,
-                           d_off, d_k, d_x, max_children, ds->group, d_start, d_lam);
+        if (lds_eval > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_eval<NHP_IMPULSE_EXPONENTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval));
+        hipLaunchKernelGGL((k_adj_eval<NHP_IMPULSE_EXPONENTIAL>), dim3((unsigned)N), dim3(NHP_BLOCK), lds_eval, st, a, m->d_A,
+                           d_off, d_k, ds->d_adj_p, ds->d_adj_dt, d_x, max_children, d_lam);
     } else {
-        if (lds_pairs > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_pairs<NHP_IMPULSE_LOGITNORMAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pairs));
-        hipLaunchKernelGGL((k_adj_pairs<NHP_IMPULSE_LOGITNORMAL>), dim3((unsigned)N), dim3(NHP_BLOCK), lds_pairs, st, a, m->d_A,
-                           d_off, d_k, d_x, max_children, ds->group, d_start, d_lam);
+        if (lds_eval > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_eval<NHP_IMPULSE_LOGITNORMAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval));
+        hipLaunchKernelGGL((k_adj_eval<NHP_IMPULSE_LOGITNORMAL>), dim3((unsigned)N), dim3(NHP_BLOCK), lds_eval, st, a, m->d_A,
+                           d_off, d_k, ds->d_adj_p, ds->d_adj_dt, d_x, max_children, d_lam);
     }
     NHP_HIP(ctx, hipGetLastError());
     if (lds_sweep > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sweep));

@@ -75,6 +75,11 @@ struct nhp_cont_dataset {
     double *d_cnt = nullptr;            // [N] events per node
     int32_t *d_pn = nullptr;            // [M] bucket order: parent node of each child from the latest parent sweep (-1 = baseline)
     mutable bool pn_valid = false;      // d_pn holds an assignment (set by the sampler / nhp_cont_lgcp_loglik)
+    // adjacency sweep: the data-only pair lists (per child column, sorted by parent node), built on first use
+    int32_t *d_adj_k = nullptr, *d_adj_p = nullptr;   // [pairs] child slot within the column, parent node
+    double *d_adj_dt = nullptr;                       // [pairs] t_child - t_parent
+    int32_t *d_adj_start = nullptr;                   // [N*(N+1)] per-column offsets by parent node
+    int64_t *d_adj_off = nullptr;                     // [N+1] first pair of each column
     // host copies kept for host-side helpers
     std::vector<int32_t> h_boff;
     std::vector<double> h_cnt;
