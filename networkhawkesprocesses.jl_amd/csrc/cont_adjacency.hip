@@ -41,7 +41,8 @@ __device__ __forceinline__ double adj_baseline(const nhp_cont_args &a, int c, do
 // node, each {child slot, parent node, Δt}, plus the per-column offsets by parent node.
 __global__ __launch_bounds__(NHP_BLOCK) void k_adj_build(nhp_cont_args a, const int64_t *__restrict__ pair_off, int group,
                                                          int32_t *__restrict__ ent_k, int32_t *__restrict__ ent_p,
-                                                         double *__restrict__ ent_dt, int32_t *__restrict__ col_start)
+                                                         double *__restrict__ ent_dt, int32_t *__restrict__ col_start,
+                                                         unsigned char *__restrict__ col_plain)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = a.N, c = blockIdx.x, tid = threadIdx.x;
@@ -95,6 +96,18 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_build(nhp_cont_args a, const 
         }
     }
     for (int p = tid; p <= N; p += NHP_BLOCK) col_start[(size_t)c * (N + 1) + p] = start[p];
+    // col_plain[p + c·N] = 1 if the list of (p, c) fits one 64-lane chunk and names every child at most once
+    // (the common case): the sweep then needs no LDS accumulation and no ownership marks for that entry
+    __syncthreads();
+    __threadfence_block();
+    for (int p = tid; p < N; p += NHP_BLOCK) {
+        const int eb = start[p], ee = start[p + 1];
+        bool plain = ee - eb <= 64;
+        for (int i = eb; plain && i < ee; ++i)
+            for (int j = i + 1; j < ee; ++j)
+                if (ent_k[base + i] == ent_k[base + j]) { plain = false; break; }
+        col_plain[(size_t)p + (size_t)c * N] = plain ? 1 : 0;
+    }
 }
 
 // Per sweep: x = W[p,c]·ħ(Δt) for every cached entry of column c (a streaming pass: coalesced reads of
@@ -178,7 +191,8 @@ __device__ __forceinline__ double adj_readlane(double v, int l)     // l is wave
 __global__ __launch_bounds__(64) void k_adj_sweep(nhp_cont_args a, double *__restrict__ A,
                                                   const int64_t *__restrict__ pair_off,
                                                   const int32_t *__restrict__ ent_k, const double *__restrict__ ent_x,
-                                                  const int32_t *__restrict__ col_start, const double *__restrict__ lam_g,
+                                                  const int32_t *__restrict__ col_start, const unsigned char *__restrict__ col_plain,
+                                                  const double *__restrict__ lam_g,
                                                   const double *__restrict__ rho_mat, double rho_scalar,
                                                   const double *__restrict__ u, uint64_t seed, uint64_t step,
                                                   int max_children, double *__restrict__ col_links)
@@ -196,12 +210,11 @@ __global__ __launch_bounds__(64) void k_adj_sweep(nhp_cont_args a, double *__res
 
     const int64_t base = pair_off[c];
     double links = 0.0;
-    // entries of parent p: lane l owns entry eb + l (+64, +128, ... for the rare long lists)
-    int nk = -1;
-    double nx = 0.0;
-    if (N > 0 && start[0] + lane < start[1]) { nk = ent_k[base + start[0] + lane]; nx = ent_x[base + start[0] + lane]; }
     double c_uni = 0.0, c_bias = 0.0, c_a = 0.0;                            // this lane's parent of the current 64-chunk
-    for (int p = 0; p < (NHP_SKIP(a, 64) ? 0 : N); ++p) {
+    int c_plain = 0;
+    // one parent node: lane l owns entry eb + l of its list (ck, cx: fetched ADJ_AHEAD parents earlier, so the
+    // global-load latency is off the chain), entries eb + 64, ... of the rare long lists are read in place
+    auto visit = [&](const int p, const int ck, const double cx) {
         if ((p & 63) == 0) {
             const int pp = p + lane;
             if (pp < N) {
@@ -213,16 +226,34 @@ __global__ __launch_bounds__(64) void k_adj_sweep(nhp_cont_args a, double *__res
                 c_uni = nhp_log(uu / (1.0 - uu));
                 c_bias = -(a.W[kq] * a.cnt[pp]) + nhp_log(rho) - nhp_log(1.0 - rho);
                 c_a = A[kq];
+                c_plain = col_plain[kq];
             }
         }
         const int eb = start[p], ee = start[p + 1];
         const size_t kpc = (size_t)p + (size_t)c * N;
         const double aold = adj_readlane(c_a, p & 63);
         const double uni_p = adj_readlane(c_uni, p & 63), bias_p = adj_readlane(c_bias, p & 63);
-        const int ck = nk;                       // this lane's first entry of p (or -1)
-        const double cx = nx;
-        nk = -1;
-        if (p + 1 < N && ee + lane < start[p + 2]) { nk = ent_k[base + ee + lane]; nx = ent_x[base + ee + lane]; }
+        if (__builtin_amdgcn_readlane(c_plain, p & 63)) {
+            // plain list: every lane's entry is a different child -- one LDS read on the chain, no atomics, no marks
+            const double lv = ck >= 0 ? lam[ck] : 1.0;
+            const double l0 = ck >= 0 ? lv - aold * cx : 1.0;
+            // hardware reciprocal and log2 (≈1 ulp each): the 1e-3 band below is far wider than their error
+            float t32 = ck >= 0 ? 0.6931471806f * __builtin_amdgcn_logf(1.0f + (float)cx * __builtin_amdgcn_rcpf((float)l0)) : 0.0f;
+            t32 = adj_wave_sum_f32(t32);
+            const double d32 = bias_p + (double)t32;
+            double an;
+            if (fabs(uni_p - d32) > 1e-3 * (1.0 + (double)t32)) {
+                an = uni_p <= d32 ? 1.0 : 0.0;
+            } else {
+                const double delta = nhp_wave_sum(ck >= 0 ? nhp_log(l0 + cx) - nhp_log(l0) : 0.0);
+                an = uni_p <= bias_p + delta ? 1.0 : 0.0;
+            }
+            if (lane == 0) A[kpc] = an;
+            links += an;
+            if (an != aold && ck >= 0) lam[ck] = lv + (an - aold) * cx;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the next parent reads these λ in program order
+            return;
+        }
         if (ck >= 0) atomicAdd(&dx[ck], cx);
         for (int e = eb + 64 + lane; e < ee; e += 64) atomicAdd(&dx[ent_k[base + e]], ent_x[base + e]);
         NHP_LDS_SYNC();
@@ -268,6 +299,29 @@ __global__ __launch_bounds__(64) void k_adj_sweep(nhp_cont_args a, double *__res
         if (ck >= 0) settle(ck);
         for (int e = eb + 64 + lane; e < ee; e += 64) settle(ent_k[base + e]);
         NHP_LDS_SYNC();
+    };
+    constexpr int ADJ_AHEAD = 4;
+    int ek[ADJ_AHEAD];
+    double ex[ADJ_AHEAD];
+    auto fetch = [&](const int p, int *k_out, double *x_out) {
+        *k_out = -1; *x_out = 0.0;
+        if (p < N) {
+            const int e = start[p] + lane;
+            if (e < start[p + 1]) { *k_out = ent_k[base + e]; *x_out = ent_x[base + e]; }
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < ADJ_AHEAD; ++q) fetch(q, &ek[q], &ex[q]);
+    for (int p0 = 0; p0 < (NHP_SKIP(a, 64) ? 0 : N); p0 += ADJ_AHEAD) {
+        int nk[ADJ_AHEAD];
+        double nx[ADJ_AHEAD];
+#pragma unroll
+        for (int q = 0; q < ADJ_AHEAD; ++q) fetch(p0 + ADJ_AHEAD + q, &nk[q], &nx[q]);
+#pragma unroll
+        for (int q = 0; q < ADJ_AHEAD; ++q)
+            if (p0 + q < N) visit(p0 + q, ek[q], ex[q]);
+#pragma unroll
+        for (int q = 0; q < ADJ_AHEAD; ++q) { ek[q] = nk[q]; ex[q] = nx[q]; }
     }
     if (lane == 0 && col_links) col_links[c] = links;
 }
@@ -298,16 +352,16 @@ extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_d
         nhp_cont_dataset *mds = const_cast<nhp_cont_dataset *>(ds);
         if (hipMalloc((void **)&mds->d_adj_k, 4 * P) != hipSuccess || hipMalloc((void **)&mds->d_adj_p, 4 * P) != hipSuccess ||
             hipMalloc((void **)&mds->d_adj_dt, 8 * P) != hipSuccess || hipMalloc((void **)&mds->d_adj_start, 4 * N * (N + 1)) != hipSuccess ||
-            hipMalloc((void **)&mds->d_adj_off, 8 * (N + 1)) != hipSuccess) {
-            (void)hipFree(mds->d_adj_k); (void)hipFree(mds->d_adj_p); (void)hipFree(mds->d_adj_dt); (void)hipFree(mds->d_adj_start); (void)hipFree(mds->d_adj_off);
-            mds->d_adj_k = nullptr; mds->d_adj_p = nullptr; mds->d_adj_dt = nullptr; mds->d_adj_start = nullptr; mds->d_adj_off = nullptr;
+            hipMalloc((void **)&mds->d_adj_off, 8 * (N + 1)) != hipSuccess || hipMalloc((void **)&mds->d_adj_plain, NN) != hipSuccess) {
+            (void)hipFree(mds->d_adj_k); (void)hipFree(mds->d_adj_p); (void)hipFree(mds->d_adj_dt); (void)hipFree(mds->d_adj_start); (void)hipFree(mds->d_adj_off); (void)hipFree(mds->d_adj_plain);
+            mds->d_adj_plain = nullptr; mds->d_adj_k = nullptr; mds->d_adj_p = nullptr; mds->d_adj_dt = nullptr; mds->d_adj_start = nullptr; mds->d_adj_off = nullptr;
             nhp_set_error(ctx, "resample_adjacency: out of device memory for %zu cached pairs", P);
             return NHP_ENOMEM;
         }
         NHP_HIP(ctx, hipMemcpyAsync(mds->d_adj_off, ds->h_pair_off.data(), 8 * (N + 1), hipMemcpyHostToDevice, st));
         if (lds_build > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
         hipLaunchKernelGGL(k_adj_build, dim3((unsigned)N), dim3(NHP_BLOCK), lds_build, st, a, ds->d_adj_off, ds->group, mds->d_adj_k,
-                           mds->d_adj_p, mds->d_adj_dt, mds->d_adj_start);
+                           mds->d_adj_p, mds->d_adj_dt, mds->d_adj_start, mds->d_adj_plain);
         NHP_HIP(ctx, hipGetLastError());
     }
     const size_t M1 = (size_t)(ds->M > 0 ? ds->M : 1);
@@ -335,7 +389,7 @@ extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_d
     }
     NHP_HIP(ctx, hipGetLastError());
     if (lds_sweep > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sweep));
-    hipLaunchKernelGGL(k_adj_sweep, dim3((unsigned)N), dim3(64), lds_sweep, st, a, m->d_A, d_off, d_k, d_x, d_start, d_lam,
+    hipLaunchKernelGGL(k_adj_sweep, dim3((unsigned)N), dim3(64), lds_sweep, st, a, m->d_A, d_off, d_k, d_x, d_start, ds->d_adj_plain, d_lam,
                        d_rho, rho, d_u, seed, step, max_children, d_links);
     NHP_HIP(ctx, hipGetLastError());
     std::vector<double> links(N);
