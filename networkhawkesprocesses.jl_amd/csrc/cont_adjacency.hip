@@ -42,7 +42,7 @@ __device__ __forceinline__ double adj_baseline(const nhp_cont_args &a, int c, do
 __global__ __launch_bounds__(NHP_BLOCK) void k_adj_build(nhp_cont_args a, const int64_t *__restrict__ pair_off, int group,
                                                          int32_t *__restrict__ ent_k, int32_t *__restrict__ ent_p,
                                                          double *__restrict__ ent_dt, int32_t *__restrict__ col_start,
-                                                         unsigned char *__restrict__ col_plain)
+                                                         unsigned char *__restrict__ col_group, int max_children)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = a.N, c = blockIdx.x, tid = threadIdx.x;
@@ -96,17 +96,42 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_build(nhp_cont_args a, const 
         }
     }
     for (int p = tid; p <= N; p += NHP_BLOCK) col_start[(size_t)c * (N + 1) + p] = start[p];
-    // col_plain[p + c·N] = 1 if the list of (p, c) fits one 64-lane chunk and names every child at most once
-    // (the common case): the sweep then needs no LDS accumulation and no ownership marks for that entry
+    // Grouping (data only).  Entries (p, c) and (p', c) of a column interact only through children that have
+    // parents on both nodes, so consecutive parents whose lists share no child can be decided together with
+    // the same result as one after the other.  col_group[p + c·N]: 1..4 = p heads a group of that many
+    // consecutive parents -- each list at most 16 entries, all children distinct inside the group, all in
+    // one 64-parent chunk -- which the sweep decides in ONE step (16 lanes per parent); 0 = member of the
+    // group before it; 255 = p is decided alone by the general path (long list, or a child named twice).
     __syncthreads();
     __threadfence_block();
-    for (int p = tid; p < N; p += NHP_BLOCK) {
-        const int eb = start[p], ee = start[p + 1];
-        bool plain = ee - eb <= 64;
-        for (int i = eb; plain && i < ee; ++i)
-            for (int j = i + 1; j < ee; ++j)
-                if (ent_k[base + i] == ent_k[base + j]) { plain = false; break; }
-        col_plain[(size_t)p + (size_t)c * N] = plain ? 1 : 0;
+    if (tid == 0) {
+        int *seen = scan_tmp + NHP_BLOCK;                // [max_children] group id that last touched the child
+        for (int k = 0; k < nchild; ++k) seen[k] = 0;
+        int gid = 0, p = 0;
+        unsigned char *grp = col_group + (size_t)c * N;
+        auto fits = [&](int q, int id) {                 // list of q: <= 16 entries, children unseen in group id
+            const int eb = start[q], ee = start[q + 1];
+            if (ee - eb > 16) return false;
+            for (int e = eb; e < ee; ++e) if (seen[ent_k[base + e]] == id) return false;
+            return true;
+        };
+        auto take = [&](int q, int id) { for (int e = start[q]; e < start[q + 1]; ++e) seen[ent_k[base + e]] = id; };
+        while (p < N) {
+            ++gid;
+            bool ok = start[p + 1] - start[p] <= 16;
+            if (ok) {                                    // a child twice in p's own list?  mark as we go
+                for (int e = start[p]; e < start[p + 1]; ++e) {
+                    int &sk = seen[ent_k[base + e]];
+                    if (sk == gid) { ok = false; break; }
+                    sk = gid;
+                }
+            }
+            if (!ok) { grp[p] = 255; ++p; continue; }
+            int g = 1;
+            while (g < 4 && p + g < N && ((p + g) & 63) != 0 && fits(p + g, gid)) { take(p + g, gid); grp[p + g] = 0; ++g; }
+            grp[p] = (unsigned char)g;
+            p += g;
+        }
     }
 }
 
@@ -175,6 +200,12 @@ __device__ __forceinline__ float adj_wave_sum_f32(float v)          // every lan
            (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
 }
 
+__device__ __forceinline__ float adj_row_sum_f32(float v)           // every lane returns the sum of its row of 16 lanes
+{
+    v = adj_dpp_add_f32(v, 0); v = adj_dpp_add_f32(v, 1); v = adj_dpp_add_f32(v, 2); v = adj_dpp_add_f32(v, 3);
+    return v;
+}
+
 __device__ __forceinline__ double adj_readlane(double v, int l)     // l is wave-uniform
 {
     const long long b = __double_as_longlong(v);
@@ -191,7 +222,7 @@ __device__ __forceinline__ double adj_readlane(double v, int l)     // l is wave
 __global__ __launch_bounds__(64) void k_adj_sweep(nhp_cont_args a, double *__restrict__ A,
                                                   const int64_t *__restrict__ pair_off,
                                                   const int32_t *__restrict__ ent_k, const double *__restrict__ ent_x,
-                                                  const int32_t *__restrict__ col_start, const unsigned char *__restrict__ col_plain,
+                                                  const int32_t *__restrict__ col_start, const unsigned char *__restrict__ col_group,
                                                   const double *__restrict__ lam_g,
                                                   const double *__restrict__ rho_mat, double rho_scalar,
                                                   const double *__restrict__ u, uint64_t seed, uint64_t step,
@@ -203,125 +234,115 @@ __global__ __launch_bounds__(64) void k_adj_sweep(nhp_cont_args a, double *__res
     double *dx = lam + max_children;                                       // [max_children] Σ x_kp of the current p
     int *marker = reinterpret_cast<int *>(dx + max_children);              // [max_children]
     int *start = marker + max_children;                                    // [N + 2] pair-list offsets by p
+    unsigned char *grp = reinterpret_cast<unsigned char *>(start + N + 2); // [N + 1] grouping codes (k_adj_build)
     const int kb = a.boff[c], nchild = a.boff[c + 1] - kb;
     for (int k = lane; k < nchild; k += 64) { lam[k] = lam_g[kb + k]; dx[k] = 0.0; marker[k] = 0; }
     for (int p = lane; p <= N + 1; p += 64) start[p] = col_start[(size_t)c * (N + 1) + (p <= N ? p : N)];
+    for (int p = lane; p <= N; p += 64) grp[p] = p < N ? col_group[(size_t)c * N + p] : 255;
     NHP_LDS_SYNC();
 
     const int64_t base = pair_off[c];
     double links = 0.0;
     double c_uni = 0.0, c_bias = 0.0, c_a = 0.0;                            // this lane's parent of the current 64-chunk
-    int c_plain = 0;
-    // one parent node: lane l owns entry eb + l of its list (ck, cx: fetched ADJ_AHEAD parents earlier, so the
-    // global-load latency is off the chain), entries eb + 64, ... of the rare long lists are read in place
-    auto visit = [&](const int p, const int ck, const double cx) {
-        if ((p & 63) == 0) {
-            const int pp = p + lane;
-            if (pp < N) {
-                const size_t kq = (size_t)pp + (size_t)c * N;
-                const double rho = rho_mat ? rho_mat[kq] : rho_scalar;
-                // the Bernoulli rule u <= exp(ll1 - logsumexp(ll0, ll1)) = 1/(1 + e^{-d}) is logit(u) <= d:
-                // the logit is taken here, off the chain, which then carries no exp and no division
-                const double uu = u ? u[kq] : nhp_philox_uniform(seed ^ 0xBE5466CF34E90C6Cull, step, kq);
-                c_uni = nhp_log(uu / (1.0 - uu));
-                c_bias = -(a.W[kq] * a.cnt[pp]) + nhp_log(rho) - nhp_log(1.0 - rho);
-                c_a = A[kq];
-                c_plain = col_plain[kq];
-            }
+    // per-entry constants of 64 parents at a time, one per lane: logit of the draw, prior log-odds - W·cnt, A
+    auto refresh = [&](const int p64) {
+        const int pp = p64 + lane;
+        if (pp < N) {
+            const size_t kq = (size_t)pp + (size_t)c * N;
+            const double rho = rho_mat ? rho_mat[kq] : rho_scalar;
+            // the Bernoulli rule u <= exp(ll1 - logsumexp(ll0, ll1)) = 1/(1 + e^{-d}) is logit(u) <= d:
+            // the logit is taken here, off the chain, which then carries no exp and no division
+            const double uu = u ? u[kq] : nhp_philox_uniform(seed ^ 0xBE5466CF34E90C6Cull, step, kq);
+            c_uni = nhp_log(uu / (1.0 - uu));
+            c_bias = -(a.W[kq] * a.cnt[pp]) + nhp_log(rho) - nhp_log(1.0 - rho);
+            c_a = A[kq];
         }
+    };
+
+    // ---- a group of g <= 4 independent parents p .. p+g-1 (same 64-chunk): 16 lanes per parent, one entry per
+    // lane, all children distinct -- one LDS read on the chain, no atomics, no ownership marks.  The fp32
+    // screening of the general path applies per parent; if any of them is inside its band all are redone in fp64.
+    auto visit_group = [&](const int p, const int g, const int ck, const double cx) {
+        const int slot = lane >> 4, pp = p + (slot < g ? slot : 0);
+        const double aold = __shfl(c_a, pp & 63), uni_p = __shfl(c_uni, pp & 63), bias_p = __shfl(c_bias, pp & 63);
+        const double lv = ck >= 0 ? lam[ck] : 1.0;
+        const double l0 = ck >= 0 ? lv - aold * cx : 1.0;
+        // hardware reciprocal and log2 (≈1 ulp each): the 1e-3 band below is far wider than their error
+        float t32 = ck >= 0 ? 0.6931471806f * __builtin_amdgcn_logf(1.0f + (float)cx * __builtin_amdgcn_rcpf((float)l0)) : 0.0f;
+        t32 = adj_row_sum_f32(t32);                                  // sum over the parent's 16 lanes
+        const double d32 = bias_p + (double)t32;
+        const bool sure = fabs(uni_p - d32) > 1e-3 * (1.0 + (double)t32);
+        double an = uni_p <= d32 ? 1.0 : 0.0;
+        if (__ballot(!sure && slot < g) != 0ull) {                   // wave-uniform: some parent needs the exact sum
+            double delta = ck >= 0 ? nhp_log(l0 + cx) - nhp_log(l0) : 0.0;
+            delta = nhp_dpp_add(delta, 0); delta = nhp_dpp_add(delta, 1); delta = nhp_dpp_add(delta, 2); delta = nhp_dpp_add(delta, 3);
+            an = uni_p <= bias_p + delta ? 1.0 : 0.0;
+        }
+        if (slot < g) {
+            if ((lane & 15) == 0) A[(size_t)pp + (size_t)c * N] = an;
+            if (an != aold && ck >= 0) lam[ck] = lv + (an - aold) * cx;
+        }
+        // links: one count per parent of the group
+        const unsigned long long heads = __ballot((lane & 15) == 0 && slot < g && an == 1.0);
+        links += (double)__popcll(heads);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the next step reads these λ in program order
+    };
+
+    // ---- one parent alone (a long list, or a child named more than once): lane l owns entries eb + l, eb + l + 64, ...
+    auto visit_general = [&](const int p) {
         const int eb = start[p], ee = start[p + 1];
         const size_t kpc = (size_t)p + (size_t)c * N;
         const double aold = adj_readlane(c_a, p & 63);
         const double uni_p = adj_readlane(c_uni, p & 63), bias_p = adj_readlane(c_bias, p & 63);
-        if (__builtin_amdgcn_readlane(c_plain, p & 63)) {
-            // plain list: every lane's entry is a different child -- one LDS read on the chain, no atomics, no marks
-            const double lv = ck >= 0 ? lam[ck] : 1.0;
-            const double l0 = ck >= 0 ? lv - aold * cx : 1.0;
-            // hardware reciprocal and log2 (≈1 ulp each): the 1e-3 band below is far wider than their error
-            float t32 = ck >= 0 ? 0.6931471806f * __builtin_amdgcn_logf(1.0f + (float)cx * __builtin_amdgcn_rcpf((float)l0)) : 0.0f;
-            t32 = adj_wave_sum_f32(t32);
-            const double d32 = bias_p + (double)t32;
-            double an;
-            if (fabs(uni_p - d32) > 1e-3 * (1.0 + (double)t32)) {
-                an = uni_p <= d32 ? 1.0 : 0.0;
-            } else {
-                const double delta = nhp_wave_sum(ck >= 0 ? nhp_log(l0 + cx) - nhp_log(l0) : 0.0);
-                an = uni_p <= bias_p + delta ? 1.0 : 0.0;
-            }
-            if (lane == 0) A[kpc] = an;
-            links += an;
-            if (an != aold && ck >= 0) lam[ck] = lv + (an - aold) * cx;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the next parent reads these λ in program order
-            return;
-        }
-        if (ck >= 0) atomicAdd(&dx[ck], cx);
-        for (int e = eb + 64 + lane; e < ee; e += 64) atomicAdd(&dx[ent_k[base + e]], ent_x[base + e]);
+        for (int e = eb + lane; e < ee; e += 64) atomicAdd(&dx[ent_k[base + e]], ent_x[base + e]);
         NHP_LDS_SYNC();
-        // this lane's first-chunk entry: the first entry of child k for this p owns the child
-        bool owned = false;
-        double od = 0.0, ol0 = 1.0;
-        if (ck >= 0 && atomicExch(&marker[ck], p + 1) != p + 1) {
-            owned = true;
-            od = dx[ck];
-            ol0 = lam[ck] - aold * od;
-        }
-        // Screening in fp32: d = bias + Σ log(1 + x/λ⁰) only has to be compared with logit(u), and a
-        // single-precision sum settles that unless the two are within its error of each other (about one
-        // decision in a thousand).  The exact fp64 evaluation below then gives the same answer by
-        // construction, so the result does not depend on which path ran; the λ_k updates are always fp64.
-        double anew = -1.0;
-        if (ee - eb <= 64) {
-            float t32 = owned ? __logf(1.0f + (float)od / (float)ol0) : 0.0f;
-            t32 = adj_wave_sum_f32(t32);
-            const double d32 = bias_p + (double)t32;
-            if (fabs(uni_p - d32) > 1e-3 * (1.0 + (double)t32)) anew = uni_p <= d32 ? 1.0 : 0.0;   // NaN/inf fail the test
-        }
-        if (anew < 0.0) {
-            double delta = owned ? nhp_log(ol0 + od) - nhp_log(ol0) : 0.0;
-            for (int e = eb + 64 + lane; e < ee; e += 64) {
-                const int k = ent_k[base + e];
-                if (atomicExch(&marker[k], p + 1) != p + 1) {
-                    const double d = dx[k];
-                    const double l0 = lam[k] - aold * d;
-                    delta += nhp_log(l0 + d) - nhp_log(l0);
-                }
+        double delta = 0.0;
+        for (int e = eb + lane; e < ee; e += 64) {
+            const int k = ent_k[base + e];
+            if (atomicExch(&marker[k], p + 1) != p + 1) {           // first entry of child k for this p owns it
+                const double d = dx[k];
+                const double l0 = lam[k] - aold * d;
+                delta += nhp_log(l0 + d) - nhp_log(l0);
             }
-            delta = nhp_wave_sum(delta);
-            anew = uni_p <= bias_p + delta ? 1.0 : 0.0;            // ll1 - ll0 = bias + delta
         }
+        delta = nhp_wave_sum(delta);
+        const double anew = uni_p <= bias_p + delta ? 1.0 : 0.0;    // ll1 - ll0 = bias + delta
         if (lane == 0) A[kpc] = anew;
         links += anew;
-        auto settle = [&](int k) {
+        for (int e = eb + lane; e < ee; e += 64) {
+            const int k = ent_k[base + e];
             // the first taker carries the child's total
             const double dd = __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long *>(&dx[k]), 0ull));
             if (dd != 0.0 && anew != aold) lam[k] += (anew - aold) * dd;
-        };
-        if (ck >= 0) settle(ck);
-        for (int e = eb + 64 + lane; e < ee; e += 64) settle(ent_k[base + e]);
+        }
         NHP_LDS_SYNC();
     };
-    constexpr int ADJ_AHEAD = 4;
-    int ek[ADJ_AHEAD];
-    double ex[ADJ_AHEAD];
-    auto fetch = [&](const int p, int *k_out, double *x_out) {
+
+    // entry of lane l in the group headed by p: slot l/16 -> parent p + slot, entry start + l%16
+    auto fetch = [&](const int p, const int code, int *k_out, double *x_out) {
         *k_out = -1; *x_out = 0.0;
-        if (p < N) {
-            const int e = start[p] + lane;
-            if (e < start[p + 1]) { *k_out = ent_k[base + e]; *x_out = ent_x[base + e]; }
+        if (p < N && code != 255) {
+            const int slot = lane >> 4;
+            if (slot < code) {
+                const int e = start[p + slot] + (lane & 15);
+                if (e < start[p + slot + 1]) { *k_out = ent_k[base + e]; *x_out = ent_x[base + e]; }
+            }
         }
     };
-#pragma unroll
-    for (int q = 0; q < ADJ_AHEAD; ++q) fetch(q, &ek[q], &ex[q]);
-    for (int p0 = 0; p0 < (NHP_SKIP(a, 64) ? 0 : N); p0 += ADJ_AHEAD) {
-        int nk[ADJ_AHEAD];
-        double nx[ADJ_AHEAD];
-#pragma unroll
-        for (int q = 0; q < ADJ_AHEAD; ++q) fetch(p0 + ADJ_AHEAD + q, &nk[q], &nx[q]);
-#pragma unroll
-        for (int q = 0; q < ADJ_AHEAD; ++q)
-            if (p0 + q < N) visit(p0 + q, ek[q], ex[q]);
-#pragma unroll
-        for (int q = 0; q < ADJ_AHEAD; ++q) { ek[q] = nk[q]; ex[q] = nx[q]; }
+    int p = 0, code = N > 0 ? grp[0] : 255;
+    int ck, nk;
+    double cx, nx;
+    fetch(0, code, &ck, &cx);
+    while (p < (NHP_SKIP(a, 64) ? 0 : N)) {
+        if ((p & 63) == 0 || p == 0) refresh(p & ~63);
+        const int step_len = code == 255 ? 1 : code;
+        const int pn = p + step_len;
+        const int ncode = pn < N ? grp[pn] : 255;
+        fetch(pn, ncode, &nk, &nx);                                  // the next step's entries, in flight under this one
+        if (code == 255) visit_general(p);
+        else visit_group(p, code, ck, cx);
+        // a group never straddles a 64-parent chunk, so the refresh test above sees every chunk start
+        p = pn; code = ncode; ck = nk; cx = nx;
     }
     if (lane == 0 && col_links) col_links[c] = links;
 }
@@ -338,9 +359,9 @@ extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_d
     int max_children = 1;
     for (size_t c = 0; c < N; ++c) max_children = std::max(max_children, ds->h_boff[c + 1] - ds->h_boff[c]);
     const bool expo = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
-    const size_t lds_build = 4 * (2 * N + 2 + NHP_BLOCK);
+    const size_t lds_build = 4 * (2 * N + 2 + NHP_BLOCK + (size_t)max_children);
     const size_t lds_eval = (expo ? 16 : 24) * N + 8 * N + 8 * (size_t)max_children;
-    const size_t lds_sweep = 20 * (size_t)max_children + 4 * (N + 2);
+    const size_t lds_sweep = 20 * (size_t)max_children + 4 * (N + 2) + N + 8;
     if (lds_build > 160 * 1024 || lds_eval > 160 * 1024 || lds_sweep > 160 * 1024) {
         nhp_set_error(ctx, "resample_adjacency: a node with %d events (N = %d) exceeds the 160 KiB LDS column state", max_children, ds->N);
         return NHP_ENOTIMPL;
@@ -352,16 +373,16 @@ extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_d
         nhp_cont_dataset *mds = const_cast<nhp_cont_dataset *>(ds);
         if (hipMalloc((void **)&mds->d_adj_k, 4 * P) != hipSuccess || hipMalloc((void **)&mds->d_adj_p, 4 * P) != hipSuccess ||
             hipMalloc((void **)&mds->d_adj_dt, 8 * P) != hipSuccess || hipMalloc((void **)&mds->d_adj_start, 4 * N * (N + 1)) != hipSuccess ||
-            hipMalloc((void **)&mds->d_adj_off, 8 * (N + 1)) != hipSuccess || hipMalloc((void **)&mds->d_adj_plain, NN) != hipSuccess) {
-            (void)hipFree(mds->d_adj_k); (void)hipFree(mds->d_adj_p); (void)hipFree(mds->d_adj_dt); (void)hipFree(mds->d_adj_start); (void)hipFree(mds->d_adj_off); (void)hipFree(mds->d_adj_plain);
-            mds->d_adj_plain = nullptr; mds->d_adj_k = nullptr; mds->d_adj_p = nullptr; mds->d_adj_dt = nullptr; mds->d_adj_start = nullptr; mds->d_adj_off = nullptr;
+            hipMalloc((void **)&mds->d_adj_off, 8 * (N + 1)) != hipSuccess || hipMalloc((void **)&mds->d_adj_group, NN) != hipSuccess) {
+            (void)hipFree(mds->d_adj_k); (void)hipFree(mds->d_adj_p); (void)hipFree(mds->d_adj_dt); (void)hipFree(mds->d_adj_start); (void)hipFree(mds->d_adj_off); (void)hipFree(mds->d_adj_group);
+            mds->d_adj_group = nullptr; mds->d_adj_k = nullptr; mds->d_adj_p = nullptr; mds->d_adj_dt = nullptr; mds->d_adj_start = nullptr; mds->d_adj_off = nullptr;
             nhp_set_error(ctx, "resample_adjacency: out of device memory for %zu cached pairs", P);
             return NHP_ENOMEM;
         }
         NHP_HIP(ctx, hipMemcpyAsync(mds->d_adj_off, ds->h_pair_off.data(), 8 * (N + 1), hipMemcpyHostToDevice, st));
         if (lds_build > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
         hipLaunchKernelGGL(k_adj_build, dim3((unsigned)N), dim3(NHP_BLOCK), lds_build, st, a, ds->d_adj_off, ds->group, mds->d_adj_k,
-                           mds->d_adj_p, mds->d_adj_dt, mds->d_adj_start, mds->d_adj_plain);
+                           mds->d_adj_p, mds->d_adj_dt, mds->d_adj_start, mds->d_adj_group, max_children);
         NHP_HIP(ctx, hipGetLastError());
     }
     const size_t M1 = (size_t)(ds->M > 0 ? ds->M : 1);
@@ -389,7 +410,7 @@ extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_d
     }
     NHP_HIP(ctx, hipGetLastError());
     if (lds_sweep > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sweep));
-    hipLaunchKernelGGL(k_adj_sweep, dim3((unsigned)N), dim3(64), lds_sweep, st, a, m->d_A, d_off, d_k, d_x, d_start, ds->d_adj_plain, d_lam,
+    hipLaunchKernelGGL(k_adj_sweep, dim3((unsigned)N), dim3(64), lds_sweep, st, a, m->d_A, d_off, d_k, d_x, d_start, ds->d_adj_group, d_lam,
                        d_rho, rho, d_u, seed, step, max_children, d_links);
     NHP_HIP(ctx, hipGetLastError());
     std::vector<double> links(N);

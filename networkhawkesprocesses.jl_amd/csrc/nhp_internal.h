@@ -80,7 +80,7 @@ struct nhp_cont_dataset {
     double *d_adj_dt = nullptr;                       // [pairs] t_child - t_parent
     int32_t *d_adj_start = nullptr;                   // [N*(N+1)] per-column offsets by parent node
     int64_t *d_adj_off = nullptr;                     // [N+1] first pair of each column
-    unsigned char *d_adj_plain = nullptr;             // [N*N] 1: the list of (p, c) has <= 64 entries, all different children
+    unsigned char *d_adj_group = nullptr;             // [N*N] grouping code of entry (p, c): see k_adj_build
     // host copies kept for host-side helpers
     std::vector<int32_t> h_boff;
     std::vector<double> h_cnt;
