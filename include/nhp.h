@@ -248,6 +248,14 @@ nhp_status nhp_disc_vb_step(nhp_ctx *ctx, const nhp_disc_dataset *ds, double dt,
 nhp_status nhp_disc_resample_parents(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
                                      const double *W, const double *theta, const double *A, double dt,
                                      uint64_t seed, uint64_t step, int64_t *counts);
+/* resample!(process::DiscreteStandardHawkesProcess, data, convolved)  src/discrete.jl:362-368 in one call: the
+ * parent counts above, then the conjugate draws on the device (Philox-keyed; distributional parity with Julia):
+ * λ0 ~ Gamma(α0 + counts[:, 0], 1/(β0 + T dt)) (the intended form of src/baselines.jl:413-419),
+ * W ~ Gamma(κ + Σ_b counts, 1/(ν + Σ_t data[p, :]))  src/weights.jl:59-64,
+ * θ[p, c, :] ~ Dirichlet(γ + counts)  src/impulses.jl:337-353.  lambda0, W, theta are read and overwritten. */
+nhp_status nhp_disc_gibbs_step(nhp_ctx *ctx, const nhp_disc_dataset *ds, double *lambda0, double *W, double *theta,
+                               const double *A, double dt, double alpha0, double beta0, double kappa, double nu,
+                               double gamma0, uint64_t seed, uint64_t step);
 /* resample_adjacency_matrix!(process::DiscreteNetworkHawkesProcess, data, convolved)
  * src/discrete.jl:424-480: one Gibbs sweep over A [N*N] (host, updated in place), columns in parallel,
  * entries of a column in sequence, each conditional on the current column.  Link probabilities

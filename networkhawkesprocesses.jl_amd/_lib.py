@@ -82,6 +82,7 @@ def _declare(lib):
     f("nhp_disc_lgcp_loglik", i32, _vp, _vp, _dp, dbl, _dp)
     f("nhp_disc_loglik_grad", i32, _vp, _vp, _dp, _dp, _dp, dbl, _dp, _dp, i64)
     f("nhp_disc_resample_parents", i32, _vp, _vp, _dp, _dp, _dp, _dp, dbl, u64, u64, _ip)
+    f("nhp_disc_gibbs_step", i32, _vp, _vp, _dp, _dp, _dp, _dp, dbl, dbl, dbl, dbl, dbl, dbl, u64, u64)
     f("nhp_disc_resample_adjacency", i32, _vp, _vp, _dp, _dp, _dp, _dp, dbl, _dp, dbl, _dp, u64, u64, _dp)
     f("nhp_cont_resample_adjacency", i32, _vp, _vp, _vp, _dp, dbl, _dp, u64, u64, _dp, _dp)
     f("nhp_probe_math", i32, _vp, i32, _dp, _dp, i64, _dp)

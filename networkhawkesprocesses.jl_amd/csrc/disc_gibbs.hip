@@ -6,6 +6,7 @@
 
 #include "nhp_internal.h"
 #include "nhp_math.h"
+#include "nhp_rng.h"
 
 // ---- discrete Gibbs parent counts (reference resample_parents / resample_parent
 // src/parents.jl:82-116 reduced over time to counts[c + N·k] = Σ_t parents[t, c, k], which is all the
@@ -188,15 +189,16 @@ __global__ __launch_bounds__(256, 3) void k_disc_resample_parents(const double *
     }
 }
 
-extern "C" nhp_status nhp_disc_resample_parents(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
-                                                const double *W, const double *theta, const double *A, double dt,
-                                                uint64_t seed, uint64_t step, int64_t *counts)
+// Runs the parent-count sweep; *d_counts_out (int [N*(1+K)], index c + N*k) stays in ctx scratch until the next call.
+static nhp_status disc_parent_counts(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0, const double *W,
+                                     const double *theta, const double *A, double dt, uint64_t seed, uint64_t step,
+                                     size_t extra_doubles, int **d_counts_out, double **extra_out, double **dW_out,
+                                     double **dth_out, double **dl0_out)
 {
-    if (!ctx || !ds || !counts) return NHP_EINVAL;
     NHP_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t N = (size_t)ds->N, K = N * (size_t)ds->B, NC = N * (1 + K);
+    const size_t N = (size_t)ds->N, NN = N * N, K = N * (size_t)ds->B, NC = N * (1 + K);
     double *E2, *base, *extra;
-    NHP_TRY(nhp_disc_stage_bump(ctx, ds, lambda0, W, theta, A, dt, &E2, &base, (NC + 1) / 2 + 1, &extra, 1));
+    NHP_TRY(nhp_disc_stage_bump(ctx, ds, lambda0, W, theta, A, dt, &E2, &base, (NC + 1) / 2 + 1 + extra_doubles, &extra, 1));
     int *d_counts = reinterpret_cast<int *>(extra);
     hipStream_t st = ctx->stream;
     NHP_HIP(ctx, hipMemsetAsync(d_counts, 0, sizeof(int) * NC, st));
@@ -209,10 +211,79 @@ extern "C" nhp_status nhp_disc_resample_parents(nhp_ctx *ctx, const nhp_disc_dat
                        lambda0 ? nullptr : ds->d_baseT, ds->T, ds->N, ds->B, b_magic, seed, step, d_counts, ds->d_base_counts);
     if (ds->d_base_counts) const_cast<nhp_disc_dataset *>(ds)->base_counts_valid = true;
     NHP_HIP(ctx, hipGetLastError());
+    *d_counts_out = d_counts;
+    if (extra_out) *extra_out = extra + (NC + 1) / 2 + 1;
+    // stage_bump's layout after E: base (N) | λ0 (N) | W (N²) | θ (N²B) | A (N²) | extra
+    if (dl0_out) *dl0_out = base + N;
+    if (dW_out) *dW_out = base + 2 * N;
+    if (dth_out) *dth_out = base + 2 * N + NN;
+    return NHP_OK;
+}
+
+extern "C" nhp_status nhp_disc_resample_parents(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
+                                                const double *W, const double *theta, const double *A, double dt,
+                                                uint64_t seed, uint64_t step, int64_t *counts)
+{
+    if (!ctx || !ds || !counts) return NHP_EINVAL;
+    const size_t N = (size_t)ds->N, NC = N * (1 + N * (size_t)ds->B);
+    int *d_counts;
+    NHP_TRY(disc_parent_counts(ctx, ds, lambda0, W, theta, A, dt, seed, step, 0, &d_counts, nullptr, nullptr, nullptr, nullptr));
+    hipStream_t st = ctx->stream;
     std::vector<int> h((size_t)NC);
     NHP_HIP(ctx, hipMemcpyAsync(h.data(), d_counts, sizeof(int) * NC, hipMemcpyDeviceToHost, st));
     NHP_HIP(ctx, hipStreamSynchronize(st));
     for (size_t i = 0; i < NC; ++i) counts[i] = h[i];
+    return NHP_OK;
+}
+
+// ---- conjugate draws of the discrete resample! methods on the device (src/baselines.jl:413-419 as intended (D2),
+// src/weights.jl:59-64, src/impulses.jl:337-353): λ0_c ~ Gamma(α0 + counts[c, 0], 1/(β0 + T·dt));
+// W[p,c] ~ Gamma(κ + Σ_b counts[c, 1+pB+b], 1/(ν + Σ_t data[p, t])); θ[p,c,:] ~ Dirichlet(γ + counts[c, 1+pB+·])
+// as normalised Gamma(·, 1) draws.  Philox-keyed like the continuous draws: distributional parity with Julia.
+__global__ __launch_bounds__(256) void k_disc_gibbs_draw(int N, int B, double Tdt, double alpha0, double beta0, double kappa,
+                                                         double nu, double gamma0, uint64_t seed, uint64_t step,
+                                                         const int *__restrict__ counts, const double *__restrict__ node_counts,
+                                                         double *__restrict__ lambda0, double *__restrict__ W,
+                                                         double *__restrict__ theta)
+{
+    const size_t NN = (size_t)N * N;
+    const size_t pc = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (pc < (size_t)N)
+        lambda0[pc] = dev_gamma(alpha0 + (double)counts[pc], 1.0 / (beta0 + Tdt), seed ^ 0x243F6A8885A308D3ull, step, pc);
+    if (pc >= NN) return;
+    const size_t p = pc % N, c = pc / N;
+    double m = 0.0, gs = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const double cnt = (double)counts[c + (size_t)N * (1 + p * B + b)];
+        m += cnt;
+        const double gv = dev_gamma(gamma0 + cnt, 1.0, seed ^ 0xA4093822299F31D0ull, step, pc + (size_t)b * NN);
+        theta[pc + (size_t)b * NN] = gv;
+        gs += gv;
+    }
+    for (int b = 0; b < B; ++b) theta[pc + (size_t)b * NN] /= gs;
+    W[pc] = dev_gamma(kappa + m, 1.0 / (nu + node_counts[p]), seed ^ 0x13198A2E03707344ull, step, pc);
+}
+
+// resample!(process::DiscreteStandardHawkesProcess, data, convolved) src/discrete.jl:362-368 in one call: parent
+// counts, then the conjugate draws, all on the device; lambda0 [N], W [N*N], theta [N*N*B] are read and overwritten.
+extern "C" nhp_status nhp_disc_gibbs_step(nhp_ctx *ctx, const nhp_disc_dataset *ds, double *lambda0, double *W,
+                                          double *theta, const double *A, double dt, double alpha0, double beta0,
+                                          double kappa, double nu, double gamma0, uint64_t seed, uint64_t step)
+{
+    if (!ctx || !ds || !lambda0 || !W || !theta) return NHP_EINVAL;
+    const size_t N = (size_t)ds->N, NN = N * N, B = (size_t)ds->B;
+    int *d_counts;
+    double *dW, *dth, *dl0;
+    NHP_TRY(disc_parent_counts(ctx, ds, lambda0, W, theta, A, dt, seed, step, 0, &d_counts, nullptr, &dW, &dth, &dl0));
+    hipStream_t st = ctx->stream;
+    // Σ_t data[p, t] = node_counts(data): the first half of the dataset's column statistics
+    hipLaunchKernelGGL(k_disc_gibbs_draw, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, st, (int)N, (int)B, (double)ds->T * dt,
+                       alpha0, beta0, kappa, nu, gamma0, seed, step, d_counts, ds->d_colsum, dl0, dW, dth);
+    NHP_HIP(ctx, hipGetLastError());
+    NHP_HIP(ctx, hipMemcpyAsync(lambda0, dl0, 8 * N, hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipMemcpyAsync(W, dW, 8 * NN, hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipMemcpyAsync(theta, dth, 8 * NN * B, hipMemcpyDeviceToHost, st));
+    NHP_HIP(ctx, hipStreamSynchronize(st));
     return NHP_OK;
 }
 

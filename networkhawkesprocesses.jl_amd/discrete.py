@@ -492,7 +492,7 @@ def disc_resample_adjacency_matrix_(process, data=None, convolved=None, u=None, 
     return nl.value
 
 
-def disc_resample_(process, data, convolved, rng, seed=0, step=0, ctx=None):
+def disc_resample_(process, data, convolved, rng, seed=0, step=0, ctx=None, device_draws=True):
     """resample!(process::DiscreteStandardHawkesProcess, data, convolved) -- src/discrete.jl:362-368, and the
     network twin :416-424 (adds the adjacency sweep and the network's ρ).
 
@@ -505,8 +505,19 @@ def disc_resample_(process, data, convolved, rng, seed=0, step=0, ctx=None):
     ctx = ctx or _lib.default_context()
     ds = _convolved(process, data, convolved, ctx)
     N, B = ds.N, ds.B
-    counts = resample_parent_counts(process, convolved=ds, seed=seed, step=step, ctx=ctx)
     b, w, imp = process.baseline, process.weights, process.impulses
+    if device_draws and isinstance(b, DiscreteHomogeneousProcess):
+        # parents and conjugate draws in one GPU call (nhp_disc_gibbs_step): only the new parameters come back
+        l0, W, th, A = process._lowered()
+        l0, W, th = l0.copy(), W.copy(), th.copy()
+        _lib.check(_lib.lib().nhp_disc_gibbs_step(ctx.h, ds.h, _lib.dptr(l0), _lib.dptr(W), _lib.dptr(th), _lib.dptr(A), process.dt,
+                                                  b.α0, b.β0, w.κ, w.ν, imp.γ, seed, step), ctx.h)
+        b.λ, w.W, imp.θ = l0, W.reshape((N, N), order="F"), th.reshape((N, N, B), order="F")
+        if isinstance(process, DiscreteNetworkHawkesProcess):
+            links = disc_resample_adjacency_matrix_(process, convolved=ds, seed=seed, step=step, ctx=ctx)
+            process.network.resample_links_(links, N * N, rng)
+        return process.params()
+    counts = resample_parent_counts(process, convolved=ds, seed=seed, step=step, ctx=ctx)
     if isinstance(b, DiscreteLogGaussianCoxProcess):
         b.resample_(ds, rng)              # elliptical slice on parents[:, :, 1], left on the device by the sweep above
     else:
@@ -522,7 +533,7 @@ def disc_resample_(process, data, convolved, rng, seed=0, step=0, ctx=None):
     return process.params()
 
 
-def disc_mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, ctx=None):
+def disc_mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, ctx=None, device_draws=True):
     """mcmc!(process::DiscreteHawkesProcess, data) -- src/inference.jl:49-70: convolve once, then
     resample!(process, data, convolved) per step."""
     import time
@@ -533,7 +544,7 @@ def disc_mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, 
     res = MarkovChainMonteCarlo()
     start = time.time()
     while res.steps < nsteps:
-        res.samples.append(disc_resample_(process, None, ds, rng, seed=seed, step=res.steps, ctx=ctx))
+        res.samples.append(disc_resample_(process, None, ds, rng, seed=seed, step=res.steps, ctx=ctx, device_draws=device_draws))
         res.steps += 1
         if res.steps % log_freq == 0 and verbose:
             res.elapsed = time.time() - start

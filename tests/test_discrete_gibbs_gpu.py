@@ -132,3 +132,37 @@ def test_empty_and_tiny_data(nhp, orc):
     dsa, conva = nhp.convolve(p1, d1, fetch=True)
     assert np.array_equal(nhp.resample_parent_counts(p1, convolved=dsa, seed=2, step=3),
                           orc.disc_resample_parents(d1, conva, p1.baseline.λ, p1.weights.W, p1.impulses.θ, p1.dt, seed=2, step=3))
+
+
+def test_device_draws_follow_their_conjugate_posteriors(nhp):
+    # nhp_disc_gibbs_step: with parameters that make the counts (nearly) deterministic -- W = 0: every event is a
+    # baseline event -- the draws must match Gamma(α0 + Σ data, 1/(β0 + T dt)), Gamma(κ, 1/(ν + Σ data[p])), Dirichlet(γ)
+    rng = np.random.default_rng(5)
+    N, T, B, L = 4, 4000, 3, 5
+    data = rng.poisson(0.3, (N, T)).astype(np.int64)
+    draws_l, draws_W, draws_t = [], [], []
+    for s in range(200):
+        th = np.full((N, N, B), 0.25); th[:, :, -1] = 0.5
+        proc = nhp.DiscreteStandardHawkesProcess(nhp.DiscreteHomogeneousProcess(np.full(N, 0.3), 1.0),
+                                                 nhp.DiscreteGaussianImpulseResponse(th, L, 1.0),
+                                                 nhp.DenseWeightModel(np.zeros((N, N))), 1.0)
+        nhp.resample_(proc, data, None, rng, seed=7, step=s)
+        draws_l.append(proc.baseline.λ.copy()); draws_W.append(proc.weights.W.copy()); draws_t.append(proc.impulses.θ.copy())
+    lam, W, th = np.mean(draws_l, axis=0), np.mean(draws_W, axis=0), np.mean(draws_t, axis=0)
+    cnt = data.sum(axis=1)
+    assert np.all(np.abs(lam - (1 + cnt) / (1 + T)) / ((1 + cnt) / (1 + T)) < 0.02)
+    want_W = 1.0 / (1.0 + cnt)[:, None] * np.ones((N, N))                    # Gamma(1, 1/(1 + Mn[p])) mean
+    assert np.all(np.abs(W - want_W) / want_W < 0.25)
+    assert np.all(np.abs(th - 1.0 / B) < 0.06)                               # Dirichlet(1,1,1) mean
+    assert np.allclose(np.sum(draws_t[0], axis=2), 1.0)
+    # the host-draw path samples the same posteriors
+    draws = []
+    for s_ in range(100):
+        th = np.full((N, N, B), 0.25); th[:, :, -1] = 0.5
+        proc = nhp.DiscreteStandardHawkesProcess(nhp.DiscreteHomogeneousProcess(np.full(N, 0.3), 1.0),
+                                                 nhp.DiscreteGaussianImpulseResponse(th, L, 1.0),
+                                                 nhp.DenseWeightModel(np.zeros((N, N))), 1.0)
+        nhp.resample_(proc, data, None, rng, seed=9, step=s_, device_draws=False)
+        draws.append(proc.baseline.λ.copy())
+    lam2 = np.mean(draws, axis=0)
+    assert np.all(np.abs(lam2 - (1 + cnt) / (1 + T)) / ((1 + cnt) / (1 + T)) < 0.02)
