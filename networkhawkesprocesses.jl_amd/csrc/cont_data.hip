@@ -23,7 +23,7 @@ static nhp_status upload(nhp_ctx *ctx, T **dst, const T *src, size_t n)
     return NHP_OK;
 }
 
-static int pick_group(double kbar)
+int nhp_pick_group(double kbar)
 {
     const char *env = getenv("NHP_GROUP");
     if (env) {
@@ -73,10 +73,11 @@ extern "C" nhp_status nhp_cont_dataset_create(nhp_ctx *ctx, const double *events
         pairs += i - f;
     }
     ds->pairs = pairs;
+    for (int64_t i = 0; i < M && events[i] == 0.0; ++i) ds->n_zero_time = i + 1;
     ds->h_pair_off.assign((size_t)N + 1, 0);
     for (int64_t i = 0; i < M; ++i) ds->h_pair_off[node32[i] + 1] += i - first[i];
     for (int32_t c = 0; c < N; ++c) ds->h_pair_off[c + 1] += ds->h_pair_off[c];
-    ds->group = pick_group(M > 0 ? (double)pairs / (double)M : 0.0);
+    ds->group = nhp_pick_group(M > 0 ? (double)pairs / (double)M : 0.0);
 
     // stable counting sort of children by node
     ds->h_boff.assign((size_t)N + 1, 0);
@@ -196,7 +197,7 @@ extern "C" void nhp_cont_dataset_destroy(nhp_cont_dataset *ds)
     (void)hipStreamSynchronize(ds->ctx->stream);
     (void)hipFree(ds->d_times); (void)hipFree(ds->d_nodes); (void)hipFree(ds->d_child); (void)hipFree(ds->d_child_w); (void)hipFree(ds->d_ev);
     (void)hipFree(ds->d_boff); (void)hipFree(ds->d_items); (void)hipFree(ds->d_cnt); (void)hipFree(ds->d_pn);
-    (void)hipFree(ds->d_adj_k); (void)hipFree(ds->d_adj_p); (void)hipFree(ds->d_adj_dt); (void)hipFree(ds->d_adj_start); (void)hipFree(ds->d_adj_off); (void)hipFree(ds->d_adj_group);
+    (void)hipFree(ds->d_adj_k); (void)hipFree(ds->d_adj_p); (void)hipFree(ds->d_adj_dt); (void)hipFree(ds->d_adj_start); (void)hipFree(ds->d_adj_off); (void)hipFree(ds->d_adj_group); (void)hipFree(ds->d_child_cut);
     delete ds;
 }
 
@@ -227,6 +228,7 @@ static nhp_status check_desc(nhp_ctx *ctx, const nhp_cont_model_desc *d)
 
 static nhp_status copy_params(nhp_ctx *ctx, nhp_cont_model *m, const nhp_cont_model_desc *d)
 {
+    ++m->version;
     size_t NN = (size_t)m->N * m->N;
     size_t nl = m->baseline_kind == NHP_BASELINE_LGCP ? (size_t)m->N * m->grid_n : (size_t)m->N;
     hipStream_t st = ctx->stream;
@@ -301,6 +303,7 @@ extern "C" nhp_status nhp_cont_model_set_params(nhp_ctx *ctx, nhp_cont_model *m,
         return NHP_ESHAPE;
     }
     NHP_HIP(ctx, hipSetDevice(ctx->device));
+    ++m->version;
     hipStream_t st = ctx->stream;
     NHP_HIP(ctx, hipMemcpyAsync(m->d_lambda0, x, sizeof(double) * nb, hipMemcpyHostToDevice, st));
     NHP_HIP(ctx, hipMemcpyAsync(m->d_p1, x + nb, sizeof(double) * NN, hipMemcpyHostToDevice, st));

@@ -285,7 +285,12 @@ extern "C" nhp_status nhp_cont_loglik_grad(nhp_ctx *ctx, const nhp_cont_dataset 
     double *d_grad = (double *)ctx->d_scratch, *d_lambda = d_grad + P;
     nhp_cont_args a = nhp_make_args(ds, m);
     hipStream_t st = ctx->stream;
-    if ((flags & NHP_LL_RECURSIVE) && exp_imp) {
+    // the recursive formulation through its truncated window when the bound allows (cont_recursive.hip): the windowed
+    // gradient on the other window starts, with the recursion's unmasked integral
+    const nhp_child *child_cut = nullptr;
+    int cut_group = 0;
+    if ((flags & NHP_LL_RECURSIVE) && exp_imp) NHP_TRY(nhp_recursive_window(ctx, ds, m, &child_cut, &cut_group));
+    if ((flags & NHP_LL_RECURSIVE) && exp_imp && !child_cut) {
         const size_t lds = 8 * (4 + NHP_WAVES + 8 * N);
         if (lds > 160 * 1024) { nhp_set_error(ctx, "recursive gradient: n_nodes = %d exceeds the LDS budget", ds->N); return NHP_ENOTIMPL; }
         if (lds > 64 * 1024)
@@ -299,15 +304,18 @@ extern "C" nhp_status nhp_cont_loglik_grad(nhp_ctx *ctx, const nhp_cont_dataset 
         NHP_HIP(ctx, hipGetLastError());
         NHP_TRY(nhp_launch_finalize(ctx, a, (int)N, ctx->d_results));
     } else {
-        hipLaunchKernelGGL(k_grad_init, dim3(1024), dim3(256), 0, st, a, 1, d_grad);
+        const int mask = child_cut ? 0 : 1;
+        const int G = child_cut ? cut_group : ds->group;
+        if (child_cut) { a.child = child_cut; a.child_w = child_cut; }
+        hipLaunchKernelGGL(k_grad_init, dim3(1024), dim3(256), 0, st, a, mask, d_grad);
         NHP_HIP(ctx, hipGetLastError());
-        NHP_TRY(nhp_launch_event_intensity(ctx, ds, m, d_lambda));          // pass A: partials + λ_i
+        NHP_TRY(nhp_launch_event_intensity_as(ctx, ds, m, child_cut, G, mask, d_lambda));   // pass A: partials + λ_i
         NHP_TRY(nhp_launch_finalize(ctx, a, ds->n_items, ctx->d_results));
         const size_t lds = 32 + 16 * N + 8 * N * (exp_imp ? 2 : 3);
         if (lds > 160 * 1024) { nhp_set_error(ctx, "gradient: n_nodes = %d exceeds the 160 KiB LDS budget", ds->N); return NHP_ENOTIMPL; }
         dim3 grid((unsigned)ds->n_items);
-        if (exp_imp) launch_grad_group<NHP_IMPULSE_EXPONENTIAL>(ds->group, grid, lds, st, a, d_lambda, d_grad);
-        else launch_grad_group<NHP_IMPULSE_LOGITNORMAL>(ds->group, grid, lds, st, a, d_lambda, d_grad);
+        if (exp_imp) launch_grad_group<NHP_IMPULSE_EXPONENTIAL>(G, grid, lds, st, a, d_lambda, d_grad);
+        else launch_grad_group<NHP_IMPULSE_LOGITNORMAL>(G, grid, lds, st, a, d_lambda, d_grad);
         NHP_HIP(ctx, hipGetLastError());
     }
     NHP_HIP(ctx, hipMemcpyAsync(grad, d_grad, 8 * P, hipMemcpyDeviceToHost, st));

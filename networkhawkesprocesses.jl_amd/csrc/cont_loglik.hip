@@ -291,7 +291,8 @@ static void launch_group(int G, dim3 grid, size_t lds, hipStream_t st, const nhp
 }
 
 static nhp_status run_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m,
-                               double *d_out, double *d_lambda)
+                               double *d_out, double *d_lambda, const nhp_child *child_w = nullptr, int group = 0,
+                               int mask_integral = 1)
 {
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t per = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? 16 : 24;
@@ -299,11 +300,13 @@ static nhp_status run_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const n
     if (lds > 160 * 1024) { nhp_set_error(ctx, "n_nodes = %d exceeds the 160 KiB LDS column budget", ds->N); return NHP_ENOTIMPL; }
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)ds->n_items));
     nhp_cont_args a = nhp_make_args(ds, m);
+    if (child_w) a.child_w = child_w;                     // same children, other window starts (recursive path)
+    const int G = group ? group : ds->group;
     dim3 grid((unsigned)ds->n_items);
     if (m->impulse_kind == NHP_IMPULSE_EXPONENTIAL)
-        launch_group<NHP_IMPULSE_EXPONENTIAL>(ds->group, grid, lds, ctx->stream, a, 1, ctx->d_partials, d_lambda, ctx->d_counter, d_out);
+        launch_group<NHP_IMPULSE_EXPONENTIAL>(G, grid, lds, ctx->stream, a, mask_integral, ctx->d_partials, d_lambda, ctx->d_counter, d_out);
     else
-        launch_group<NHP_IMPULSE_LOGITNORMAL>(ds->group, grid, lds, ctx->stream, a, 1, ctx->d_partials, d_lambda, ctx->d_counter, d_out);
+        launch_group<NHP_IMPULSE_LOGITNORMAL>(G, grid, lds, ctx->stream, a, mask_integral, ctx->d_partials, d_lambda, ctx->d_counter, d_out);
     NHP_HIP(ctx, hipGetLastError());
     return NHP_OK;
 }
@@ -318,6 +321,18 @@ nhp_status nhp_launch_finalize(nhp_ctx *ctx, const nhp_cont_args &a, int n_parti
 nhp_status nhp_launch_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_out)
 {
     return run_windowed(ctx, ds, m, d_out, nullptr);
+}
+
+nhp_status nhp_launch_windowed_as(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, const nhp_child *child_w,
+                                  int group, int mask_integral, double *d_out)
+{
+    return run_windowed(ctx, ds, m, d_out, nullptr, child_w, group, mask_integral);
+}
+
+nhp_status nhp_launch_event_intensity_as(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, const nhp_child *child_w,
+                                         int group, int mask_integral, double *d_lambda)
+{
+    return run_windowed(ctx, ds, m, nullptr, d_lambda, child_w, group, mask_integral);
 }
 
 nhp_status nhp_launch_event_intensity(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_lambda)

@@ -21,6 +21,7 @@
 #include "nhp_math.h"
 
 #define NHP_RING 64   // children whose wave partials are buffered before the log pass
+#define NHP_REC_PAIR_SLOT 70   // a free 128-byte line of ctx->d_counter (lines 0..64 are the ll kernel's tickets)
 
 __device__ __forceinline__ double rec_baseline(const nhp_cont_args &a, int c, double t)
 {
@@ -144,7 +145,151 @@ __global__ __launch_bounds__(BLOCK) void k_recursive(nhp_cont_args a, double *__
     }
 }
 
+// ---- the same sum through a truncated window ------------------------------------------------------------
+// The recursion adds, for child i, EVERY earlier event j with weight (a·w·θ)·e^{-θ(t_i - t_j)}.  Events older than
+//     cut = ln( M · max(w·θ) / (min λ0 · 2^-60) ) / min θ
+// contribute, all together, less than 2^-60 of λ_i (λ_i >= λ0_c, at most M of them, each below max(wθ)·e^{-minθ·cut}),
+// i.e. nothing an fp64 sum of the kept terms can register.  When that window is short compared with the 2·N
+// exponentials per event of the recursion, the windowed kernel (H1) evaluates the full-history sum instead: same
+// parents in the same time order, the recursion's two quirks kept (events at exactly t = 0 skipped, D9; integral
+// term not masked by A, D7).  The bound is recomputed when the parameters change; without a positive λ0 and θ, or
+// with a long window, the O(M·N) recursion below runs.
+__global__ __launch_bounds__(256) void k_rec_stats(nhp_cont_args a, double *__restrict__ out /* [3 * gridDim.x] */)
+{
+    __shared__ double r0[NHP_WAVES], r1[NHP_WAVES], r2[NHP_WAVES];
+    const size_t NN = (size_t)a.N * a.N, nl = a.baseline_kind == NHP_BASELINE_HOMOGENEOUS ? (size_t)a.N : (size_t)a.N * a.grid_n;
+    double tmin = __builtin_inf(), wmax = 0.0, lmin = __builtin_inf();
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < NN; k += (size_t)gridDim.x * 256) {
+        const double th = a.p1[k], wt = a.W[k] * th;
+        tmin = th < tmin || th != th ? th : tmin;
+        wmax = wt > wmax || wt != wt ? wt : wmax;
+    }
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < nl; k += (size_t)gridDim.x * 256) {
+        const double l = a.lambda0[k];
+        lmin = l < lmin || l != l ? l : lmin;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double t2 = __shfl_xor(tmin, off), w2 = __shfl_xor(wmax, off), l2 = __shfl_xor(lmin, off);
+        tmin = t2 < tmin || t2 != t2 ? t2 : tmin;
+        wmax = w2 > wmax || w2 != w2 ? w2 : wmax;
+        lmin = l2 < lmin || l2 != l2 ? l2 : lmin;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { r0[wave] = tmin; r1[wave] = wmax; r2[wave] = lmin; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < NHP_WAVES; ++w) {
+            tmin = r0[w] < tmin || r0[w] != r0[w] ? r0[w] : tmin;
+            wmax = r1[w] > wmax || r1[w] != r1[w] ? r1[w] : wmax;
+            lmin = r2[w] < lmin || r2[w] != r2[w] ? r2[w] : lmin;
+        }
+        out[3 * blockIdx.x] = tmin; out[3 * blockIdx.x + 1] = wmax; out[3 * blockIdx.x + 2] = lmin;
+    }
+}
+
+// child_cut[k] = child[k] with window start = first event with t_j > t_i - cut, never before the events at t = 0
+__global__ __launch_bounds__(256) void k_rec_windows(const nhp_child *__restrict__ child, const double *__restrict__ times,
+                                                     int64_t M, double cut, int n_zero, nhp_child *__restrict__ child_cut,
+                                                     unsigned long long *__restrict__ pairs)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long mine = 0;
+    if (k < M) {
+        nhp_child ch = child[k];
+        const double lim = ch.t - cut;
+        int lo = n_zero, hi = ch.idx;                       // first j in [n_zero, idx] with times[j] > lim
+        if (lo > hi) lo = hi;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (times[mid] > lim) hi = mid; else lo = mid + 1; }
+        ch.first = lo;
+        child_cut[k] = ch;
+        mine = (unsigned long long)(ch.idx - lo);
+    }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(pairs, mine);
+}
+
+// cut for this model (cached per parameter version); 0 = no usable bound
+static nhp_status rec_cut_for(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *cut)
+{
+    if (m->rec_version == m->version) { *cut = m->rec_cut; return NHP_OK; }
+    const int blocks = 64;
+    NHP_TRY(nhp_ctx_reserve_partials(ctx, 3 * (size_t)blocks));
+    nhp_cont_args a = nhp_make_args(ds, m);
+    hipLaunchKernelGGL(k_rec_stats, dim3(blocks), dim3(256), 0, ctx->stream, a, ctx->d_partials);
+    NHP_HIP(ctx, hipGetLastError());
+    double h[3 * 64];
+    NHP_HIP(ctx, hipMemcpyAsync(h, ctx->d_partials, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double tmin = h[0], wmax = h[1], lmin = h[2];
+    for (int b = 1; b < blocks; ++b) {
+        if (h[3 * b] < tmin || h[3 * b] != h[3 * b]) tmin = h[3 * b];
+        if (h[3 * b + 1] > wmax || h[3 * b + 1] != h[3 * b + 1]) wmax = h[3 * b + 1];
+        if (h[3 * b + 2] < lmin || h[3 * b + 2] != h[3 * b + 2]) lmin = h[3 * b + 2];
+    }
+    double c = 0.0;
+    if (tmin > 0.0 && lmin > 0.0 && wmax >= 0.0 && tmin < __builtin_inf() && lmin < __builtin_inf() && wmax < __builtin_inf()) {
+        const double mass = (double)(ds->M > 0 ? ds->M : 1) * wmax;
+        c = mass > 0.0 ? (log(mass / lmin) + 60.0 * 0.6931471805599453) / tmin : 1e-300;
+        if (!(c > 0.0)) c = 1e-300;                          // no excitation at all: an empty window is exact
+    }
+    m->rec_cut = c;
+    m->rec_version = m->version;
+    *cut = c;
+    return NHP_OK;
+}
+
+static nhp_status nhp_launch_recursive_full(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_out);
+
+// *child_cut = the children with truncated-window starts (and *group the lanes-per-child width for them) when the
+// full-history sum may be evaluated through a window for this (data, parameters); nullptr when the recursion must run
+nhp_status nhp_recursive_window(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, const nhp_child **child_cut,
+                                int *group)
+{
+    *child_cut = nullptr;
+    static const int mode = getenv("NHP_REC_WINDOW") ? atoi(getenv("NHP_REC_WINDOW")) : 1;     // 0: always the recursion
+    if (!mode || ds->M <= 0 || m->impulse_kind != NHP_IMPULSE_EXPONENTIAL) return NHP_OK;
+    double cut = 0.0;
+    NHP_TRY(rec_cut_for(ctx, ds, m, &cut));
+    // expected parents per window; the recursion costs 2·N exponentials per event at about half the pair rate
+    const double rate = ds->t_last > 0.0 ? (double)ds->M / ds->t_last : 0.0;
+    if (!(cut > 0.0) || cut * rate > 1.5 * (double)ds->N || cut * rate > 8192.0) return NHP_OK;
+    nhp_cont_dataset *mds = const_cast<nhp_cont_dataset *>(ds);
+    if (!mds->d_child_cut && hipMalloc((void **)&mds->d_child_cut, sizeof(nhp_child) * (size_t)ds->M) != hipSuccess) {
+        nhp_set_error(ctx, "out of device memory (recursive windows)");
+        return NHP_ENOMEM;
+    }
+    if (ds->cut_cached != cut) {
+        unsigned long long *d_pairs = reinterpret_cast<unsigned long long *>(ctx->d_counter + 32 * (NHP_REC_PAIR_SLOT));
+        NHP_HIP(ctx, hipMemsetAsync(d_pairs, 0, sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(k_rec_windows, dim3((unsigned)((ds->M + 255) / 256)), dim3(256), 0, ctx->stream, ds->d_child, ds->d_times,
+                           ds->M, cut, (int)ds->n_zero_time, mds->d_child_cut, d_pairs);
+        NHP_HIP(ctx, hipGetLastError());
+        unsigned long long hp = 0;
+        NHP_HIP(ctx, hipMemcpyAsync(&hp, d_pairs, sizeof(hp), hipMemcpyDeviceToHost, ctx->stream));
+        NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        NHP_HIP(ctx, hipMemsetAsync(d_pairs, 0, sizeof(unsigned long long), ctx->stream));    // counters rest at 0
+        ds->cut_cached = cut;
+        ds->cut_pairs = (int64_t)hp;
+    }
+    const double kbar = (double)ds->cut_pairs / (double)ds->M;
+    if (kbar > 1.5 * (double)ds->N) return NHP_OK;
+    *child_cut = ds->d_child_cut;
+    *group = nhp_pick_group(kbar);
+    return NHP_OK;
+}
+
 nhp_status nhp_launch_recursive(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_out)
+{
+    if (m->impulse_kind != NHP_IMPULSE_EXPONENTIAL) return NHP_EINVAL;
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    const nhp_child *child_cut = nullptr;
+    int group = 0;
+    NHP_TRY(nhp_recursive_window(ctx, ds, m, &child_cut, &group));
+    if (child_cut) return nhp_launch_windowed_as(ctx, ds, m, child_cut, group, 0, d_out);
+    return nhp_launch_recursive_full(ctx, ds, m, d_out);
+}
+
+static nhp_status nhp_launch_recursive_full(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_out)
 {
     if (m->impulse_kind != NHP_IMPULSE_EXPONENTIAL) return NHP_EINVAL;
     NHP_HIP(ctx, hipSetDevice(ctx->device));

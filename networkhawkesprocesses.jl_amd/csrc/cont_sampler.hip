@@ -386,6 +386,7 @@ extern "C" nhp_status nhp_cont_gibbs_step(nhp_ctx *ctx, const nhp_cont_dataset *
     NHP_TRY(run_sampler(ctx, ds, m, nullptr, seed, step, false, true, &o));
     gibbs_priors g{pr->alpha0, pr->beta0, pr->kappa, pr->nu, pr->a, pr->b, pr->mu_mu, pr->kappa_mu};
     const size_t NN = (size_t)ds->N * ds->N;
+    ++m->version;
     hipLaunchKernelGGL(k_gibbs_draw, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, ctx->stream, ds->N, m->impulse_kind,
                        ds->duration, g, seed, step, o.cnt0, o.Mn, o.Mnm, o.X, o.V, m->d_lambda0, m->d_p1, m->d_p2, m->d_W);
     NHP_HIP(ctx, hipGetLastError());

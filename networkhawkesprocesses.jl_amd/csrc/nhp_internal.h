@@ -80,6 +80,11 @@ struct nhp_cont_dataset {
     double *d_adj_dt = nullptr;                       // [pairs] t_child - t_parent
     int32_t *d_adj_start = nullptr;                   // [N*(N+1)] per-column offsets by parent node
     int64_t *d_adj_off = nullptr;                     // [N+1] first pair of each column
+    // recursive ll evaluated as a truncated window (cont_recursive.hip): children with window starts for `cut_cached`
+    nhp_child *d_child_cut = nullptr;
+    mutable double cut_cached = -1.0;
+    mutable int64_t cut_pairs = 0;
+    int64_t n_zero_time = 0;            // events at exactly t = 0.0 (the recursion's seen-flag skips them: SURVEY D9)
     unsigned char *d_adj_group = nullptr;             // [N*N] grouping code of entry (p, c): see k_adj_build
     // host copies kept for host-side helpers
     std::vector<int32_t> h_boff;
@@ -95,6 +100,11 @@ struct nhp_cont_model {
     double *d_p1 = nullptr;             // theta (exp) or mu (logit-normal)
     double *d_p2 = nullptr;             // tau (logit-normal)
     double *d_W = nullptr, *d_A = nullptr;
+    // parameters change through create/update/set_params and the device-side draws: `version` counts the changes, so
+    // quantities derived from the parameters (the recursive path's truncation window) are recomputed only when stale
+    uint64_t version = 1;
+    mutable uint64_t rec_version = 0;
+    mutable double rec_cut = 0.0;       // look-back beyond which the full-history sum is below 2^-60 of every λ_i (0: no bound)
 };
 
 // Kernel-side view of model + data (passed by value).
@@ -164,6 +174,13 @@ void nhp_set_error(nhp_ctx *ctx, const char *fmt, ...);
     } while (0)
 
 nhp_status nhp_ctx_reserve_partials(nhp_ctx *ctx, size_t n_doubles);
+int nhp_pick_group(double mean_window);
+nhp_status nhp_recursive_window(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, const nhp_child **child_cut,
+                                int *group);
+nhp_status nhp_launch_event_intensity_as(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, const nhp_child *child_w,
+                                         int group, int mask_integral, double *d_lambda);
+nhp_status nhp_launch_windowed_as(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, const nhp_child *child_w,
+                                  int group, int mask_integral, double *d_out);
 nhp_status nhp_ctx_reserve_scratch(nhp_ctx *ctx, size_t bytes);
 nhp_cont_args nhp_make_args(const nhp_cont_dataset *ds, const nhp_cont_model *m);
 nhp_status nhp_check_pair(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m);

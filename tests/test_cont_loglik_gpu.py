@@ -172,3 +172,40 @@ def test_batch_of_models(nhp, orc):
     _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, ds.h, arr, 3, 0, _lib.dptr(out)), ctx.h)
     for c, got in zip(cases, out):
         assert rel(got, orc.loglik_windowed(c["om"], data[0], data[1], data[2])) < TOL
+
+
+@pytest.mark.parametrize("network", [False, True])
+@pytest.mark.parametrize("lgcp", [False, True])
+def test_recursive_through_the_truncated_window_matches_the_recursion(nhp, orc, network, lgcp):
+    # fast-decaying impulses: the full-history sum is evaluated through a window beyond which the tail is below
+    # 2^-60 of every λ_i (csrc/cont_recursive.hip); the oracle runs the literal O(M·N) recursion.  Events at exactly
+    # t = 0 (skipped by the recursion, D9) and the unmasked integral (D7) are part of the comparison.
+    N, M, T = 64, 4000, 400.0
+    rng = np.random.default_rng(77)
+    times = np.sort(rng.uniform(0.0, T, M))
+    times[:3] = 0.0
+    nodes = rng.integers(1, N + 1, M).astype(np.int64)
+    th = rng.uniform(20.0, 40.0, (N, N))
+    W = rng.uniform(0.0, 1.0, (N, N)) / N
+    A = (rng.uniform(size=(N, N)) < 0.5).astype(np.float64) if network else None
+    if lgcp:
+        gx = np.linspace(0.0, T, 9)
+        lam0 = np.exp(rng.normal(0.0, 0.3, (N, 9)))
+        base = nhp.LogGaussianCoxProcess(gx, list(lam0))
+    else:
+        gx, lam0 = None, rng.uniform(0.5, 1.5, N)
+        base = nhp.HomogeneousProcess(lam0)
+    imp, w = nhp.ExponentialImpulseResponse(th, 1.0, 1.0, 0.05), nhp.DenseWeightModel(W)
+    proc = (nhp.ContinuousNetworkHawkesProcess(base, imp, w, A, nhp.BernoulliNetworkModel(0.5, N)) if network
+            else nhp.ContinuousStandardHawkesProcess(base, imp, w))
+    om = orc.ContModel(lam0, W, theta=th, dt_max=0.05, A=A, grid_x=gx)
+    got = nhp.loglikelihood(proc, (times, nodes, T), recursive=True)
+    want = orc.loglik_recursive(om, times, nodes, T)
+    assert rel(got, want) < 1e-12
+    if not network:                                       # (mle! is defined for the standard process)
+        ll, g = nhp.loglikelihood_gradient(proc, (times, nodes, T), recursive=True)
+        wll, wg = orc.loglik_grad(om, times, nodes, T, recursive=True)
+        assert rel(ll, wll) < 1e-12
+        assert np.max(np.abs(g - wg) / np.maximum(1.0, np.abs(wg))) < 1e-10
+    # and it is NOT the windowed (Δtmax = 0.05) value: the recursion ignores Δtmax (D8)
+    assert rel(nhp.loglikelihood(proc, (times, nodes, T), recursive=False), want) > 1e-6
