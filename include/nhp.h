@@ -54,6 +54,8 @@ enum {
                                     (src/continuous.jl:212-214,361-363): O(M*N) recursion that
                                     ignores dt_max; for other impulses the flag is ignored, as
                                     in the reference */
+    NHP_LL_FULL_RECURSION = 2,   /* with NHP_LL_RECURSIVE: always run the O(M*N) recursion, never its
+                                    truncated-window evaluation (same value to fp64 resolution) */
 };
 
 typedef struct nhp_ctx nhp_ctx;

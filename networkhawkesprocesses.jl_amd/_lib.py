@@ -16,6 +16,7 @@ OK, EINVAL, EDOMAIN, ESHAPE, ENOMEM, EHIP, ENOTIMPL = range(7)
 BASELINE_HOMOGENEOUS, BASELINE_LGCP = 0, 1
 IMPULSE_EXPONENTIAL, IMPULSE_LOGITNORMAL = 0, 1
 LL_RECURSIVE = 1
+LL_FULL_RECURSION = 2
 MAX_SLOTS = 4096
 
 _dp = C.POINTER(C.c_double)

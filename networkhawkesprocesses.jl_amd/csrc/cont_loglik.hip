@@ -347,7 +347,7 @@ static nhp_status enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_co
     NHP_TRY(nhp_check_pair(ctx, ds, m));
     if (slot < 0 || slot >= NHP_MAX_SLOTS) return NHP_EINVAL;
     if ((flags & NHP_LL_RECURSIVE) && m->impulse_kind == NHP_IMPULSE_EXPONENTIAL)
-        return nhp_launch_recursive(ctx, ds, m, ctx->d_results + slot);
+        return nhp_launch_recursive_flags(ctx, ds, m, flags, ctx->d_results + slot);
     return nhp_launch_windowed(ctx, ds, m, ctx->d_results + slot);
 }
 

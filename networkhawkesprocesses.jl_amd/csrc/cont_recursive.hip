@@ -280,11 +280,16 @@ nhp_status nhp_recursive_window(nhp_ctx *ctx, const nhp_cont_dataset *ds, const 
 
 nhp_status nhp_launch_recursive(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_out)
 {
+    return nhp_launch_recursive_flags(ctx, ds, m, NHP_LL_RECURSIVE, d_out);
+}
+
+nhp_status nhp_launch_recursive_flags(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, int32_t flags, double *d_out)
+{
     if (m->impulse_kind != NHP_IMPULSE_EXPONENTIAL) return NHP_EINVAL;
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     const nhp_child *child_cut = nullptr;
     int group = 0;
-    NHP_TRY(nhp_recursive_window(ctx, ds, m, &child_cut, &group));
+    if (!(flags & NHP_LL_FULL_RECURSION)) NHP_TRY(nhp_recursive_window(ctx, ds, m, &child_cut, &group));
     if (child_cut) return nhp_launch_windowed_as(ctx, ds, m, child_cut, group, 0, d_out);
     return nhp_launch_recursive_full(ctx, ds, m, d_out);
 }

@@ -177,6 +177,7 @@ nhp_status nhp_ctx_reserve_partials(nhp_ctx *ctx, size_t n_doubles);
 int nhp_pick_group(double mean_window);
 nhp_status nhp_recursive_window(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, const nhp_child **child_cut,
                                 int *group);
+nhp_status nhp_launch_recursive_flags(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, int32_t flags, double *d_out);
 nhp_status nhp_launch_event_intensity_as(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, const nhp_child *child_w,
                                          int group, int mask_integral, double *d_lambda);
 nhp_status nhp_launch_windowed_as(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, const nhp_child *child_w,
