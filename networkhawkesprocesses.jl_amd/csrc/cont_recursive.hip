@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_rec_windows(const nhp_child *__restrict
 // cut for this model (cached per parameter version); 0 = no usable bound
 static nhp_status rec_cut_for(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *cut)
 {
-    if (m->rec_version == m->version) { *cut = m->rec_cut; return NHP_OK; }
+    if (m->rec_version == m->version && m->rec_M == ds->M) { *cut = m->rec_cut; return NHP_OK; }
     const int blocks = 64;
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 3 * (size_t)blocks));
     nhp_cont_args a = nhp_make_args(ds, m);
@@ -236,6 +236,7 @@ static nhp_status rec_cut_for(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
     }
     m->rec_cut = c;
     m->rec_version = m->version;
+    m->rec_M = ds->M;
     *cut = c;
     return NHP_OK;
 }

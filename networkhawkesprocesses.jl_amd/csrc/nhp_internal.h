@@ -104,6 +104,7 @@ struct nhp_cont_model {
     // quantities derived from the parameters (the recursive path's truncation window) are recomputed only when stale
     uint64_t version = 1;
     mutable uint64_t rec_version = 0;
+    mutable int64_t rec_M = -1;         // the event count the cached bound was derived for
     mutable double rec_cut = 0.0;       // look-back beyond which the full-history sum is below 2^-60 of every λ_i (0: no bound)
 };
 
