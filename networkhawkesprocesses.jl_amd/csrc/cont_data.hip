@@ -74,6 +74,7 @@ extern "C" nhp_status nhp_cont_dataset_create(nhp_ctx *ctx, const double *events
     }
     ds->pairs = pairs;
     for (int64_t i = 0; i < M && events[i] == 0.0; ++i) ds->n_zero_time = i + 1;
+    for (int64_t i = 0; i < M; ++i) ds->max_window = std::max<int32_t>(ds->max_window, (int32_t)(i - first[i]));
     ds->h_pair_off.assign((size_t)N + 1, 0);
     for (int64_t i = 0; i < M; ++i) ds->h_pair_off[node32[i] + 1] += i - first[i];
     for (int32_t c = 0; c < N; ++c) ds->h_pair_off[c + 1] += ds->h_pair_off[c];

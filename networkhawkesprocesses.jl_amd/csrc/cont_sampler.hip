@@ -171,6 +171,138 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_sampler(nhp_cont_args a, const do
     }
 }
 
+// ---- 8 lanes per child ------------------------------------------------------------------------------
+// k_sampler gives a child to one lane; its window is then walked with 64 different cache lines per load
+// instruction and one dependent load per parent.  Here 8 lanes share a child and a window is consumed 8
+// records at a time -- one contiguous 128-byte run per child and instruction, the access pattern of the
+// windowed log-likelihood kernel -- while the order-sensitive arithmetic stays EXACTLY the single-lane
+// sequence: each lane evaluates one weight, then the partial sums ((w0 + w1) + w2) + ... are formed by a
+// chain of eight dependent steps, step t executed by lane t on the value lane t-1 produced (DPP row_shr:1),
+// and the cumulative probabilities cp_k = cp_{k-1} + w_k/s the same way (one division per lane, in
+// parallel).  Bit-identical indices; used when no window exceeds Julia's 1024-element sequential-sum limit.
+#define S8_CACHE 4       // chunks of 8 weights kept in registers between the sum pass and the scan pass
+
+__device__ __forceinline__ double s8_shr1(double v)        // lane i <- lane i-1 (within a row of 16)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x111, 0xF, 0xF, false),
+                            __builtin_amdgcn_update_dpp(lo, lo, 0x111, 0xF, 0xF, false));
+}
+
+// sequential prefix over the 8 lanes of a group: returns p_k = (...((carry ⊕ x_0) + x_1)...) + x_k in lane k,
+// where `carry ⊕ x_0` is x_0 itself for the first chunk (the reference starts from the first element, not 0)
+__device__ __forceinline__ double s8_chain(double x, double carry, bool first, int gl)
+{
+#pragma clang fp contract(off)
+    double v = first ? x : carry + x;                       // lane 0's value; other lanes overwrite below
+#pragma unroll
+    for (int t = 1; t < 8; ++t) {
+        const double prev = s8_shr1(v);
+        if (gl == t) v = prev + x;
+    }
+    return v;
+}
+
+template <int IMP>
+__global__ __launch_bounds__(NHP_BLOCK) void k_sampler8(nhp_cont_args a, const double *__restrict__ u,
+                                                        uint64_t seed, uint64_t step,
+                                                        int64_t *__restrict__ parents, int64_t *__restrict__ pnodes,
+                                                        int32_t *__restrict__ pn_b, double *__restrict__ dt_b,
+                                                        int *__restrict__ err)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 *col = reinterpret_cast<double2 *>(smem);
+    double *colw = reinterpret_cast<double *>(col + a.N);
+    const nhp_item it = a.items[blockIdx.x];
+    const int c = it.node, N = a.N, tid = threadIdx.x, gl = tid & 7, gid = tid >> 3;
+    const int glane7 = (tid & 63 & ~7) + 7;                  // last lane of this group inside the wave
+    for (int p = tid; p < N; p += NHP_BLOCK) {
+        const size_t k = (size_t)p + (size_t)c * N;
+        double w = a.W[k];
+        if (a.A) w = a.A[k] * w;
+        if (IMP == NHP_IMPULSE_EXPONENTIAL) {
+            const double scale = 1.0 / a.p1[k];            // Exponential(1/θ) ...
+            col[p] = make_double2(1.0 / scale, w);         // ... and its rate inv(scale)
+        } else {
+            col[p] = make_double2(a.p1[k], __builtin_sqrt(a.p2[k]));
+            colw[p] = w;
+        }
+    }
+    __syncthreads();
+    samp_col sc{col, colw};
+
+    const int nchild = it.kend - it.kbeg;
+    for (int k0 = 0; k0 < nchild; k0 += NHP_BLOCK / 8) {    // block-uniform trip count; idle groups are masked
+        const int kq = k0 + gid;
+        const bool live = kq < nchild;
+        const nhp_child ch = a.child[it.kbeg + (live ? kq : 0)];
+        const int i = ch.idx;
+        const double t = ch.t;
+        const int n = (live && i > 0) ? i - ch.first + 1 : 0;           // index == 1 -> (0, 0): src/parents.jl:26-28
+        const double base = n > 0 ? samp_baseline(a, c, t) : 0.0;
+        // chunks needed by any group of this wave (groups walk in lock step; a finished group adds zeros)
+        int nq = (n + 7) >> 3;
+        int nq_max = nq;
+#pragma unroll
+        for (int o = 32; o >= 8; o >>= 1) nq_max = max(nq_max, __shfl_xor(nq_max, o));
+        // weight k of the child: k < n-1 -> parent i-1-k, k == n-1 -> baseline, beyond -> 0
+        auto weight = [&](int k) -> double {
+            if (k < n - 1) return samp_weight<IMP>(a, sc, t, i - 1 - k);
+            return k == n - 1 ? base : 0.0;
+        };
+        // ---- pass 1: s = w_0 + w_1 + ... left to right (the first S8_CACHE chunks stay in registers: static
+        // indices, so they really are registers)
+        double wreg[S8_CACHE];
+        double carry = 0.0;
+#pragma unroll
+        for (int q = 0; q < S8_CACHE; ++q) {
+            wreg[q] = 0.0;
+            if (q < nq_max) {
+                wreg[q] = weight(8 * q + gl);
+                const double v = s8_chain(wreg[q], carry, q == 0, gl);
+                carry = __shfl(v, glane7);
+            }
+        }
+        for (int q = S8_CACHE; q < nq_max; ++q) {
+            const double v = s8_chain(weight(8 * q + gl), carry, false, gl);
+            carry = __shfl(v, glane7);
+        }
+        const double s = carry;
+        if (n > 0 && (!(s > 0.0) || !(s < __builtin_inf()))) *err = 1;
+        // ---- pass 2: smallest kk with cp_kk > draw, capped at n-1 (the baseline)
+        const double draw = n > 0 ? (u ? u[i] : nhp_philox_uniform(seed, step, (uint64_t)i)) : 0.0;
+        int kk = n > 0 ? n - 1 : 0;
+        bool found = n == 0;
+        carry = 0.0;
+        auto scan = [&](const int q, const double w) {
+            const double cp = s8_chain(w / s, carry, q == 0, gl);
+            carry = __shfl(cp, glane7);
+            const int kidx = 8 * q + gl;
+            // lanes of the group whose cumulative probability already exceeds the draw (only real weights count)
+            const unsigned long long hits = __ballot(!found && kidx < n && cp > draw);
+            const unsigned int mine = (unsigned int)(hits >> ((tid & 63) & ~7)) & 0xFFu;
+            if (!found && mine) { kk = 8 * q + (__ffs(mine) - 1); found = true; }
+        };
+#pragma unroll
+        for (int q = 0; q < S8_CACHE; ++q)
+            if (q < nq_max && __ballot(!found) != 0ull) scan(q, wreg[q]);
+        for (int q = S8_CACHE; q < nq_max; ++q) {
+            if (__ballot(!found) == 0ull) break;
+            scan(q, weight(8 * q + gl));
+        }
+        int parent = -1;
+        if (n > 0 && kk < n - 1) parent = i - 1 - kk;
+        if (live && gl == 0) {
+            const int pnode = parent >= 0 ? a.nodes[parent] : -1;
+            if (parents) parents[i] = (int64_t)parent + 1;     // 1-based event index, 0 = baseline
+            if (pnodes) pnodes[i] = (int64_t)pnode + 1;
+            pn_b[it.kbeg + kq] = pnode;
+            dt_b[it.kbeg + kq] = parent >= 0 ? t - a.times[parent] : 0.0;
+        }
+    }
+}
+
 // ---- statistics: workgroup c scans the children of c; thread t owns the parent nodes p = t (mod 256)
 // Every child is looked at once per wave: the wave whose lane owns the child's parent node takes a
 // (rare) branch and updates that node's cells in LDS -- thread-exclusive addresses, no atomics, and
@@ -285,20 +417,23 @@ static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
     if (u && M) NHP_HIP(ctx, hipMemcpyAsync(d_u, u, 8 * M, hipMemcpyHostToDevice, st));
 
     nhp_cont_args a = nhp_make_args(ds, m);
-    const size_t per = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? 16 : 24;
-    const size_t lds = per * N + 8 * (size_t)NHP_BLOCK * SAMP_CLD;
+    const bool expo = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
+    // 8 lanes per child (k_sampler8) from a mean window of 24 parents: measured (N=1024, M=1e6, exp | logit-normal)
+    // 508 | 846 µs vs 681 | 1228 µs at K̄=64 and 3.3 | 6.3 ms vs 5.0 | 8.9 ms at K̄=512, but 144 | 198 µs vs 115 | 174 µs
+    // at K̄=8, where the 8-step chains outweigh the better gathers.  Never when some window reaches Julia's
+    // pairwise-sum threshold (> 1024 weights), which only the single-lane kernel implements.
+    // NHP_SAMPLER=1 | 8 forces a kernel (8 still respects the threshold).
+    const int force = getenv("NHP_SAMPLER") ? atoi(getenv("NHP_SAMPLER")) : 0;
+    const double kbar = ds->M > 0 ? (double)ds->pairs / (double)ds->M : 0.0;
+    const bool coop = force != 1 && ds->max_window + 1 <= 1024 && (force == 8 || kbar >= 24.0);
+    const size_t lds = (expo ? 16 : 24) * N + (coop ? 0 : 8 * (size_t)NHP_BLOCK * SAMP_CLD);
     if (lds > 160 * 1024) { nhp_set_error(ctx, "n_nodes = %d exceeds the 160 KiB LDS column budget", ds->N); return NHP_ENOTIMPL; }
-    if (lds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)k_sampler<NHP_IMPULSE_EXPONENTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)k_sampler<NHP_IMPULSE_LOGITNORMAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
-    dim3 grid((unsigned)ds->n_items);
-    if (m->impulse_kind == NHP_IMPULSE_EXPONENTIAL)
-        hipLaunchKernelGGL((k_sampler<NHP_IMPULSE_EXPONENTIAL>), grid, dim3(NHP_BLOCK), lds, st, a, d_u, seed, step,
-                           want_parents ? o->parents : nullptr, want_parents ? o->pnodes : nullptr, o->pn_b, o->dt_b, d_err);
-    else
-        hipLaunchKernelGGL((k_sampler<NHP_IMPULSE_LOGITNORMAL>), grid, dim3(NHP_BLOCK), lds, st, a, d_u, seed, step,
-                           want_parents ? o->parents : nullptr, want_parents ? o->pnodes : nullptr, o->pn_b, o->dt_b, d_err);
+    using samp_fn = void (*)(nhp_cont_args, const double *, uint64_t, uint64_t, int64_t *, int64_t *, int32_t *, double *, int *);
+    const samp_fn fn = coop ? (expo ? k_sampler8<NHP_IMPULSE_EXPONENTIAL> : k_sampler8<NHP_IMPULSE_LOGITNORMAL>)
+                            : (expo ? k_sampler<NHP_IMPULSE_EXPONENTIAL> : k_sampler<NHP_IMPULSE_LOGITNORMAL>);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(fn, dim3((unsigned)ds->n_items), dim3(NHP_BLOCK), lds, st, a, d_u, seed, step,
+                       want_parents ? o->parents : nullptr, want_parents ? o->pnodes : nullptr, o->pn_b, o->dt_b, d_err);
     NHP_HIP(ctx, hipGetLastError());
     ds->pn_valid = true;
     if (want_stats) {

@@ -64,6 +64,7 @@ struct nhp_cont_dataset {
     int32_t group = 8;                  // lanes cooperating on one child in the windowed kernels
     int32_t n_items = 0;
     int32_t max_item = 0;               // most children in one item (sizes the deferred-log LDS buffer)
+    int32_t max_window = 0;             // longest look-back window, in parents
     nhp_event *d_ev = nullptr;          // [M] time order, packed (t, node)
     // device arrays
     double *d_times = nullptr;          // [M] time order

@@ -132,3 +132,20 @@ def test_fused_statistics_match_reference_helpers(nhp, orc, kind):
     # statistics only (no parent vectors copied back)
     _, _, st2 = nhp.resample_parents(c["proc"], c["data"], seed=5, step=2, with_stats=True, want_parents=False)
     assert np.array_equal(st2["Mnm"], st["Mnm"])
+
+
+@pytest.mark.parametrize("which", ["1", "8"])
+@pytest.mark.parametrize("kind", ["exponential", "logitnormal"])
+def test_both_sampler_kernels_give_the_oracle_indices(nhp, orc, which, kind, monkeypatch):
+    # the single-lane kernel and the 8-lanes-per-child kernel (exact sequential DPP chains) are chosen by mean
+    # window; force each and compare with the oracle on short, medium and ragged windows, LGCP baseline, network
+    monkeypatch.setenv("NHP_SAMPLER", which)
+    from helpers import random_case
+    for (N, M, T, dtm, net, lg, seed) in ((5, 3000, 100.0, 0.3, False, False, 1), (7, 4000, 40.0, 1.5, True, True, 2),
+                                          (3, 2500, 10.0, 2.0, False, False, 3)):
+        c = random_case(N, M, T, kind, dtm, network=net, lgcp=lg, seed=seed, nhp=nhp, orc=orc)
+        u = np.random.default_rng(seed).uniform(size=M)
+        p, pn = nhp.resample_parents(c["proc"], c["data"], u=u)
+        wp, wpn = orc.resample_parents(c["om"], c["times"], c["nodes"], u, flags=orc.MATH_DET)
+        assert np.array_equal(p, wp) and np.array_equal(pn, wpn)
+
