@@ -250,6 +250,210 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
     if (tid <= NHP_SHARDS) __hip_atomic_store(&counter[32 * tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- several parameter sets per launch ---------------------------------------------------------------
+// At short windows an evaluation is bound by the scattered gathers of the parent windows, which do
+// not depend on the parameters.  nhp_cont_loglik_batch therefore evaluates S = 2 or 4 models of the same kinds
+// in ONE pass over the data: S columns of the tables sit in LDS, every parent record is fetched once and used S
+// times.  Same arithmetic per model as k_windowed (same item layout, same per-child lane order); the logs of a
+// round are taken by all lanes from a small LDS buffer.
+struct nhp_multi {
+    const double *p1[4], *p2[4], *W[4], *A[4], *lambda0[4], *grid[4];
+    double *out[4];
+};
+
+__device__ __forceinline__ double baseline_at_p(int kind, const double *lambda0, const double *x, int grid_n, int c, double t)
+{
+#pragma clang fp contract(off)
+    if (kind == NHP_BASELINE_HOMOGENEOUS) return lambda0[c];
+    const double *y = lambda0 + (size_t)c * grid_n;
+    int lo = 0, hi = grid_n - 1;
+    if (!(t < x[hi])) return y[hi];
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (t >= x[mid]) lo = mid; else hi = mid;
+    }
+    return (y[lo + 1] * (t - x[lo]) + y[lo] * (x[lo + 1] - t)) / (x[lo + 1] - x[lo]);
+}
+
+template <int IMP, int G, int S>
+__global__ __launch_bounds__(NHP_WBLOCK) void k_windowed_multi(nhp_cont_args a, nhp_multi mm, double *__restrict__ partials,
+                                                              unsigned int *__restrict__ counter)
+{
+    constexpr int U = 4, GROUPS = NHP_WBLOCK / G, GW = 64 / G, ROUND = GROUPS * U;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *red = reinterpret_cast<double *>(smem);                 // [16] + flag
+    double2 *col = reinterpret_cast<double2 *>(smem + 192);         // [S][N]
+    double *colw = reinterpret_cast<double *>(col + (size_t)S * a.N);   // [S][N], logit-normal only
+    double *rb = colw + (IMP == NHP_IMPULSE_EXPONENTIAL ? 0 : (size_t)S * a.N);   // [ROUND][S] λ of the round's children
+    const nhp_item it = a.items[blockIdx.x];
+    const int c = it.node, N = a.N, tid = threadIdx.x;
+    double integ[S];
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+        integ[m] = 0.0;
+        for (int p = tid; p < N; p += NHP_WBLOCK) {
+            const size_t k = (size_t)p + (size_t)c * N;
+            double w = mm.W[m][k];
+            if (mm.A[m]) w = mm.A[m][k] * w;                         // windowed path: the integral is masked too
+            if (IMP == NHP_IMPULSE_EXPONENTIAL) {
+                col[(size_t)m * N + p] = make_double2(mm.p1[m][k], w);
+            } else {
+                col[(size_t)m * N + p] = make_double2(mm.p1[m][k], __builtin_sqrt(mm.p2[m][k]));
+                colw[(size_t)m * N + p] = w;
+            }
+            if (it.first) integ[m] += a.cnt[p] * w;
+        }
+    }
+    __syncthreads();
+    const int gid = tid / G, gl = tid % G;
+    const int nchild = it.kend - it.kbeg;
+    const int slot0 = (gid / GW) * (GW * U) + (gid % GW);
+    double acc = 0.0;                                               // Σ log λ of model (tid % S)
+    for (int r0 = 0; r0 < nchild; r0 += ROUND) {
+        double t[U], s[U][S];
+        int j[U], f[U];
+        bool valid[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = r0 + slot0 + u * GW;
+            valid[u] = kk < nchild;
+            const nhp_child ch = a.child_w[it.kbeg + (valid[u] ? kk : r0)];
+            t[u] = ch.t;
+            j[u] = ch.idx - 1 - gl;
+            f[u] = valid[u] ? ch.first : 0x7fffffff;
+#pragma unroll
+            for (int m = 0; m < S; ++m) s[u][m] = 0.0;
+        }
+        bool more = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) more |= j[u] >= f[u];
+        nhp_event e[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) e[u] = a.ev[j[u] > 0 ? j[u] : 0];
+        while (more) {
+            nhp_event en[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) en[u] = a.ev[j[u] - G > 0 ? j[u] - G : 0];
+            more = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double dt = t[u] - e[u].t;
+                const bool in = j[u] >= f[u];
+#pragma unroll
+                for (int m = 0; m < S; ++m) {
+                    const double2 q = col[(size_t)m * N + e[u].node];
+                    double term;
+                    if (IMP == NHP_IMPULSE_EXPONENTIAL) term = q.y * nhp_pdf_exponential(q.x, dt);
+                    else term = colw[(size_t)m * N + e[u].node] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
+                    s[u][m] += in ? term : 0.0;
+                }
+                j[u] -= G;
+                more |= j[u] >= f[u];
+                e[u] = en[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int m = 0; m < S; ++m) {
+                const double v = group_sum<G>(s[u][m]);
+                if (gl == 0) {
+                    // rb slot = position of the child inside the round; invalid slots hold 1.0 (log 1 = 0)
+                    const int slot = slot0 + u * GW;
+                    rb[slot * S + m] = valid[u] ? baseline_at_p(a.baseline_kind, mm.lambda0[m], mm.grid[m], a.grid_n, c, t[u]) + v : 1.0;
+                }
+            }
+        __syncthreads();
+        for (int e2 = tid; e2 < ROUND * S; e2 += NHP_WBLOCK) acc += nhp_log(rb[e2]);      // e2 % S == tid % S
+        __syncthreads();
+    }
+    // per-model workgroup sums (lane tid holds model tid % S), then the fused last-block finalize per model
+    int *flag = reinterpret_cast<int *>(red + 16);
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+        const double blk = nhp_block_sum_n<NHP_WBLOCK / 64>((tid % S) == m ? acc : 0.0, red);
+        const double blk_int = nhp_block_sum_n<NHP_WBLOCK / 64>(integ[m], red);
+        if (tid == 0) {
+            __hip_atomic_store(&partials[(2 * (size_t)blockIdx.x) * S + 2 * m], blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&partials[(2 * (size_t)blockIdx.x) * S + 2 * m + 1], blk_int, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int nb = gridDim.x, sh = blockIdx.x % NHP_SHARDS;
+        const unsigned int pop = (nb - sh + NHP_SHARDS - 1) / NHP_SHARDS;
+        const unsigned int used = nb < NHP_SHARDS ? nb : NHP_SHARDS;
+        int last = 0;
+        if (__hip_atomic_fetch_add(&counter[32 * (1 + sh)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pop - 1)
+            last = __hip_atomic_fetch_add(&counter[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == used - 1;
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+        double sl = 0.0, si = 0.0;
+        for (unsigned int i = tid; i < gridDim.x; i += NHP_WBLOCK) {
+            sl += __hip_atomic_load(&partials[(2 * (size_t)i) * S + 2 * m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            si += __hip_atomic_load(&partials[(2 * (size_t)i) * S + 2 * m + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        nhp_cont_args am = a;
+        am.lambda0 = mm.lambda0[m]; am.grid = mm.grid[m];
+        double sb = baseline_integral_part(am);
+        sl = nhp_block_sum_n<NHP_WBLOCK / 64>(sl, red);
+        si = nhp_block_sum_n<NHP_WBLOCK / 64>(si, red);
+        sb = nhp_block_sum_n<NHP_WBLOCK / 64>(sb, red);
+        if (tid == 0) *mm.out[m] = (0.0 - sb) - si + sl;
+    }
+    if (tid <= NHP_SHARDS) __hip_atomic_store(&counter[32 * tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int IMP, int S>
+static void launch_multi(int G, dim3 grid, size_t lds, hipStream_t st, const nhp_cont_args &a, const nhp_multi &mm,
+                         double *partials, unsigned int *counter)
+{
+#define NHP_MCASE(g)                                                                                              \
+    case g:                                                                                                       \
+        if (lds > 64 * 1024)                                                                                      \
+            (void)hipFuncSetAttribute((const void *)k_windowed_multi<IMP, g, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_windowed_multi<IMP, g, S>), grid, dim3(NHP_WBLOCK), lds, st, a, mm, partials, counter); \
+        break;
+    switch (G) {
+        NHP_MCASE(1) NHP_MCASE(2) NHP_MCASE(4) NHP_MCASE(8) NHP_MCASE(16)
+    default:
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)k_windowed_multi<IMP, 32, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_windowed_multi<IMP, 32, S>), grid, dim3(NHP_WBLOCK), lds, st, a, mm, partials, counter);
+    }
+#undef NHP_MCASE
+}
+
+// S models (2 or 4) of identical kinds on one dataset, results into ctx->d_results[slot0 .. slot0+S)
+template <int S>
+static nhp_status enqueue_multi(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *const *ms, int32_t slot0)
+{
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    const nhp_cont_model *m0 = ms[0];
+    const bool expo = m0->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
+    const int G = ds->group > 32 ? 32 : ds->group;
+    const size_t round = (size_t)(NHP_WBLOCK / G) * 4;
+    const size_t lds = 192 + (expo ? 16 : 24) * (size_t)ds->N * S + 8 * round * S;
+    NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)ds->n_items * S));
+    nhp_cont_args a = nhp_make_args(ds, m0);
+    nhp_multi mm;
+    for (int k = 0; k < 4; ++k) {
+        const nhp_cont_model *m = ms[k < S ? k : 0];
+        mm.p1[k] = m->d_p1; mm.p2[k] = m->d_p2; mm.W[k] = m->d_W; mm.A[k] = m->has_A ? m->d_A : nullptr;
+        mm.lambda0[k] = m->d_lambda0; mm.grid[k] = m->d_grid;
+        mm.out[k] = ctx->d_results + slot0 + (k < S ? k : 0);
+    }
+    dim3 grid((unsigned)ds->n_items);
+    if (expo) launch_multi<NHP_IMPULSE_EXPONENTIAL, S>(G, grid, lds, ctx->stream, a, mm, ctx->d_partials, ctx->d_counter);
+    else launch_multi<NHP_IMPULSE_LOGITNORMAL, S>(G, grid, lds, ctx->stream, a, mm, ctx->d_partials, ctx->d_counter);
+    NHP_HIP(ctx, hipGetLastError());
+    return NHP_OK;
+}
+
 // ll = -Σ_c ∫λ0_c - Σ_blocks integ + Σ_blocks loglam   (src/continuous.jl:216-221,237)
 // Baseline integral: λ .* duration (src/baselines.jl:98-102) or the trapezoid rule over the
 // grid, which ignores `duration` (src/baselines.jl:336, src/utils/interpolation.jl:40-48).
@@ -366,13 +570,41 @@ extern "C" nhp_status nhp_cont_loglik(nhp_ctx *ctx, const nhp_cont_dataset *ds, 
 }
 
 // nb evaluations (finite-difference sweeps, chain populations) back to back, one synchronisation
+// models that one k_windowed_multi launch can take together: same kinds and shapes, all windowed
+static bool multi_compatible(const nhp_cont_dataset *ds, const nhp_cont_model *x, const nhp_cont_model *y, size_t lds_limit, int S)
+{
+    if (!x || !y || x->ctx != y->ctx || x->N != y->N || x->impulse_kind != y->impulse_kind || x->baseline_kind != y->baseline_kind ||
+        x->grid_n != y->grid_n || x->has_A != y->has_A || x->dt_max != y->dt_max) return false;
+    const size_t lds = 192 + (x->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? 16 : 24) * (size_t)ds->N * S + 8 * 256 * 4 * (size_t)S;
+    return lds <= lds_limit;
+}
+
 extern "C" nhp_status nhp_cont_loglik_batch(nhp_ctx *ctx, const nhp_cont_dataset *ds,
                                             const nhp_cont_model *const *models, int32_t nb, int32_t flags, double *ll)
 {
     if (!models || !ll || nb < 0) return NHP_EINVAL;
+    // windowed evaluations at short windows are bound by gathers that do not depend on the parameters: take the models
+    // four (or two) at a time through one pass over the data; everything else goes one launch per model
+    static const int fuse = getenv("NHP_BATCH_FUSE") ? atoi(getenv("NHP_BATCH_FUSE")) : 4;      // largest group: 0/1 off, 2, 4
+    const double kbar = ds && ds->M > 0 ? (double)ds->pairs / (double)ds->M : 0.0;
     for (int32_t done = 0; done < nb; done += NHP_MAX_SLOTS) {
         const int32_t n = nb - done < NHP_MAX_SLOTS ? nb - done : NHP_MAX_SLOTS;
-        for (int32_t k = 0; k < n; ++k) NHP_TRY(enqueue(ctx, ds, models[done + k], flags, k));
+        int32_t k = 0;
+        while (k < n) {
+            const nhp_cont_model *const *ms = models + done + k;
+            const bool windowed = ms[0] && !((flags & NHP_LL_RECURSIVE) && ms[0]->impulse_kind == NHP_IMPULSE_EXPONENTIAL);
+            int take = 1;
+            if (fuse >= 2 && windowed && kbar <= 48.0 && ds && ds->N >= 1) {
+                NHP_TRY(nhp_check_pair(ctx, ds, ms[0]));
+                if (fuse >= 4 && k + 4 <= n && multi_compatible(ds, ms[0], ms[1], 80 * 1024, 4) && multi_compatible(ds, ms[0], ms[2], 80 * 1024, 4) &&
+                    multi_compatible(ds, ms[0], ms[3], 80 * 1024, 4)) take = 4;
+                else if (k + 2 <= n && multi_compatible(ds, ms[0], ms[1], 64 * 1024, 2)) take = 2;
+            }
+            if (take == 4) { for (int q = 1; q < 4; ++q) NHP_TRY(nhp_check_pair(ctx, ds, ms[q])); NHP_TRY(enqueue_multi<4>(ctx, ds, ms, k)); }
+            else if (take == 2) { NHP_TRY(nhp_check_pair(ctx, ds, ms[1])); NHP_TRY(enqueue_multi<2>(ctx, ds, ms, k)); }
+            else NHP_TRY(enqueue(ctx, ds, ms[0], flags, k));
+            k += take;
+        }
         NHP_TRY(nhp_ctx_fetch(ctx, 0, n, ll + done));
     }
     return NHP_OK;

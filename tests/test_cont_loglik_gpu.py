@@ -209,3 +209,21 @@ def test_recursive_through_the_truncated_window_matches_the_recursion(nhp, orc, 
         assert np.max(np.abs(g - wg) / np.maximum(1.0, np.abs(wg))) < 1e-10
     # and it is NOT the windowed (Δtmax = 0.05) value: the recursion ignores Δtmax (D8)
     assert rel(nhp.loglikelihood(proc, (times, nodes, T), recursive=False), want) > 1e-6
+
+
+@pytest.mark.parametrize("kind,network,lgcp", [("exponential", False, False), ("logitnormal", True, False), ("exponential", False, True)])
+def test_fused_batches_of_models(nhp, orc, kind, network, lgcp):
+    # nhp_cont_loglik_batch takes compatible models four (or two) at a time through one pass over the data
+    import ctypes as C
+    from nhp_amd import _lib
+    ctx = nhp.default_context()
+    cases = [random_case(9, 2500, 120.0, kind, 1.0, network=network, lgcp=lgcp, seed=s, nhp=nhp, orc=orc) for s in range(60, 67)]
+    data = cases[0]["data"]
+    ds = nhp.device_dataset(cases[0]["proc"], data, ctx)
+    models = [c["proc"].device_model(ctx) for c in cases]
+    arr = (C.c_void_p * 7)(*[m.h for m in models])
+    out = np.empty(7)
+    _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, ds.h, arr, 7, 0, _lib.dptr(out)), ctx.h)      # 4 + 2 + 1
+    for c, got in zip(cases, out):
+        assert rel(got, orc.loglik_windowed(c["om"], data[0], data[1], data[2])) < TOL
+
