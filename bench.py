@@ -189,6 +189,7 @@ def config_workloads(nhp, ctx, which):
         t_vb = timed(lambda: nhp.update_(proc, data, dsd, ctx=ctx, n_steps=10), 2) / 10.0     # 10 resident steps per call
         flop = 2.0 * T * N * N * B
         # discrete Gibbs: parent counts of one sweep, and the adjacency sweep of the network twin
+        t_lg = timed(lambda: nhp.loglikelihood_gradient(proc, data, convolved=dsd, ctx=ctx), 3)       # the mle! objective + analytic gradient
         t_pc = timed(lambda: nhp.resample_parent_counts(proc, convolved=dsd, seed=1, step=0, ctx=ctx), 2)
         import copy
         gproc = copy.deepcopy(proc)           # a full resample! (parents + device-side conjugate draws); parameters move
@@ -199,6 +200,7 @@ def config_workloads(nhp, ctx, which):
         out.append({"workload": "c4 discrete N=512 B=8 L=32 T=1e5", "convolve_ms": 1e3 * t_c, "loglik_ms": 1e3 * t_ll,
                     "loglik_tflops_fp64": flop / t_ll / 1e12, "vb_step_ms": 1e3 * t_vb,
                     "vb_tflops_fp64": 2 * flop / t_vb / 1e12, "mfma_fp64_peak_tflops": 78.6,
+                    "loglik_plus_gradient_ms": 1e3 * t_lg,
                     "gibbs_parent_counts_ms": 1e3 * t_pc, "gibbs_step_ms": 1e3 * t_gs, "gibbs_adjacency_sweep_ms": 1e3 * t_adj,
                     "events": int(data.sum())})
     return out

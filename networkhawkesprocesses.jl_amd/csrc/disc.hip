@@ -30,7 +30,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define A_MC_LD (BM + 16)     // m-contiguous image: row stride ≡ 128 B (mod 256) -> kk rows hit disjoint banks
 #define KC_LD (BK + 2)        // k-contiguous image: row stride = 2 (mod 32) bank pairs -> 16 lanes x 2 kk conflict-free
 
-enum { EPI_INTENSITY = 0, EPI_LOGLIK = 1, EPI_VB_Z = 2, EPI_SLAB = 3 };
+enum { EPI_INTENSITY = 0, EPI_LOGLIK = 1, EPI_VB_Z = 2, EPI_SLAB = 3, EPI_GRAD = 4 };   // EPI_GRAD = EPI_LOGLIK + EPI_VB_Z in one pass
 
 struct gemm_args {
     const double *A; size_t lda;
@@ -43,7 +43,8 @@ struct gemm_args {
     const double *baseT;      // [M x N] additive per-element term (time-varying baseline); overrides base if non-null
     const double *dataT;      // [M x N] counts as f64, t fastest
     double *out;              // EPI_INTENSITY: λ [M x N]; EPI_VB_Z: R [M x N]; EPI_SLAB: slabs [z][M x N]
-    double *partials;         // EPI_LOGLIK: [2 * blocks]; EPI_VB_Z: column partials [rowBlocks][N]
+    double *partials;         // EPI_LOGLIK: [2 * blocks]; EPI_VB_Z / EPI_GRAD: column partials [rowBlocks][N]
+    double *partials2;        // EPI_GRAD: the log-likelihood partials [2 * blocks]
 };
 
 // C[m,n] = Σ_k Aop[m,k]·B[k + n·ldb];  A_MCONTIG: Aop[m,k] = A[m + k·lda], else A[k + m·lda].
@@ -171,22 +172,29 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
                         const double rr = g.dataT[o] / (base + v);
                         g.out[o] = rr;
                         colp[j] += rr;
+                    } else if (EPI == EPI_GRAD) {
+                        const double lam = base + v, s = g.dataT[o], rr = s / lam;
+                        g.out[o] = rr;
+                        colp[j] += rr;
+                        t_sum += (s == 0.0 ? 0.0 : s * nhp_log(lam));
+                        t_sum2 += lam;
                     } else {
                         g.out[(size_t)blockIdx.z * (size_t)g.M * g.N + o] = v;
                     }
                 }
             }
     }
-    if (EPI == EPI_LOGLIK) {
+    if (EPI == EPI_LOGLIK || EPI == EPI_GRAD) {
         const double s1 = nhp_block_sum(t_sum, red);
         const double s2 = nhp_block_sum(t_sum2, red);
         if (tid == 0) {
             const size_t b = (size_t)bx + (size_t)by * gridDim.x;
-            g.partials[2 * b] = s1;
-            g.partials[2 * b + 1] = s2;
+            double *pp = EPI == EPI_GRAD ? g.partials2 : g.partials;
+            pp[2 * b] = s1;
+            pp[2 * b + 1] = s2;
         }
     }
-    if (EPI == EPI_VB_Z) {
+    if (EPI == EPI_VB_Z || EPI == EPI_GRAD) {
         // deterministic column sums: lanes sharing r16 -> wave partial -> the two row-waves
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -753,19 +761,17 @@ extern "C" nhp_status nhp_disc_loglik_grad(nhp_ctx *ctx, const nhp_disc_dataset 
     double *dslab = x; x += (size_t)splits * K * N;
     double *dgrad = x;
     hipStream_t st = ctx->stream;
-    // ll: GEMM-1 with the Poisson epilogue
+    // GEMM-1 once, with both epilogues: the Poisson log-likelihood partials AND R = data / Z with its column sums
     gemm_args g{};
     g.A = ds->d_conv; g.lda = T; g.B = E; g.ldb = K; g.M = (int)T; g.N = (int)N; g.K = (int)K; g.k_chunk = (int)K;
     g.base = base; g.baseT = lambda0 ? nullptr : ds->d_baseT; g.dataT = ds->d_dataT;
     const int blocks = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)blocks));
-    g.partials = ctx->d_partials;
-    launch_gemm<true, EPI_LOGLIK>(g, 1, st);
+    g.partials2 = ctx->d_partials;
+    g.out = dR; g.partials = dcolp;
+    launch_gemm<true, EPI_GRAD>(g, 1, st);
     hipLaunchKernelGGL(k_sum_pairs, dim3(1), dim3(256), 0, st, ctx->d_partials, blocks, ds->lgamma_sum, ctx->d_results);
-    // R = data / Z and its column sums, then Gᵀ·R in T-slabs
-    gemm_args g1 = g;
-    g1.out = dR; g1.partials = dcolp;
-    launch_gemm<true, EPI_VB_Z>(g1, 1, st);
+    // then Gᵀ·R in T-slabs
     gemm_args g2{};
     g2.A = ds->d_conv; g2.lda = T; g2.B = dR; g2.ldb = T; g2.M = (int)K; g2.N = (int)N; g2.K = (int)T; g2.k_chunk = k_chunk;
     g2.out = dslab;
