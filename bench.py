@@ -206,6 +206,39 @@ def config_workloads(nhp, ctx, which):
     return out
 
 
+def sharded_leg(nhp, ctx, N, M, world, names):
+    """N>1 only, after the timed region: ONE evaluation cut into column shards over the ranks (sharded.py; SURVEY 8e,
+    second way) against the same call on one GPU.  Wall time per call (parameters resident), all-reduce included.
+    Every rank runs this (the all-reduce is a collective); returns one entry per workload."""
+    out = []
+    for name in names:
+        w = WORKLOADS[name]
+        times, nodes, T = nhp.synthetic.s_metric_data(N, M, kbar=w["kbar"])
+        proc = nhp.synthetic.s_metric_process(N, M, T, w["kind"], 1.0)
+        data = (times, nodes, T)
+        if w.get("full"):
+            os.environ["NHP_REC_WINDOW"] = "0"
+        try:
+            sd = nhp.ShardedDataset(proc, data, ctx)
+            ds = nhp.device_dataset(proc, data, ctx)
+            reps = 5 if w["recursive"] else 20
+            model = proc.device_model(ctx)            # parameters resident, as in the headline measurement
+
+            def timed(target):
+                nhp.loglikelihood(proc, target, recursive=w["recursive"], ctx=ctx, model=model)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    v = nhp.loglikelihood(proc, target, recursive=w["recursive"], ctx=ctx, model=model)
+                return (time.perf_counter() - t0) / reps, v
+            t1, whole = timed(ds)
+            ts, parts = timed(sd)
+            out.append({"workload": name, "ranks": world, "one_gpu_ms": 1e3 * t1, "sharded_ms": 1e3 * ts,
+                        "columns_of_rank0": list(sd.ranges[0]), "rel_diff": abs(parts - whole) / abs(whole)})
+        finally:
+            os.environ.pop("NHP_REC_WINDOW", None)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,6 +251,8 @@ def main():
                     help="comma list of secondary workloads reported under 'other_workloads' (N=1 only)")
     ap.add_argument("--configs", default=os.environ.get("NHP_BENCH_CONFIGS", "c2,c3,c4"),
                     help="comma list of BASELINE configs measured as secondary workloads (N=1 only); '' to skip")
+    ap.add_argument("--sharded", default=os.environ.get("NHP_BENCH_SHARDED", "windowed_k512,recursive_full"),
+                    help="comma list of workloads whose single evaluation is also column-sharded over the ranks (N>1 only); '' to skip")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -260,6 +295,9 @@ def main():
         if rank == 0:
             lls = torch.cat(gathered)
     wall_s = float(wall.item())
+    sharded = None
+    if world > 1 and args.sharded:
+        sharded = sharded_leg(nhp, ctx, args.nodes, args.events, world, [x for x in args.sharded.split(",") if x])
 
     if rank == 0:
         B = algorithmic_bytes(r["N"], r["M"], r["kind"])
@@ -282,6 +320,8 @@ def main():
                          "pair_rate_per_s": r["pairs"] / (ms_kernel * 1e-3)},
             "loglik": [float(v) for v in lls.cpu()],
         }
+        if sharded is not None:
+            out["one_evaluation_over_all_ranks"] = sharded
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(r)
             out["speedup_vs_cpu_core"] = out["value"] / out["cpu_baseline"]["value"]

@@ -113,6 +113,17 @@ int32_t nhp_abi_version(void);
 nhp_status nhp_cont_dataset_create(nhp_ctx *ctx, const double *events, const int64_t *nodes,
                                    int64_t n_events, int32_t n_nodes, double duration,
                                    double dt_max, nhp_cont_dataset **out);
+/* Column shard of the same data for evaluating ONE log-likelihood / gradient on several GPUs (second
+ * way): the log-likelihood (src/continuous.jl:216-237) is a sum over child nodes c of
+ *   -∫λ0_c - Σ_p cnt[p]·[A·]W[p,c] + Σ_{i: c_i = c} log λ_i
+ * and the gradient is block-separable in the same columns.  The shard holds every event (all of them are parents) but
+ * evaluates only the children on the 0-based nodes [col_begin, col_end); nhp_cont_loglik / _enqueue / _batch / _grad
+ * on it return that part (gradient entries of other columns are 0), so the parts of a partition of [0, n_nodes) add up
+ * to the whole -- one scalar (or P-vector) all-reduce per evaluation.  The sampler / statistics / adjacency entry
+ * points need every column and return NHP_ENOTIMPL on a shard. */
+nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double *events, const int64_t *nodes,
+                                           int64_t n_events, int32_t n_nodes, double duration, double dt_max,
+                                           int32_t col_begin, int32_t col_end, nhp_cont_dataset **out);
 void nhp_cont_dataset_destroy(nhp_cont_dataset *ds);
 /* Σ_i K_i: parent-child pairs inside the look-back window (SURVEY 8d F_alg) */
 int64_t nhp_cont_dataset_pairs(const nhp_cont_dataset *ds);

@@ -25,6 +25,8 @@ from .inference import (MarkovChainMonteCarlo, MaximumLikelihood, logprior,  # n
                         resample_adjacency_matrix_)
 from . import inference as _inf
 from . import synthetic  # noqa: F401
+from . import sharded  # noqa: F401
+from .sharded import ShardedDataset, sharded_loglikelihood, sharded_loglikelihood_gradient  # noqa: F401
 
 
 def loglikelihood(process, data, *args, **kwargs):

@@ -65,6 +65,7 @@ def _declare(lib):
     f("nhp_ctx_timer_start", i32, _vp)
     f("nhp_ctx_timer_stop", i32, _vp, _dp)
     f("nhp_cont_dataset_create", i32, _vp, _dp, _ip, i64, i32, dbl, dbl, C.POINTER(_vp))
+    f("nhp_cont_dataset_create_columns", i32, _vp, _dp, _ip, i64, i32, dbl, dbl, i32, i32, C.POINTER(_vp))
     f("nhp_cont_dataset_destroy", None, _vp)
     f("nhp_cont_dataset_pairs", i64, _vp)
     f("nhp_cont_model_create", i32, _vp, C.POINTER(ModelDesc), C.POINTER(_vp))

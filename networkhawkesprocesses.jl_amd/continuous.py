@@ -108,7 +108,9 @@ class DeviceModel:
 class DeviceDataset:
     """nhp_cont_dataset handle: (events, nodes, duration) uploaded once, pre-pass done for Δtmax."""
 
-    def __init__(self, ctx, data, nnodes, Δtmax):
+    def __init__(self, ctx, data, nnodes, Δtmax, columns=None):
+        """columns = (begin, end), 0-based half-open: a column shard (sharded.py) that evaluates only the children on
+        those nodes; None = the whole dataset."""
         events, nodes, duration = data
         self.events = _lib.f64(events)
         self.nodes = np.ascontiguousarray(nodes, dtype=np.int64)
@@ -116,9 +118,10 @@ class DeviceDataset:
             raise ValueError("events and nodes must have the same length")
         self.duration, self.Δtmax, self.nnodes, self.ctx = float(duration), float(Δtmax), int(nnodes), ctx
         h = C.c_void_p()
-        _lib.check(_lib.lib().nhp_cont_dataset_create(ctx.h, _lib.dptr(self.events), _lib.iptr(self.nodes),
-                                                      len(self.events), nnodes, self.duration, self.Δtmax,
-                                                      C.byref(h)), ctx.h)
+        self.columns = (0, int(nnodes)) if columns is None else (int(columns[0]), int(columns[1]))
+        _lib.check(_lib.lib().nhp_cont_dataset_create_columns(ctx.h, _lib.dptr(self.events), _lib.iptr(self.nodes),
+                                                              len(self.events), nnodes, self.duration, self.Δtmax,
+                                                              self.columns[0], self.columns[1], C.byref(h)), ctx.h)
         self.h = h
         self._fin = weakref.finalize(self, _lib.lib().nhp_cont_dataset_destroy, h)
 
@@ -202,14 +205,19 @@ def _check_recursive(process, recursive):
     return _lib.LL_RECURSIVE if (recursive and isinstance(process.impulses, ExponentialImpulseResponse)) else 0
 
 
-def loglikelihood(process, data, recursive=True, ctx=None):
+def loglikelihood(process, data, recursive=True, ctx=None, model=None):
     """loglikelihood(process, data; recursive=true) -- src/continuous.jl:210-239,360-389.
 
     Exponential impulses with `recursive` take the O(M·N) recursion that ignores Δtmax
-    (:212-214); everything else takes the windowed sum."""
+    (:212-214); everything else takes the windowed sum.  A `sharded.ShardedDataset` evaluates it on all ranks together.
+    `model`: a device-resident model (process.device_model(ctx)) to evaluate as is, skipping the parameter upload
+    that otherwise precedes every call."""
+    from .sharded import ShardedDataset, sharded_loglikelihood
+    if isinstance(data, ShardedDataset):
+        return sharded_loglikelihood(process, data, recursive=recursive, model=model)
     ctx = ctx or _lib.default_context()
     ds = device_dataset(process, data, ctx)
-    model = process.device_model(ctx)
+    model = model or process.device_model(ctx)
     ll = C.c_double()
     _lib.check(_lib.lib().nhp_cont_loglik(ctx.h, ds.h, model.h, _check_recursive(process, recursive), C.byref(ll)), ctx.h)
     return ll.value
@@ -242,13 +250,16 @@ def intensity(process, data, times, ctx=None):
     return res[0] if scalar else res
 
 
-def loglikelihood_gradient(process, data, recursive=True, ctx=None):
+def loglikelihood_gradient(process, data, recursive=True, ctx=None, model=None):
     """(ll, ∇ll) with the gradient in params! order [λ0; θ | μ; τ; W].  The reference supplies no
     gradient to Optim (src/continuous.jl:190), which then spends 2P objective calls on finite
     differences; this is one fused pass."""
+    from .sharded import ShardedDataset, sharded_loglikelihood_gradient
+    if isinstance(data, ShardedDataset):
+        return sharded_loglikelihood_gradient(process, data, recursive=recursive, model=model)
     ctx = ctx or _lib.default_context()
     ds = device_dataset(process, data, ctx)
-    model = process.device_model(ctx)
+    model = model or process.device_model(ctx)
     P = len(process.params())
     g = np.empty(P)
     ll = C.c_double()

@@ -352,6 +352,7 @@ extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_d
                                                   uint64_t seed, uint64_t step, double *A_out, double *n_links)
 {
     NHP_TRY(nhp_check_pair(ctx, ds, m));
+    NHP_WHOLE_DATASET(ctx, ds, "resample_adjacency");
     if (!m->has_A) { nhp_set_error(ctx, "resample_adjacency: the model has no adjacency matrix"); return NHP_EINVAL; }
     if (!rho_matrix && !(rho >= 0.0 && rho <= 1.0)) { nhp_set_error(ctx, "link probability must lie in [0, 1]"); return NHP_EDOMAIN; }
     NHP_HIP(ctx, hipSetDevice(ctx->device));

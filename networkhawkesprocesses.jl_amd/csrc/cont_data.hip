@@ -42,8 +42,24 @@ extern "C" nhp_status nhp_cont_dataset_create(nhp_ctx *ctx, const double *events
                                               int64_t M, int32_t N, double duration, double dt_max,
                                               nhp_cont_dataset **out)
 {
+    return nhp_cont_dataset_create_columns(ctx, events, nodes, M, N, duration, dt_max, 0, N, out);
+}
+
+bool nhp_is_column_shard(const nhp_cont_dataset *ds) { return ds->col_begin != 0 || ds->col_end != ds->N; }
+
+// The log-likelihood is a sum over child nodes c of  -∫λ0_c - Σ_p cnt[p]·W[p,c] + Σ_{i: c_i = c} log λ_i  and the
+// gradient is block-separable in the same columns, so one evaluation shards over GPUs by column range: every shard
+// holds all events (they are all parents) but builds work items only for its own columns (second way).
+extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double *events, const int64_t *nodes,
+                                                      int64_t M, int32_t N, double duration, double dt_max,
+                                                      int32_t col_begin, int32_t col_end, nhp_cont_dataset **out)
+{
     if (!ctx || !out || M < 0 || N < 1 || (M > 0 && (!events || !nodes))) return NHP_EINVAL;
     *out = nullptr;
+    if (col_begin < 0 || col_end > N || col_begin >= col_end) {
+        nhp_set_error(ctx, "column range [%d, %d) must be a non-empty part of [0, %d)", col_begin, col_end, N);
+        return NHP_EINVAL;
+    }
     if (M >= (int64_t)1 << 31) { nhp_set_error(ctx, "n_events must be < 2^31"); return NHP_EINVAL; }
     if (!(duration >= 0.0)) { nhp_set_error(ctx, "duration must be non-negative"); return NHP_EDOMAIN; }
     if (!(dt_max > 0.0)) { nhp_set_error(ctx, "dt_max must be positive"); return NHP_EDOMAIN; }
@@ -59,6 +75,7 @@ extern "C" nhp_status nhp_cont_dataset_create(nhp_ctx *ctx, const double *events
 
     nhp_cont_dataset *ds = new nhp_cont_dataset();
     ds->ctx = ctx; ds->M = M; ds->N = N; ds->duration = duration; ds->dt_max = dt_max;
+    ds->col_begin = col_begin; ds->col_end = col_end;
     ds->t_last = M > 0 ? events[M - 1] : 0.0;
 
     std::vector<int32_t> node32((size_t)M), first((size_t)M);
@@ -143,6 +160,12 @@ extern "C" nhp_status nhp_cont_dataset_create(nhp_ctx *ctx, const double *events
             it.first = q == 0;
             items.push_back(it);
         }
+    }
+    if (col_begin != 0 || col_end != N) {          // a column shard keeps the items of its own columns
+        std::vector<nhp_item> own;
+        for (const nhp_item &it : items)
+            if (it.node >= col_begin && it.node < col_end) own.push_back(it);
+        items.swap(own);
     }
     ds->n_items = (int32_t)items.size();
     for (const nhp_item &it : items) ds->max_item = std::max(ds->max_item, it.kend - it.kbeg);
@@ -332,6 +355,7 @@ nhp_cont_args nhp_make_args(const nhp_cont_dataset *ds, const nhp_cont_model *m)
     a.items = ds->d_items; a.cnt = ds->d_cnt;
     a.lambda0 = m->d_lambda0; a.grid = m->d_grid; a.p1 = m->d_p1; a.p2 = m->d_p2; a.W = m->d_W;
     a.A = m->has_A ? m->d_A : nullptr;
+    a.col_begin = ds->col_begin; a.col_end = ds->col_end;
     a.M = ds->M; a.N = ds->N; a.grid_n = m->grid_n; a.baseline_kind = m->baseline_kind;
     a.impulse_kind = m->impulse_kind; a.dt_max = ds->dt_max; a.inv_dtmax = 1.0 / ds->dt_max;
     a.duration = ds->duration;

@@ -74,6 +74,13 @@ __global__ __launch_bounds__(256) void k_grad_init(nhp_cont_args a, int mask_int
     const size_t P = nb + nimp + NN;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x) {
         double v = 0.0;
+        // a column shard owns the terms of its child nodes only; everything else stays 0 so that shards add up
+        const size_t col = i < nb ? (a.baseline_kind == NHP_BASELINE_HOMOGENEOUS ? i : i / (size_t)a.grid_n)
+                                  : ((i - nb) % NN) / N;
+        if (col < (size_t)a.col_begin || col >= (size_t)a.col_end) {
+            grad[i] = 0.0;
+            continue;
+        }
         if (i < nb) {
             if (a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) {
                 v = -a.duration;
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_grad_recursive(nhp_cont_args a, d
     double *nS = R + a.N, *nR = nS + a.N;                        // segment accumulators referenced to t_k
     double *GS = nR + a.N, *GR = GS + a.N;                       // Σ_k g_k S_p(t_k), Σ_k g_k R_p(t_k)
 
-    const int c = blockIdx.x, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = a.col_begin + blockIdx.x, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double integ = 0.0;
     for (int p = tid; p < N; p += NHP_BLOCK) {
         const size_t k = (size_t)p + (size_t)c * N;
@@ -243,8 +250,8 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_grad_recursive(nhp_cont_args a, d
     const double blk = nhp_block_sum(logsum, red);
     const double blk_int = nhp_block_sum(integ, red);
     if (tid == 0) {
-        partials[2 * (size_t)c] = blk;
-        partials[2 * (size_t)c + 1] = blk_int;
+        partials[2 * (size_t)blockIdx.x] = blk;
+        partials[2 * (size_t)blockIdx.x + 1] = blk_int;
         if (a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) grad[c] = -a.duration + gsum;
     }
 }
@@ -297,13 +304,16 @@ extern "C" nhp_status nhp_cont_loglik_grad(nhp_ctx *ctx, const nhp_cont_dataset 
         if (lds > 64 * 1024)
             NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_grad_recursive, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * N));
-        if (lgcp) {      // the grid-intensity block is accumulated with atomics: start it from the integral's derivative
+        // the grid-intensity block is accumulated with atomics: start it from the integral's derivative; a column shard
+        // needs the zeros of the columns it does not own
+        if (lgcp || nhp_is_column_shard(ds)) {
             hipLaunchKernelGGL(k_grad_init, dim3(1024), dim3(256), 0, st, a, 0, d_grad);
             NHP_HIP(ctx, hipGetLastError());
         }
-        hipLaunchKernelGGL(k_grad_recursive, dim3((unsigned)N), dim3(NHP_BLOCK), lds, st, a, ctx->d_partials, d_grad);
+        const int ncol = ds->col_end - ds->col_begin;
+        hipLaunchKernelGGL(k_grad_recursive, dim3((unsigned)ncol), dim3(NHP_BLOCK), lds, st, a, ctx->d_partials, d_grad);
         NHP_HIP(ctx, hipGetLastError());
-        NHP_TRY(nhp_launch_finalize(ctx, a, (int)N, ctx->d_results));
+        NHP_TRY(nhp_launch_finalize(ctx, a, ncol, ctx->d_results));
     } else {
         const int mask = child_cut ? 0 : 1;
         const int G = child_cut ? cut_group : ds->group;

@@ -58,7 +58,7 @@ __device__ __forceinline__ double baseline_at(const nhp_cont_args &a, int c, dou
 __device__ __forceinline__ double baseline_integral_part(const nhp_cont_args &a)
 {
     double sb = 0.0;
-    for (int c = threadIdx.x; c < a.N; c += blockDim.x) {
+    for (int c = a.col_begin + threadIdx.x; c < a.col_end; c += blockDim.x) {
         if (a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) {
             sb += a.lambda0[c] * a.duration;
         } else {
@@ -615,6 +615,7 @@ extern "C" nhp_status nhp_cont_event_intensity(nhp_ctx *ctx, const nhp_cont_data
 {
     if (!lambda) return NHP_EINVAL;
     NHP_TRY(nhp_check_pair(ctx, ds, m));
+    NHP_WHOLE_DATASET(ctx, ds, "event_intensity");
     NHP_TRY(nhp_ctx_reserve_scratch(ctx, sizeof(double) * (size_t)(ds->M > 0 ? ds->M : 1)));
     NHP_TRY(nhp_launch_event_intensity(ctx, ds, m, (double *)ctx->d_scratch));
     NHP_HIP(ctx, hipMemcpyAsync(lambda, ctx->d_scratch, sizeof(double) * (size_t)ds->M, hipMemcpyDeviceToHost, ctx->stream));

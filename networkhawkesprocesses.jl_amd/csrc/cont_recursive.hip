@@ -58,7 +58,7 @@ __global__ __launch_bounds__(BLOCK) void k_recursive(nhp_cont_args a, double *__
     double *acc0 = th + a.N;                                     // [N] segment accumulators (double-buffered)
     double *acc1 = acc0 + a.N;
 
-    const int c = blockIdx.x, N = a.N, tid = threadIdx.x;
+    const int c = a.col_begin + blockIdx.x, N = a.N, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
 
     double S[REC_PQ], thr[REC_PQ], wthr[REC_PQ];
@@ -142,8 +142,8 @@ __global__ __launch_bounds__(BLOCK) void k_recursive(nhp_cont_args a, double *__
     const double blk = nhp_block_sum_n<WAVES>(logsum, red);
     const double blk_int = nhp_block_sum_n<WAVES>(integ, red);
     if (tid == 0) {
-        partials[2 * (size_t)c] = blk;
-        partials[2 * (size_t)c + 1] = blk_int;
+        partials[2 * (size_t)blockIdx.x] = blk;
+        partials[2 * (size_t)blockIdx.x + 1] = blk_int;
     }
 }
 
@@ -318,12 +318,12 @@ static nhp_status nhp_launch_recursive_full(nhp_ctx *ctx, const nhp_cont_dataset
         const size_t lds = sizeof(double) * (8 + 2 * NHP_RING * ((B) / 64) + 3 * (size_t)ds->N);               \
         if (lds > 64 * 1024)                                                                                   \
             (void)hipFuncSetAttribute((const void *)k_recursive<B, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_recursive<B, Q>), dim3((unsigned)ds->N), dim3(B), lds, ctx->stream, a, ctx->d_partials); \
+        hipLaunchKernelGGL((k_recursive<B, Q>), dim3((unsigned)(ds->col_end - ds->col_begin)), dim3(B), lds, ctx->stream, a, ctx->d_partials); \
     } while (0)
     // measured at N = 1024, M = 1e6: 256 x 8 3.16 ms, 256 x 4 3.18, 512 x 4 3.35, 128 x 8 4.19, 64 x 16 7.35
     if (ds->N <= 2048) NHP_REC_LAUNCH(256, 8);
     else NHP_REC_LAUNCH(512, 8);
 #undef NHP_REC_LAUNCH
     NHP_HIP(ctx, hipGetLastError());
-    return nhp_launch_finalize(ctx, a, ds->N, d_out);
+    return nhp_launch_finalize(ctx, a, ds->col_end - ds->col_begin, d_out);
 }

@@ -459,6 +459,7 @@ extern "C" nhp_status nhp_cont_resample_parents(nhp_ctx *ctx, const nhp_cont_dat
                                                 int64_t *parents, int64_t *parentnodes, nhp_cont_stats *stats)
 {
     NHP_TRY(nhp_check_pair(ctx, ds, m));
+    NHP_WHOLE_DATASET(ctx, ds, "resample_parents");
     samp_out o;
     NHP_TRY(run_sampler(ctx, ds, m, u, seed, step, parents || parentnodes, stats != nullptr, &o));
     const size_t M = (size_t)ds->M, N = (size_t)ds->N, NN = N * N;
@@ -515,6 +516,7 @@ extern "C" nhp_status nhp_cont_gibbs_step(nhp_ctx *ctx, const nhp_cont_dataset *
                                           const nhp_gibbs_priors *pr, uint64_t seed, uint64_t step)
 {
     NHP_TRY(nhp_check_pair(ctx, ds, m));
+    NHP_WHOLE_DATASET(ctx, ds, "gibbs_step");
     if (!pr) return NHP_EINVAL;
     if (m->baseline_kind != NHP_BASELINE_HOMOGENEOUS) { nhp_set_error(ctx, "gibbs_step: homogeneous baseline only"); return NHP_ENOTIMPL; }
     samp_out o;

@@ -70,6 +70,9 @@ struct nhp_cont_dataset {
     double *d_times = nullptr;          // [M] time order
     int32_t *d_nodes = nullptr;         // [M] 0-based
     nhp_child *d_child = nullptr;       // [M] bucket order (time order inside a node)
+    // column shard (nhp_cont_dataset_create_columns): only children on nodes [col_begin, col_end) are evaluated, every
+    // event is still a parent; the whole dataset has col_begin = 0, col_end = N
+    int32_t col_begin = 0, col_end = 0;
     nhp_child *d_child_w = nullptr;     // [M] same, but inside each item sorted by window length (windowed kernels)
     int32_t *d_boff = nullptr;          // [N+1] bucket offsets
     nhp_item *d_items = nullptr;        // [n_items]
@@ -116,6 +119,7 @@ struct nhp_cont_args {
     const nhp_event *ev;
     const nhp_child *child;
     const nhp_child *child_w;
+    int32_t col_begin, col_end;      // columns (child nodes) this dataset owns
     const int32_t *boff;
     const nhp_item *items;
     const double *cnt;
@@ -187,6 +191,15 @@ nhp_status nhp_launch_windowed_as(nhp_ctx *ctx, const nhp_cont_dataset *ds, cons
 nhp_status nhp_ctx_reserve_scratch(nhp_ctx *ctx, size_t bytes);
 nhp_cont_args nhp_make_args(const nhp_cont_dataset *ds, const nhp_cont_model *m);
 nhp_status nhp_check_pair(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m);
+bool nhp_is_column_shard(const nhp_cont_dataset *ds);
+// entry points that need every column (samplers, intensity tables): refuse a column shard
+#define NHP_WHOLE_DATASET(ctx, ds, what)                                                                       \
+    do {                                                                                                      \
+        if (nhp_is_column_shard(ds)) {                                                                        \
+            nhp_set_error(ctx, what ": not available on a column shard (log-likelihood and gradient only)");  \
+            return NHP_ENOTIMPL;                                                                              \
+        }                                                                                                     \
+    } while (0)
 
 // launchers implemented in the kernel translation units (all asynchronous on ctx->stream)
 nhp_status nhp_launch_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_out);

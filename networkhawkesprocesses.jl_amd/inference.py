@@ -87,10 +87,14 @@ def mle_(process, data, optimizer="L-BFGS-B", verbose=False, f_abstol=1e-6, regu
         raise TypeError("mle! is defined for ContinuousStandardHawkesProcess (src/continuous.jl:144)")
     if regularize and not isinstance(process.baseline, HomogeneousProcess):
         raise NotImplementedError("logprior is not defined for LogGaussianCoxProcess in the reference (src/baselines.jl)")
-    ctx = ctx or _lib.default_context()
-    ds = device_dataset(process, data, ctx)
+    from .sharded import ShardedDataset, _all_reduce_sum
+    shard = data if isinstance(data, ShardedDataset) else None       # every rank runs the same optimizer on all-reduced values
+    ctx = (shard.ctx if shard else ctx) or _lib.default_context()
+    ds = shard.local if shard else device_dataset(process, data, ctx)
     rng = np.random.default_rng(seed)
     x0 = _rand_init_(process, rng) if guess is None else np.array(guess, dtype=np.float64)
+    if shard is not None and shard.world > 1:                        # rank 0's start everywhere
+        x0 = _all_reduce_sum(x0 if shard.rank == 0 else np.zeros_like(x0))
     lower, upper = 1e-6, 1e1
     state = {"minloss": np.inf, "steps": 0, "converged": False, "last": None}
     start = time.time()
@@ -109,6 +113,9 @@ def mle_(process, data, optimizer="L-BFGS-B", verbose=False, f_abstol=1e-6, regu
         ll_c = C.c_double()
         _lib.check(_lib.lib().nhp_cont_loglik_grad(ctx.h, ds.h, model.h, flags, C.byref(ll_c), _lib.dptr(g), P), ctx.h)
         ll = ll_c.value
+        if shard is not None:                                        # the other ranks' columns (sharded.py)
+            tot = _all_reduce_sum(np.concatenate([[ll], g]))
+            ll, g = float(tot[0]), tot[1:]
         if regularize:
             process.params_(x)
             ll += logprior(process)

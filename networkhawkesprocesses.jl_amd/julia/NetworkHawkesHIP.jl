@@ -63,13 +63,15 @@ end
 mutable struct Dataset          # (events, nodes, duration) uploaded once; pre-pass for Δtmax done
     h::Ptr{Cvoid}
 end
-function Dataset(ctx::Context, data, N::Integer, Δtmax::Real)
+# columns = 1-based node range this process evaluates (one loglikelihood over several GPUs: add the parts, e.g.
+# MPI.Allreduce(ll, +, comm)); the default is the whole dataset
+function Dataset(ctx::Context, data, N::Integer, Δtmax::Real; columns::UnitRange{Int}=1:N)
     events, nodes, duration = data
     ev, nd = Vector{Float64}(events), Vector{Int64}(nodes)
     r = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve ev nd check(ccall((:nhp_cont_dataset_create, libnhp), Int32,
-        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}, Int64, Int32, Float64, Float64, Ref{Ptr{Cvoid}}),
-        ctx.h, ev, nd, length(ev), N, duration, Δtmax, r), ctx.h)
+    GC.@preserve ev nd check(ccall((:nhp_cont_dataset_create_columns, libnhp), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}, Int64, Int32, Float64, Float64, Int32, Int32, Ref{Ptr{Cvoid}}),
+        ctx.h, ev, nd, length(ev), N, duration, Δtmax, first(columns) - 1, last(columns), r), ctx.h)
     ds = Dataset(r[])
     finalizer(d -> ccall((:nhp_cont_dataset_destroy, libnhp), Cvoid, (Ptr{Cvoid},), d.h), ds)
 end
