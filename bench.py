@@ -32,6 +32,9 @@ WORKLOADS = {
     "recursive": dict(kind="exponential", kbar=8.0, recursive=True),                 # default path: truncated window when its bound allows
     "recursive_full": dict(kind="exponential", kbar=8.0, recursive=True, full=True),  # the O(M·N) recursion itself
     "logitnormal_k8": dict(kind="logitnormal", kbar=8.0, recursive=False),
+    # SURVEY 8d "realistic" set: the events are drawn from the model itself (children clustered behind their parents,
+    # burstier windows: mean 9.1, s.d. 4.6, max 46 against 8.0 / 2.8 / 27 for the uniform times); M is what the draw gives
+    "simulated_k8": dict(kind="exponential", kbar=8.0, recursive=False, simulated=True),
 }
 
 
@@ -59,6 +62,9 @@ def run_workload(nhp, ctx, name, N, M, steps, warmup, sync):
     w = WORKLOADS[name]
     times, nodes, T = nhp.synthetic.s_metric_data(N, M, kbar=w["kbar"])
     proc = nhp.synthetic.s_metric_process(N, M, T, w["kind"], 1.0)
+    if w.get("simulated"):
+        times, nodes, T = nhp.synthetic.simulated_data(proc, T, seed=0)
+        M = len(times)
     ds = nhp.device_dataset(proc, (times, nodes, T), ctx)
     model = proc.device_model(ctx)
     flags = (_lib.LL_RECURSIVE if w["recursive"] else 0) | (_lib.LL_FULL_RECURSION if w.get("full") else 0)
@@ -109,6 +115,36 @@ def cpu_baseline(r, budget_s=12.0):
     return dict(value=1.0 / (ts * M / m), unit="log-likelihood evals/sec", cores=1, kind="port",
                 sample=f"oracle C restatement, 1 thread, first {m} of {M} events, median of {len(runs)} runs "
                        f"({ts:.3f} s each), scaled linearly to M; row sums of W hoisted (stronger baseline)")
+
+
+def cpu_baseline_all_cores(r, budget_s=6.0):
+    """the reference's `Threads.@threads` branch (src/continuous.jl:224-232) restated with OpenMP, on
+    every core the box gives this process; windowed formulation only (the reference's recursion is serial)."""
+    from oracle import oracle as orc
+    times, nodes, T = r["data"]
+    proc = r["proc"]
+    kw = dict(theta=proc.impulses.θ) if r["kind"] == "exponential" else dict(mu=proc.impulses.μ, tau=proc.impulses.τ)
+    om = orc.ContModel(proc.baseline.λ, proc.weights.W, dt_max=1.0, **kw)
+    M = len(times)
+    threads = max(1, min(orc.max_threads(), len(os.sched_getaffinity(0))))
+
+    def run(m):
+        t0 = time.perf_counter()
+        orc.loglik_windowed_mt(om, times[:m], nodes[:m], T * m / M, flags=orc.FAST_INTEGRAL, threads=threads)
+        return time.perf_counter() - t0
+
+    run(min(M, 20_000))                                   # start the thread pool
+    m = min(M, 200_000)
+    tp = run(m)
+    m = int(min(M, max(m, m * 1.0 / max(tp, 1e-6))))      # ~1 s per run
+    runs, spent = [], 0.0
+    while not runs or (spent < budget_s and len(runs) < 50):
+        runs.append(run(m))
+        spent += runs[-1]
+    ts = sorted(runs)[len(runs) // 2]
+    return dict(value=1.0 / (ts * M / m), unit="log-likelihood evals/sec", cores=threads, kind="port",
+                sample=f"oracle C restatement of the threaded branch, {threads} OpenMP threads, first {m} of {M} events, "
+                       f"median of {len(runs)} runs ({ts:.3f} s each), scaled linearly to M")
 
 
 def config_workloads(nhp, ctx, which):
@@ -239,6 +275,34 @@ def sharded_leg(nhp, ctx, N, M, world, names):
     return out
 
 
+def chains_leg(nhp, ctx, rank, steps, sync):
+    """N>1 only (BASELINE config 5): every rank runs its own mcmc! chain of the config-3 model -- parents, statistics,
+    conjugate draws and the adjacency sweep on the device, chain seed = rank -- with no exchange between chains
+    (src/inference.jl:49-70 has no cross-chain term).  Returns this rank's wall time for `steps` steps."""
+    import ctypes as C
+    from nhp_amd import _lib, inference, chains
+    N, M = 1024, 1_000_000
+    times, nodes, T = nhp.synthetic.s_metric_data(N, M, kbar=8.0)
+    proc = nhp.synthetic.s_metric_process(N, M, T, "logitnormal", 1.0, network=True)
+    ds = nhp.device_dataset(proc, (times, nodes, T), ctx)
+    model, pri = proc.device_model(ctx), inference._priors(proc)
+    seed = chains.chain_seed(1, rank)
+
+    def step(k):
+        _lib.check(_lib.lib().nhp_cont_gibbs_step(ctx.h, ds.h, model.h, C.byref(pri), seed, k), ctx.h)
+        inference.resample_adjacency_matrix_(proc, ds, seed=seed, step=k, model=model, fetch=False, ctx=ctx)
+    for k in range(3):
+        step(k)
+    ctx.synchronize()
+    sync()
+    t0 = time.perf_counter()
+    for k in range(3, 3 + steps):
+        step(k)
+    ctx.synchronize()
+    sync()
+    return time.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,12 +311,14 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("NHP_BENCH_WORKLOAD", "windowed_k8"), choices=sorted(WORKLOADS))
     ap.add_argument("--nodes", type=int, default=1024)
     ap.add_argument("--events", type=int, default=1_000_000)
-    ap.add_argument("--extra", default=os.environ.get("NHP_BENCH_EXTRA", "windowed_k64,windowed_k512,recursive,recursive_full"),
+    ap.add_argument("--extra", default=os.environ.get("NHP_BENCH_EXTRA", "windowed_k64,windowed_k512,simulated_k8,recursive,recursive_full"),
                     help="comma list of secondary workloads reported under 'other_workloads' (N=1 only)")
     ap.add_argument("--configs", default=os.environ.get("NHP_BENCH_CONFIGS", "c2,c3,c4"),
                     help="comma list of BASELINE configs measured as secondary workloads (N=1 only); '' to skip")
     ap.add_argument("--sharded", default=os.environ.get("NHP_BENCH_SHARDED", "windowed_k512,recursive_full"),
                     help="comma list of workloads whose single evaluation is also column-sharded over the ranks (N>1 only); '' to skip")
+    ap.add_argument("--chain-steps", type=int, default=int(os.environ.get("NHP_BENCH_CHAIN_STEPS", "50")),
+                    help="mcmc! steps per rank of the config-5 leg (N>1 only); 0 to skip")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -295,6 +361,11 @@ def main():
         if rank == 0:
             lls = torch.cat(gathered)
     wall_s = float(wall.item())
+    chain_wall = None
+    if world > 1 and args.chain_steps > 0:
+        tw = torch.tensor([chains_leg(nhp, ctx, rank, args.chain_steps, sync)], dtype=torch.float64, device=tdev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        chain_wall = float(tw.item())
     sharded = None
     if world > 1 and args.sharded:
         sharded = sharded_leg(nhp, ctx, args.nodes, args.events, world, [x for x in args.sharded.split(",") if x])
@@ -320,11 +391,22 @@ def main():
                          "pair_rate_per_s": r["pairs"] / (ms_kernel * 1e-3)},
             "loglik": [float(v) for v in lls.cpu()],
         }
+        if chain_wall is not None:
+            out["config5_independent_chains"] = {
+                "workload": "c3 model (N=1024, M=1e6, logit-normal network), one mcmc! chain per rank, device-side sweep",
+                "chains": world, "steps_per_chain": args.chain_steps,
+                "mcmc_steps_per_sec": world * args.chain_steps / chain_wall, "ms_per_step": 1e3 * chain_wall / args.chain_steps}
         if sharded is not None:
             out["one_evaluation_over_all_ranks"] = sharded
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(r)
             out["speedup_vs_cpu_core"] = out["value"] / out["cpu_baseline"]["value"]
+            if not r["recursive"]:
+                try:
+                    out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(r)
+                    out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline_all_cores"]["value"]
+                except Exception as exc:      # secondary number
+                    out["cpu_baseline_all_cores"] = {"error": repr(exc)}
         if world == 1 and args.extra:
             others = []
             for name in [s for s in args.extra.split(",") if s and s != args.workload]:
@@ -334,7 +416,7 @@ def main():
                 mk = o["dev_ms"] / steps
                 # exponential pair terms/s against the calibrated fp64-VALU ceiling (nhp_probe_rate, tools/rate.py);
                 # the recursive path evaluates 2·M·N exponentials per call
-                entry = {"workload": name, "value": steps / o["wall"], "kernel_ms": mk, "steps": steps,
+                entry = {"workload": name, "events": o["M"], "value": steps / o["wall"], "kernel_ms": mk, "steps": steps,
                          "pairs_per_eval": o["pairs"], "hbm_frac": Bo / (mk * 1e-3) / 1e9 / HBM_PEAK_GBS, "loglik": o["ll"]}
                 if name != "recursive":        # (the default recursive path runs a model-dependent truncated window)
                     terms = 2.0 * o["M"] * o["N"] if name == "recursive_full" else float(o["pairs"])

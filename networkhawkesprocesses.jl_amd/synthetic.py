@@ -74,6 +74,43 @@ def branching_sample(lam0, W, theta, duration, seed=0, max_events=2_000_000):
     return times[order], (nodes[order] + 1).astype(np.int64), float(duration)
 
 
+def simulated_data(process, duration, seed=0, max_events=20_000_000):
+    """Events drawn from `process` itself (exponential impulses, homogeneous baseline) at benchmark sizes: the same
+    generative model as branching_sample -- Poisson(W[p,c]) children of every event at Exponential(1/θ[p,c]) delays,
+    src/continuous.jl:16-48 -- with the N Poisson draws per event merged into one Poisson(Σ_c W[p,c]) count and a
+    categorical child node (Poisson splitting), so a generation costs O(events), not O(events·N).  Children are
+    clustered behind their parents: look-back windows are burstier than the uniform S-metric times."""
+    rng = np.random.default_rng(seed)
+    lam0 = np.asarray(process.baseline.λ, float)
+    N = len(lam0)
+    W = np.asarray(process.weights.W, float) * getattr(process, "adjacency_matrix", np.ones((N, N)))
+    theta = np.asarray(process.impulses.θ, float)
+    rows = W.sum(axis=1)
+    G = np.cumsum(W.ravel())                                   # row-major running sum: row p is G[p*N : (p+1)*N]
+    start = np.concatenate([[0.0], G[N - 1::N][:-1]])           # running sum before row p
+    n0 = rng.poisson(lam0 * duration)
+    gen_t = rng.uniform(0.0, duration, int(n0.sum()))
+    gen_n = np.repeat(np.arange(N), n0)
+    times, nodes, total = [], [], 0
+    while len(gen_t):
+        times.append(gen_t)
+        nodes.append(gen_n)
+        total += len(gen_t)
+        if total > max_events:
+            raise RuntimeError("branching process exploded (unstable weights?)")
+        k = rng.poisson(rows[gen_n])
+        par_t, par_n = np.repeat(gen_t, k), np.repeat(gen_n, k)
+        u = rng.uniform(size=len(par_n))
+        flat = np.searchsorted(G, start[par_n] + u * rows[par_n], side="right")
+        child_n = np.clip(flat - par_n * N, 0, N - 1)
+        child_t = par_t + rng.exponential(1.0 / theta[par_n, child_n])
+        keep = child_t <= duration
+        gen_t, gen_n = child_t[keep], child_n[keep]
+    times, nodes = np.concatenate(times), np.concatenate(nodes)
+    order = np.argsort(times, kind="stable")
+    return times[order], (nodes[order] + 1).astype(np.int64), float(duration)
+
+
 def readme_case(seed=0):
     """C1: the README model verbatim (README.md:27-34): N=2, λ0=1, W=0.1, θ=1, Δtmax=Inf, T=1000."""
     N, T = 2, 1000.0

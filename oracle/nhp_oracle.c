@@ -8,6 +8,9 @@
  * StatsFuns 1.1.1, LogExpFunctions 0.3.19, SpecialFunctions 2.2.0, DSP 0.7.7,
  * Julia Base 1.8 reductions -- restated from their published algorithms.
  */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "nhp_oracle.h"
 #include "nhp_detmath.h"
 
@@ -229,6 +232,45 @@ int orc_cont_loglik_windowed(const orc_cont_model *m, const double *times, const
     }
     *ll_out = ll;
     return ORC_OK;
+}
+
+/* The threaded branch of the same function: src/continuous.jl:224-232 (`Threads.@threads` over the events, one
+ * atomic add per event), network twin :374-382.  OpenMP threads with a per-thread partial sum instead of the atomic --
+ * the sum's association differs from the serial branch's exactly as the reference's own does.  Used as the all-cores CPU
+ * baseline of bench.py (SURVEY 8d ii); `threads` <= 0 takes the OpenMP default. */
+int orc_cont_loglik_windowed_mt(const orc_cont_model *m, const double *times, const int64_t *nodes,
+                                int64_t M, double duration, int flags, int threads, double *ll_out)
+{
+    int rc = validate_data(m, times, nodes, M);
+    if (rc) return rc;
+    double ll;
+    rc = integral_terms(m, nodes, M, duration, 1, flags, &ll);
+    if (rc) return rc;
+    double acc = 0.0;
+    int bad = 0;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel for num_threads(threads) reduction(+ : acc) reduction(| : bad) schedule(static)
+#endif
+    for (int64_t i = 0; i < M; ++i) {
+        double lam;
+        int r = total_intensity(m, times, nodes, i, flags, &lam);
+        if (r) { bad |= r; continue; }
+        acc += xlog(lam, flags);
+    }
+    (void)threads;
+    if (bad) return bad;
+    *ll_out = ll + acc;
+    return ORC_OK;
+}
+
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
 }
 
 /* recursive_loglikelihood: src/continuous.jl:241-276 (standard), :407-442 (network;

@@ -64,6 +64,10 @@ double orc_linear_integrate(const double *x, const double *y, int32_t n);
 /* ---- continuous log-likelihood (src/continuous.jl:210-305,360-442,521-531) */
 int orc_cont_loglik_windowed(const orc_cont_model *m, const double *times, const int64_t *nodes,
                              int64_t M, double duration, int flags, double *ll);
+/* threaded branch (src/continuous.jl:224-232); all-cores CPU baseline */
+int orc_cont_loglik_windowed_mt(const orc_cont_model *m, const double *times, const int64_t *nodes,
+                                int64_t M, double duration, int flags, int threads, double *ll_out);
+int orc_max_threads(void);
 int orc_cont_loglik_recursive(const orc_cont_model *m, const double *times, const int64_t *nodes,
                               int64_t M, double duration, int flags, double *ll);
 /* per-event total intensity, lambda[i] for i in [i0,i1) (src/continuous.jl:286-300) */

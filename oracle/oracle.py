@@ -121,6 +121,18 @@ def loglik_windowed(model, times, nodes, duration, flags=0):
     return out.value
 
 
+def loglik_windowed_mt(model, times, nodes, duration, flags=0, threads=0):
+    """The reference's Threads.@threads branch (src/continuous.jl:224-232) on `threads` OpenMP threads (0 = all)."""
+    t, n, tp, np_, M = _data(times, nodes)
+    out = C.c_double()
+    _chk(lib().orc_cont_loglik_windowed_mt(C.byref(model.c), tp, np_, M, C.c_double(duration), flags, int(threads), C.byref(out)))
+    return out.value
+
+
+def max_threads():
+    return int(lib().orc_max_threads())
+
+
 def loglik_recursive(model, times, nodes, duration, flags=0):
     t, n, tp, np_, M = _data(times, nodes)
     out = C.c_double()

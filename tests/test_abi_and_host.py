@@ -170,3 +170,24 @@ def test_simulators_have_the_right_first_moments(nhp):
     assert data.shape == (2, 20000) and data.min() >= 0
     drate = np.linalg.solve(np.eye(2) - np.full((2, 2), 0.2), np.array([0.2, 0.4]))
     assert np.all(np.abs(data.mean(axis=1) - drate) / drate < 0.08), (data.mean(axis=1), drate)
+
+
+def test_fast_simulator_matches_the_generation_wise_one(nhp):
+    """synthetic.simulated_data merges the N Poisson draws per event into one count plus a categorical child node
+    (Poisson splitting): same law as branching_sample, checked on event counts per node and on the mean delay."""
+    rng = np.random.default_rng(1)
+    N = 5
+    lam0, W, th = rng.uniform(0.5, 1.5, N), rng.uniform(0, 1, (N, N)) / N, rng.uniform(1, 5, (N, N))
+    p = nhp.ContinuousStandardHawkesProcess(nhp.HomogeneousProcess(lam0), nhp.ExponentialImpulseResponse(th, 1.0, 1.0, np.inf),
+                                            nhp.DenseWeightModel(W))
+    T = 20000.0
+    a = nhp.synthetic.simulated_data(p, T, seed=3)
+    b = nhp.synthetic.branching_sample(lam0, W, th, T, seed=4)
+    assert np.all(np.diff(a[0]) >= 0) and a[1].min() >= 1 and a[1].max() <= N and a[2] == T
+    ca, cb = np.bincount(a[1], minlength=N + 1)[1:], np.bincount(b[1], minlength=N + 1)[1:]
+    want = np.linalg.solve(np.eye(N) - W.T, lam0) * T                    # stationary rates: (I - Wᵀ)⁻¹ λ0
+    assert np.all(np.abs(ca - want) < 6 * np.sqrt(want) * 1.5) and np.all(np.abs(cb - want) < 6 * np.sqrt(want) * 1.5)
+    with pytest.raises(RuntimeError):
+        nhp.synthetic.simulated_data(nhp.ContinuousStandardHawkesProcess(
+            nhp.HomogeneousProcess(lam0), nhp.ExponentialImpulseResponse(th, 1.0, 1.0, np.inf), nhp.DenseWeightModel(W * 8)),
+            200.0, seed=0, max_events=100_000)

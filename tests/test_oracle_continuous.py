@@ -224,3 +224,24 @@ def test_gradient_finite_differences(orc, kind, recursive):
         xm[k] -= h
         fd = (f(xp) - f(xm)) / (2 * h)
         assert abs(fd - g[k]) < 1e-5 * max(1.0, abs(g[k])), (k, fd, g[k])
+
+
+@pytest.mark.parametrize("kind", ["exponential", "logitnormal"])
+def test_threaded_branch_equals_serial_branch(orc, kind):
+    """src/continuous.jl:224-232 (Threads.@threads + atomic add) against :233-237 (serial): the same terms in another
+    association; the all-cores CPU baseline of bench.py."""
+    rng = np.random.default_rng(8)
+    N, M, T = 6, 4000, 300.0
+    t = np.sort(rng.uniform(0, T, M))
+    n = rng.integers(1, N + 1, M)
+    kw = dict(theta=rng.uniform(1, 5, (N, N))) if kind == "exponential" else dict(mu=rng.normal(0, 1, (N, N)), tau=rng.uniform(0.5, 2, (N, N)))
+    A = (rng.uniform(size=(N, N)) < 0.5).astype(np.float64)
+    om = orc.ContModel(rng.uniform(0.5, 1.5, N), rng.uniform(0, 1, (N, N)) / N, dt_max=1.5, A=A, **kw)
+    want = orc.loglik_windowed(om, t, n, T)
+    for threads in (1, 2, 0):
+        got = orc.loglik_windowed_mt(om, t, n, T, threads=threads)
+        assert abs(got - want) <= 1e-12 * abs(want)
+    assert orc.loglik_windowed_mt(om, t[:0], n[:0], T) == orc.loglik_windowed(om, t[:0], n[:0], T)
+    assert orc.max_threads() >= 1
+    with pytest.raises(Exception):                         # validation errors still surface from inside the threads' caller
+        orc.loglik_windowed_mt(om, t[::-1].copy(), n, T)
