@@ -50,13 +50,13 @@ __device__ __forceinline__ double rec_baseline(const nhp_cont_args &a, int c, do
 template <int BLOCK, int PQ>
 __global__ __launch_bounds__(BLOCK) void k_recursive(nhp_cont_args a, double *__restrict__ partials)
 {
-    constexpr int WAVES = BLOCK / 64, REC_PQ = PQ;
+    constexpr int WAVES = BLOCK / 64, REC_PQ = PQ, NP = BLOCK * PQ;   // NP >= N padded state slots: no bounds branches
     extern __shared__ __align__(16) unsigned char smem[];
     double *red = reinterpret_cast<double *>(smem);              // [8]
     double *ring = red + 8;                                      // [2][NHP_RING * WAVES]
-    double *th = ring + 2 * NHP_RING * WAVES;                // [N] θ[p,c]
-    double *acc0 = th + a.N;                                     // [N] segment accumulators (double-buffered)
-    double *acc1 = acc0 + a.N;
+    double *th = ring + 2 * NHP_RING * WAVES;                    // [NP] θ[p,c]
+    double *acc0 = th + NP;                                      // [NP] segment accumulators (double-buffered)
+    double *acc1 = acc0 + NP;
 
     const int c = a.col_begin + blockIdx.x, N = a.N, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -67,13 +67,14 @@ __global__ __launch_bounds__(BLOCK) void k_recursive(nhp_cont_args a, double *__
     for (int q = 0; q < REC_PQ; ++q) {
         const int p = tid + q * BLOCK;
         S[q] = 0.0; thr[q] = 0.0; wthr[q] = 0.0;
+        th[p] = 0.0; acc0[p] = 0.0; acc1[p] = 0.0;               // slots p >= N stay (θ, aWθ, S) = 0
         if (p < N) {
             const size_t k = (size_t)p + (size_t)c * N;
             const double w = a.W[k];
             const double weff = a.A ? a.A[k] * w : w;
             const double t = a.p1[k];
             thr[q] = t; wthr[q] = weff * t;
-            th[p] = t; acc0[p] = 0.0; acc1[p] = 0.0;
+            th[p] = t;
             integ += a.cnt[p] * w;                               // unmasked: src/continuous.jl:247,413
         }
     }
@@ -82,11 +83,24 @@ __global__ __launch_bounds__(BLOCK) void k_recursive(nhp_cont_args a, double *__
     const int kb = a.boff[c], ke = a.boff[c + 1];
     double logsum = 0.0;
 
-    // fold the events of [jb, je) into acc, referenced to time tk  (t_j > 0: the D9 seen-flag)
+    // fold events into acc, referenced to time tk  (t_j > 0: the D9 seen-flag).  The FU exponentials of a thread are
+    // evaluated unconditionally (clamped records) and only the atomics are predicated: one basic block, so the
+    // independent polynomial chains interleave instead of running one masked block after the other.
+    constexpr int FU = 4;                                        // events per thread in flight together
+    auto fold_regs = [&](double *acc, const nhp_event *e, int j0, int je, double tk) {
+        double v[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) v[u] = nhp_exp_neg(-(th[e[u].node] * (tk - e[u].t)));
+#pragma unroll
+        for (int u = 0; u < FU; ++u)
+            if (j0 + u * BLOCK < je && e[u].t > 0.0) atomicAdd(&acc[e[u].node], v[u]);
+    };
     auto fold = [&](double *acc, int jb, int je, double tk) {
-        for (int j = jb + tid; j < je; j += BLOCK) {
-            const nhp_event e = a.ev[j];
-            if (e.t > 0.0) atomicAdd(&acc[e.node], nhp_exp_neg(-(th[e.node] * (tk - e.t))));
+        for (int j0 = jb + tid; j0 < je; j0 += FU * BLOCK) {
+            nhp_event e[FU];
+#pragma unroll
+            for (int u = 0; u < FU; ++u) e[u] = a.ev[j0 + u * BLOCK < je ? j0 + u * BLOCK : j0];
+            fold_regs(acc, e, j0, je, tk);
         }
     };
 
@@ -98,7 +112,8 @@ __global__ __launch_bounds__(BLOCK) void k_recursive(nhp_cont_args a, double *__
     if (kb + 1 < ke) { nx_t = a.child[kb + 1].t; nx_idx = a.child[kb + 1].idx; }
     if (kb < ke) fold(acc0, 0, ch_idx, ch_t);
     __syncthreads();
-    double prev_t = ch_t;
+    double prev_t = ch_t;                                        // first child: gap 0, exp(-0) = 1 on S = 0
+    double pending = 0.0;                                        // child k-1's lane partial: reduced under child k's math
     for (int k = kb; k < ke; ++k) {
         const int par = (k - kb) & 1;
         double *accA = par ? acc0 : acc1;                        // filled now, consumed next iteration
@@ -106,30 +121,41 @@ __global__ __launch_bounds__(BLOCK) void k_recursive(nhp_cont_args a, double *__
         const int kn = k + 2 < ke ? k + 2 : ke - 1;
         const double nn_t = a.child[kn].t;
         const int nn_idx = a.child[kn].idx;
-        if (k + 1 < ke) fold(accA, ch_idx, nx_idx, nx_t);
+        // the first FU events per thread of the next segment are requested before the decay and folded after it, so
+        // their latency hides under the decay's exponentials; longer segments finish in the ordinary loop
+        const bool more = k + 1 < ke;
+        const int fb = ch_idx + tid, fe = more ? nx_idx : ch_idx;
+        nhp_event pe[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) pe[u] = a.ev[fb + u * BLOCK < fe ? fb + u * BLOCK : 0];
         // decay the state to t_k, merge segment k, dot with the weights
         const double gap = ch_t - prev_t;
         double part = 0.0;
 #pragma unroll
         for (int q = 0; q < REC_PQ; ++q) {
             const int p = tid + q * BLOCK;
-            if (p < N) {
-                double s = S[q];
-                if (k != kb) s *= nhp_exp_neg(-(thr[q] * gap));
-                s += accB[p];
-                accB[p] = 0.0;
-                S[q] = s;
-                part += wthr[q] * s;
-            }
+            double s = S[q] * nhp_exp_neg(-(thr[q] * gap));
+            s += accB[p];
+            accB[p] = 0.0;
+            S[q] = s;
+            part += wthr[q] * s;
         }
-        part = nhp_wave_sum(part);
-        const int slot = (k - kb) & (NHP_RING - 1);
-        const int half = ((k - kb) / NHP_RING) & 1;
-        if (lane == 0) ring[(half * NHP_RING + slot) * WAVES + wave] = part;
+        // child k-1's reduction: independent of everything above, so its cross-lane latency is covered
+        if (k > kb) {
+            const double r = nhp_wave_sum(pending);
+            const int o = k - 1 - kb;
+            if (lane == 0) ring[(((o / NHP_RING) & 1) * NHP_RING + (o & (NHP_RING - 1))) * WAVES + wave] = r;
+        }
+        pending = part;
+        fold_regs(accA, pe, fb, fe, nx_t);
+        if (more) fold(accA, ch_idx + FU * BLOCK, nx_idx, nx_t);
         __syncthreads();
-        if (slot == NHP_RING - 1 || k == ke - 1) {
-            if (tid <= slot) {
-                const double tk = a.child[k - slot + tid].t;
+        // logs of a full half of the ring (children k-64 .. k-1), one lane each
+        const int done = k - kb;                                 // children whose partials are in the ring
+        if (done > 0 && (done & (NHP_RING - 1)) == 0) {
+            const int half = ((done - 1) / NHP_RING) & 1;
+            if (tid < NHP_RING) {
+                const double tk = a.child[k - NHP_RING + tid].t;
                 double lam = rec_baseline(a, c, tk);
                 for (int w = 0; w < WAVES; ++w) lam += ring[(half * NHP_RING + tid) * WAVES + w];
                 logsum += nhp_log(lam);
@@ -138,6 +164,19 @@ __global__ __launch_bounds__(BLOCK) void k_recursive(nhp_cont_args a, double *__
         prev_t = ch_t;
         ch_t = nx_t; ch_idx = nx_idx;
         nx_t = nn_t; nx_idx = nn_idx;
+    }
+    if (kb < ke) {                                               // the last child's reduction and the ring's remainder
+        const int o = ke - 1 - kb;
+        const double r = nhp_wave_sum(pending);
+        if (lane == 0) ring[(((o / NHP_RING) & 1) * NHP_RING + (o & (NHP_RING - 1))) * WAVES + wave] = r;
+        __syncthreads();
+        const int slot = o & (NHP_RING - 1), half = (o / NHP_RING) & 1;
+        if (tid <= slot) {
+            const double tk = a.child[ke - 1 - slot + tid].t;
+            double lam = rec_baseline(a, c, tk);
+            for (int w = 0; w < WAVES; ++w) lam += ring[(half * NHP_RING + tid) * WAVES + w];
+            logsum += nhp_log(lam);
+        }
     }
     const double blk = nhp_block_sum_n<WAVES>(logsum, red);
     const double blk_int = nhp_block_sum_n<WAVES>(integ, red);
@@ -315,13 +354,17 @@ static nhp_status nhp_launch_recursive_full(nhp_ctx *ctx, const nhp_cont_dataset
     nhp_cont_args a = nhp_make_args(ds, m);
 #define NHP_REC_LAUNCH(B, Q)                                                                                   \
     do {                                                                                                       \
-        const size_t lds = sizeof(double) * (8 + 2 * NHP_RING * ((B) / 64) + 3 * (size_t)ds->N);               \
+        const size_t lds = sizeof(double) * (8 + 2 * NHP_RING * ((B) / 64) + 3 * (size_t)(B) * (Q));          \
         if (lds > 64 * 1024)                                                                                   \
             (void)hipFuncSetAttribute((const void *)k_recursive<B, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_recursive<B, Q>), dim3((unsigned)(ds->col_end - ds->col_begin)), dim3(B), lds, ctx->stream, a, ctx->d_partials); \
     } while (0)
-    // measured at N = 1024, M = 1e6: 256 x 8 3.16 ms, 256 x 4 3.18, 512 x 4 3.35, 128 x 8 4.19, 64 x 16 7.35
-    if (ds->N <= 2048) NHP_REC_LAUNCH(256, 8);
+    // measured at N = 1024, M = 1e6 (first version: 256 x 8 3.16 ms, 512 x 4 3.35, 128 x 8 4.19, 64 x 16 7.35); with the
+    // segment loads issued ahead of the decay and the reduction deferred by one child: 256 x 4 2.97 ms
+    if (ds->N <= 256) NHP_REC_LAUNCH(256, 1);
+    else if (ds->N <= 512) NHP_REC_LAUNCH(256, 2);
+    else if (ds->N <= 1024) NHP_REC_LAUNCH(256, 4);
+    else if (ds->N <= 2048) NHP_REC_LAUNCH(256, 8);
     else NHP_REC_LAUNCH(512, 8);
 #undef NHP_REC_LAUNCH
     NHP_HIP(ctx, hipGetLastError());
