@@ -19,6 +19,7 @@
 // child-parent delay.  A second kernel gives workgroup c the children of node c and lets
 // lane p scan them for parent node p: no atomics, every (p,c) cell accumulates in child time
 // order -- the order the reference's serial loops use -- so ΣΔt is reproducible bit for bit.
+#include <type_traits>
 #include "nhp_internal.h"
 #include "nhp_math.h"
 #include "nhp_rng.h"
@@ -303,10 +304,11 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_sampler8(nhp_cont_args a, const d
     }
 }
 
-// ---- statistics: workgroup c scans the children of c; thread t owns the parent nodes p = t (mod 256)
-// Every child is looked at once per wave: the wave whose lane owns the child's parent node takes a
-// (rare) branch and updates that node's cells in LDS -- thread-exclusive addresses, no atomics, and
-// every (p,c) cell accumulates in child time order, the order of the reference's serial loops.
+// ---- statistics: workgroup c scans the children of c, 64 at a time (one per lane, time order); wave w owns the
+// cells of the parent nodes with (p >> 6) mod 4 == w.  The lanes of a group update their cells in LDS in parallel;
+// lanes of one group that hit the SAME cell (about two pairs per group at N = 1024) are serialised lowest lane first
+// by a ticket per cell (LDS atomic min), so every (p,c) cell still accumulates in child time order -- the order of the
+// reference's serial loops, hence the same bits -- without the per-child serial visit of the first version (82 us).
 __global__ __launch_bounds__(NHP_BLOCK) void k_stats(nhp_cont_args a, const int32_t *__restrict__ pn_b,
                                                      const double *__restrict__ dt_b,
                                                      double *__restrict__ cnt0, double *__restrict__ Mn,
@@ -322,9 +324,10 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_stats(nhp_cont_args a, const int3
     int *s_pn = reinterpret_cast<int *>(sv + N);             // [NHP_BLOCK] staged parent nodes
     double *s_v = reinterpret_cast<double *>(s_pn + NHP_BLOCK);   // [NHP_BLOCK] staged values
     double *red = s_v + NHP_BLOCK;                           // [NHP_WAVES]
+    int *tag = reinterpret_cast<int *>(red + NHP_WAVES);     // [N] lowest pending lane per cell; 64 = free
     const int kb = a.boff[c], ke = a.boff[c + 1];
     const bool lognorm = a.impulse_kind == NHP_IMPULSE_LOGITNORMAL;
-    for (int p = tid; p < N; p += NHP_BLOCK) { cnt[p] = 0.0; sx[p] = 0.0; sv[p] = 0.0; }
+    for (int p = tid; p < N; p += NHP_BLOCK) { cnt[p] = 0.0; sx[p] = 0.0; sv[p] = 0.0; tag[p] = 64; }
 
     double base_cnt = 0.0;
     for (int pass = 0; pass < (lognorm ? 2 : 1); ++pass) {
@@ -344,22 +347,21 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_stats(nhp_cont_args a, const int3
             s_v[tid] = v;
             __syncthreads();
             const int nb = min(NHP_BLOCK, ke - k0);
-            // each wave picks, with one ballot per 64 staged children, the children whose owner lane it
-            // hosts (owner thread = parent node mod 256) and visits only those, in order
+            // every wave walks the staged children 64 at a time and takes those whose cell it owns
             for (int ch = 0; ch < nb; ch += 64) {
                 const int e = ch + lane;
                 const int pe = e < nb ? s_pn[e] : -1;
                 const double ve = e < nb ? s_v[e] : 0.0;
-                unsigned long long m = __ballot(pe >= 0 && ((pe >> 6) & (NHP_WAVES - 1)) == wave);
-                while (m) {
-                    const int b = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const int pb = __builtin_amdgcn_readlane(pe, b);
-                    const double vb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ve), b),
-                                                       __builtin_amdgcn_readlane(__double2loint(ve), b));
-                    if ((pb & 63) == lane) {
-                        if (pass == 0) { cnt[pb] += 1.0; sx[pb] = sx[pb] + vb; }
-                        else { const double dlt = vb - sx[pb]; sv[pb] = sv[pb] + dlt * dlt; }
+                bool pending = pe >= 0 && ((pe >> 6) & (NHP_WAVES - 1)) == wave;
+                // LDS operations of one wave execute in program order, and a cell's ticket is only ever touched by
+                // its owner wave, so min -> read -> update -> release needs no barrier
+                while (__ballot(pending)) {
+                    if (pending) (void)__hip_atomic_fetch_min(&tag[pe], lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (pending && __hip_atomic_load(&tag[pe], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == lane) {
+                        if (pass == 0) { cnt[pe] += 1.0; sx[pe] = sx[pe] + ve; }
+                        else { const double dlt = ve - sx[pe]; sv[pe] = sv[pe] + dlt * dlt; }
+                        __hip_atomic_store(&tag[pe], 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        pending = false;
                     }
                 }
             }
@@ -437,7 +439,7 @@ static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
     NHP_HIP(ctx, hipGetLastError());
     ds->pn_valid = true;
     if (want_stats) {
-        const size_t lds_stats = 8 * (3 * N + NHP_BLOCK + NHP_WAVES) + 4 * NHP_BLOCK + 16;
+        const size_t lds_stats = 8 * (3 * N + NHP_BLOCK + NHP_WAVES) + 4 * NHP_BLOCK + 4 * N + 16;
         if (lds_stats > 160 * 1024) { nhp_set_error(ctx, "statistics: n_nodes = %d exceeds the LDS budget", ds->N); return NHP_ENOTIMPL; }
         if (lds_stats > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_stats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stats);
         hipLaunchKernelGGL(k_stats, dim3((unsigned)N), dim3(NHP_BLOCK), lds_stats, st, a, o->pn_b, o->dt_b, o->cnt0, o->Mn, o->Mnm, o->X, o->V);
@@ -491,24 +493,25 @@ __global__ __launch_bounds__(256) void k_gibbs_draw(int N, int impulse_kind, dou
     const size_t NN = (size_t)N * N;
     const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (k < (size_t)N)      // λ0_c ~ Gamma(α0 + cnt0_c, 1/(β0 + T))
-        lambda0[k] = dev_gamma(pr.alpha0 + cnt0[k], 1.0 / (pr.beta0 + duration), seed ^ 0x243F6A8885A308D3ull, step, k);
+        lambda0[k] = dev_gamma(pr.alpha0 + cnt0[k], rng_rcp(pr.beta0 + duration), seed ^ 0x243F6A8885A308D3ull, step, k);
     if (k >= NN) return;
     const double m = Mnm[k];
     // W[p,c] ~ Gamma(κ + Mnm, 1/(ν + Mn[p]))
-    W[k] = dev_gamma(pr.kappa + m, 1.0 / (pr.nu + Mn[k % N]), seed ^ 0x13198A2E03707344ull, step, k);
+    W[k] = dev_gamma(pr.kappa + m, rng_rcp(pr.nu + Mn[(uint32_t)k % (uint32_t)N]), seed ^ 0x13198A2E03707344ull, step, k);
     if (impulse_kind == NHP_IMPULSE_EXPONENTIAL) {
         // θ ~ Gamma(α + Mnm, 1/(β + Mnm·Xnm))      (Xnm = 0 where Mnm = 0)
-        p1[k] = dev_gamma(pr.a + m, 1.0 / (pr.b + m * X[k]), seed ^ 0xA4093822299F31D0ull, step, k);
+        p1[k] = dev_gamma(pr.a + m, rng_rcp(pr.b + m * X[k]), seed ^ 0xA4093822299F31D0ull, step, k);
     } else {
         // τ ~ Gamma(α0 + Mnm/2, 1/βnm),  μ ~ Normal(μnm, ((κμ + Mnm)τ)^-½); NaN (no observations) -> prior
         const double x = X[k];
-        double bnm = 0.5 * V[k] + m * pr.kappa_mu / (m + pr.kappa_mu) * (x - pr.mu_mu) * (x - pr.mu_mu) * 0.5;
+        const double rkm = rng_rcp(m + pr.kappa_mu);
+        double bnm = 0.5 * V[k] + m * pr.kappa_mu * rkm * (x - pr.mu_mu) * (x - pr.mu_mu) * 0.5;
         if (bnm != bnm) bnm = pr.b;
-        double mnm = (pr.kappa_mu * pr.mu_mu + m * x) / (pr.kappa_mu + m);
+        double mnm = (pr.kappa_mu * pr.mu_mu + m * x) * rkm;
         if (mnm != mnm) mnm = pr.mu_mu;
-        const double tau = dev_gamma(pr.a + 0.5 * m, 1.0 / bnm, seed ^ 0x082EFA98EC4E6C89ull, step, k);
+        const double tau = dev_gamma(pr.a + 0.5 * m, rng_rcp(bnm), seed ^ 0x082EFA98EC4E6C89ull, step, k);
         p2[k] = tau;
-        p1[k] = mnm + dev_normal(seed ^ 0x452821E638D01377ull, step, k, 0) / sqrt((pr.kappa_mu + m) * tau);
+        p1[k] = mnm + dev_normal(seed ^ 0x452821E638D01377ull, step, k, 0) * rng_rsqrt((pr.kappa_mu + m) * tau);
     }
 }
 
