@@ -60,20 +60,45 @@ __device__ __forceinline__ double samp_baseline(const nhp_cont_args &a, int c, d
 #define SAMP_W(k) ((k) < n - 1 ? samp_weight<IMP>(a, sc, t, i - 1 - (k)) : base)
 
 // Sequential left fold over [lo, hi] -- Julia's mapreduce_impl leaf (and the n < 16 path).
-#define SAMP_CACHE 16      // weights per child kept in LDS between the sum pass and the scan pass
+#define SAMP_CACHE 16      // weights per child kept in LDS between the sum pass and the scan pass (8: 133 us vs 122 us at mean window 8)
 #define SAMP_CLD 17        // row stride (doubles): odd, so lanes reading the same k hit distinct banks
 
+template <int IMP>
+__device__ __forceinline__ double samp_weight_of(const nhp_cont_args &a, const samp_col &sc, double t, const nhp_event &e)
+{
+#pragma clang fp contract(off)
+    const double dt = t - e.t;
+    const double2 q = sc.col[e.node];
+    if (IMP == NHP_IMPULSE_EXPONENTIAL) return q.y * nhp_pdf_exponential(q.x, dt);
+    return sc.colw[e.node] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
+}
+
+// Four weights at a time: their parent records are requested together and the four pdf evaluations are independent
+// instruction streams; only the additions stay in sequence (the order is the contract).  Slots past `hi` or at the
+// baseline position evaluate a clamped record whose value is discarded.
+#define SAMP_FU 4
 template <int IMP>
 __device__ __forceinline__ double samp_fold(const nhp_cont_args &a, const samp_col &sc, double t, int i,
                                             int n, double base, int lo, int hi, double *wcache)
 {
 #pragma clang fp contract(off)
-    double v = SAMP_W(lo);
-    if (lo < SAMP_CACHE) wcache[lo] = v;
-    for (int k = lo + 1; k <= hi; ++k) {
-        const double w = SAMP_W(k);
-        if (k < SAMP_CACHE) wcache[k] = w;
-        v = v + w;
+    double v = 0.0;
+    for (int k0 = lo; k0 <= hi; k0 += SAMP_FU) {
+        nhp_event e[SAMP_FU];
+#pragma unroll
+        for (int u = 0; u < SAMP_FU; ++u) e[u] = a.ev[k0 + u < n - 1 ? i - 1 - (k0 + u) : i - 1];
+        double w[SAMP_FU];
+#pragma unroll
+        for (int u = 0; u < SAMP_FU; ++u) w[u] = samp_weight_of<IMP>(a, sc, t, e[u]);
+#pragma unroll
+        for (int u = 0; u < SAMP_FU; ++u) {
+            const int k = k0 + u;
+            if (k <= hi) {
+                const double wk = k < n - 1 ? w[u] : base;
+                if (k < SAMP_CACHE) wcache[k] = wk;
+                v = k == lo ? wk : v + wk;
+            }
+        }
     }
     return v;
 }
@@ -145,8 +170,11 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_sampler(nhp_cont_args a, const do
     __syncthreads();
     samp_col sc{col, colw};
 
-    for (int k = it.kbeg + tid; k < it.kend; k += NHP_BLOCK) {
-        const nhp_child ch = a.child[k];
+    // children in the window-sorted order of the log-likelihood kernels: the lanes of a wave then walk windows of
+    // (nearly) equal length instead of waiting for the longest of 64; results go to the child's bucket position
+    for (int kw = it.kbeg + tid; kw < it.kend; kw += NHP_BLOCK) {
+        const nhp_child ch = a.child_w[kw];
+        const int k = a.wpos[kw];
         const int i = ch.idx;
         const double t = ch.t;
         int parent = -1;
@@ -237,7 +265,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_sampler8(nhp_cont_args a, const d
     for (int k0 = 0; k0 < nchild; k0 += NHP_BLOCK / 8) {    // block-uniform trip count; idle groups are masked
         const int kq = k0 + gid;
         const bool live = kq < nchild;
-        const nhp_child ch = a.child[it.kbeg + (live ? kq : 0)];
+        const nhp_child ch = a.child_w[it.kbeg + (live ? kq : 0)];      // window-sorted order: equal chunk counts per wave
         const int i = ch.idx;
         const double t = ch.t;
         const int n = (live && i > 0) ? i - ch.first + 1 : 0;           // index == 1 -> (0, 0): src/parents.jl:26-28
@@ -298,8 +326,9 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_sampler8(nhp_cont_args a, const d
             const int pnode = parent >= 0 ? a.nodes[parent] : -1;
             if (parents) parents[i] = (int64_t)parent + 1;     // 1-based event index, 0 = baseline
             if (pnodes) pnodes[i] = (int64_t)pnode + 1;
-            pn_b[it.kbeg + kq] = pnode;
-            dt_b[it.kbeg + kq] = parent >= 0 ? t - a.times[parent] : 0.0;
+            const int kpos = a.wpos[it.kbeg + kq];              // the child's bucket position
+            pn_b[kpos] = pnode;
+            dt_b[kpos] = parent >= 0 ? t - a.times[parent] : 0.0;
         }
     }
 }

@@ -73,7 +73,8 @@ struct nhp_cont_dataset {
     // column shard (nhp_cont_dataset_create_columns): only children on nodes [col_begin, col_end) are evaluated, every
     // event is still a parent; the whole dataset has col_begin = 0, col_end = N
     int32_t col_begin = 0, col_end = 0;
-    nhp_child *d_child_w = nullptr;     // [M] same, but inside each item sorted by window length (windowed kernels)
+    nhp_child *d_child_w = nullptr;
+    int32_t *d_wpos = nullptr;          // [M] bucket position (index into `child`) of the child at each child_w position     // [M] same, but inside each item sorted by window length (windowed kernels)
     int32_t *d_boff = nullptr;          // [N+1] bucket offsets
     nhp_item *d_items = nullptr;        // [n_items]
     double *d_cnt = nullptr;            // [N] events per node
@@ -119,6 +120,7 @@ struct nhp_cont_args {
     const nhp_event *ev;
     const nhp_child *child;
     const nhp_child *child_w;
+    const int32_t *wpos;             // child_w position -> bucket position
     int32_t col_begin, col_end;      // columns (child nodes) this dataset owns
     const int32_t *boff;
     const nhp_item *items;
