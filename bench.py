@@ -92,6 +92,36 @@ def run_workload(nhp, ctx, name, N, M, steps, warmup, sync):
                 kind=w["kind"], data=(times, nodes, T), proc=proc, recursive=w["recursive"])
 
 
+def two_streams(nhp, base_ctx, r, steps, local):
+    """Two independent evaluation streams on ONE GPU (two nhp_ctx = two HIP streams; e.g. two chains or restarts per
+    GPU): the fixed per-launch costs of one stream -- launch / completion, column staging, the reduction tail -- run
+    under the other stream's pair loops.  Same workload and kernels as the headline; reported beside it, never as
+    `value`, because a launch that shares the GPU takes longer (the per-launch roofline is the single-stream one)."""
+    from nhp_amd import _lib
+    lib = _lib.lib()
+    ctxs = [base_ctx, nhp.Context(local)]
+    dss, models, keep = [], [], []
+    for ctx in ctxs:
+        proc = nhp.synthetic.s_metric_process(r["N"], r["M"], r["data"][2], r["kind"], 1.0)
+        keep.append(proc)
+        dss.append(nhp.continuous.DeviceDataset(ctx, r["data"], r["N"], 1.0))
+        models.append(proc.device_model(ctx))
+
+    def go(n):
+        for k in range(n):
+            for c, d, m in zip(ctxs, dss, models):
+                _lib.check(lib.nhp_cont_loglik_enqueue(c.h, d.h, m.h, 0, k % _lib.MAX_SLOTS), c.h)
+        for c in ctxs:
+            c.synchronize()
+    go(5)
+    t0 = time.perf_counter()
+    go(steps)
+    dt = time.perf_counter() - t0
+    lls = [float(c.fetch(0, 1)[0]) for c in ctxs]
+    return {"streams": 2, "value": 2 * steps / dt, "unit": "log-likelihood evals/sec", "us_per_evaluation": 1e6 * dt / (2 * steps),
+            "loglik": lls}
+
+
 def cpu_baseline(r, budget_s=12.0):
     """The oracle (a C restatement of the reference's loops, 1 thread) on a bounded prefix of the
     same workload; evals/s extrapolated linearly in M (both formulations are linear in M)."""
@@ -322,6 +352,9 @@ def main():
                     help="comma list of workloads whose single evaluation is also column-sharded over the ranks (N>1 only); '' to skip")
     ap.add_argument("--chain-steps", type=int, default=int(os.environ.get("NHP_BENCH_CHAIN_STEPS", "50")),
                     help="mcmc! steps per rank of the config-5 leg (N>1 only); 0 to skip")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="also time two independent evaluation streams sharing the GPU (N=1).  Off by default: its launches "
+                         "of the headline kernel would enter the rocprofv3 per-symbol average of the default command")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -401,6 +434,11 @@ def main():
                 "mcmc_steps_per_sec": world * args.chain_steps / chain_wall, "ms_per_step": 1e3 * chain_wall / args.chain_steps}
         if sharded is not None:
             out["one_evaluation_over_all_ranks"] = sharded
+        if world == 1 and args.two_streams and not r["recursive"]:
+            try:
+                out["two_independent_streams_on_one_gpu"] = two_streams(nhp, ctx, r, args.steps, local)
+            except Exception as exc:        # secondary number
+                out["two_independent_streams_on_one_gpu"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(r)
             out["speedup_vs_cpu_core"] = out["value"] / out["cpu_baseline"]["value"]
@@ -449,6 +487,18 @@ def main():
                 tb = (time.perf_counter() - t0) / reps
                 others.append({"workload": "windowed_k8, 8 parameter sets per nhp_cont_loglik_batch call", "value": 8 / tb,
                                "us_per_evaluation": 1e6 * tb / 8, "loglik": float(outb[0])})
+                # 64 sets per call: fused launches on the context's two lanes reach their steady state
+                arr64 = (C.c_void_p * 64)(*[models[q % 8].h for q in range(64)])
+                out64 = np.empty(64)
+                _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, dsb.h, arr64, 64, 0, _lib.dptr(out64)), ctx.h)
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, dsb.h, arr64, 64, 0, _lib.dptr(out64)), ctx.h)
+                sync()
+                tb = (time.perf_counter() - t0) / reps
+                others.append({"workload": "windowed_k8, 64 parameter sets per nhp_cont_loglik_batch call", "value": 64 / tb,
+                               "us_per_evaluation": 1e6 * tb / 64, "loglik": float(out64[0])})
             except Exception as exc:        # secondary number: never take the headline down with it
                 others.append({"workload": "windowed_k8 batch", "error": repr(exc)})
             out["other_workloads"] = others

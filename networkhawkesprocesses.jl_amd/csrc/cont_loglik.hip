@@ -17,6 +17,7 @@
 //    so every parameter is read from HBM exactly once per evaluation.
 //  * Sums are reduced lane -> wave -> block -> one partial per workgroup; a one-block second
 //    kernel adds the partials in a fixed order (deterministic, no atomics).
+#include <utility>
 #include "nhp_internal.h"
 #include "nhp_math.h"
 
@@ -586,7 +587,20 @@ extern "C" nhp_status nhp_cont_loglik_batch(nhp_ctx *ctx, const nhp_cont_dataset
     // windowed evaluations at short windows are bound by gathers that do not depend on the parameters: take the models
     // four (or two) at a time through one pass over the data; everything else goes one launch per model
     static const int fuse = getenv("NHP_BATCH_FUSE") ? atoi(getenv("NHP_BATCH_FUSE")) : 4;      // largest group: 0/1 off, 2, 4
+    static const bool two_lanes = getenv("NHP_BATCH_LANES") ? atoi(getenv("NHP_BATCH_LANES")) >= 2 : true;
     const double kbar = ds && ds->M > 0 ? (double)ds->pairs / (double)ds->M : 0.0;
+    // Windowed launches alternate between the context's two lanes (stream + partial sums + tickets each): they are
+    // independent -- different result slots, read-only data and models -- so the second lane forks from the main stream
+    // (everything enqueued before this call, e.g. parameter uploads, is visible to it) and joins it before the results
+    // are fetched.  The lane is switched by swapping the context's fields around a launch, so the launch code is shared.
+    struct lane_guard {
+        nhp_ctx *c; bool on = false;
+        void flip() { std::swap(c->stream, c->stream2); std::swap(c->d_partials, c->d_partials2); std::swap(c->partials_cap, c->partials2_cap);
+                      std::swap(c->d_counter, c->d_counter2); on = !on; }
+        ~lane_guard() { if (on) flip(); }
+    } lane{ctx};
+    bool forked = false;
+    int launches = 0;
     for (int32_t done = 0; done < nb; done += NHP_MAX_SLOTS) {
         const int32_t n = nb - done < NHP_MAX_SLOTS ? nb - done : NHP_MAX_SLOTS;
         int32_t k = 0;
@@ -600,10 +614,26 @@ extern "C" nhp_status nhp_cont_loglik_batch(nhp_ctx *ctx, const nhp_cont_dataset
                     multi_compatible(ds, ms[0], ms[3], 80 * 1024, 4)) take = 4;
                 else if (k + 2 <= n && multi_compatible(ds, ms[0], ms[1], 64 * 1024, 2)) take = 2;
             }
+            const bool second = two_lanes && windowed && ctx && ctx->stream2 && (launches & 1);
+            if (second) {
+                if (!forked) {
+                    NHP_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+                    NHP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+                    forked = true;
+                }
+                lane.flip();
+            }
             if (take == 4) { for (int q = 1; q < 4; ++q) NHP_TRY(nhp_check_pair(ctx, ds, ms[q])); NHP_TRY(enqueue_multi<4>(ctx, ds, ms, k)); }
             else if (take == 2) { NHP_TRY(nhp_check_pair(ctx, ds, ms[1])); NHP_TRY(enqueue_multi<2>(ctx, ds, ms, k)); }
             else NHP_TRY(enqueue(ctx, ds, ms[0], flags, k));
+            if (second) lane.flip();
+            if (windowed) ++launches;
             k += take;
+        }
+        if (forked) {                                       // the main stream continues after the second lane's launches
+            NHP_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+            NHP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+            forked = false;
         }
         NHP_TRY(nhp_ctx_fetch(ctx, 0, n, ll + done));
     }

@@ -52,6 +52,11 @@ extern "C" nhp_status nhp_ctx_create(int32_t device, nhp_ctx **out)
     NHP_HIP(ctx, hipHostMalloc(&ctx->h_results, sizeof(double) * NHP_MAX_SLOTS));
     NHP_HIP(ctx, hipMalloc(&ctx->d_counter, 128 * 80));
     NHP_HIP(ctx, hipMemsetAsync(ctx->d_counter, 0, 128 * 80, ctx->stream));
+    NHP_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    NHP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    NHP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    NHP_HIP(ctx, hipMalloc(&ctx->d_counter2, 128 * 80));
+    NHP_HIP(ctx, hipMemsetAsync(ctx->d_counter2, 0, 128 * 80, ctx->stream));
     NHP_HIP(ctx, hipMemsetAsync(ctx->d_results, 0, sizeof(double) * NHP_MAX_SLOTS, ctx->stream));
     NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = ctx;
@@ -63,6 +68,12 @@ extern "C" void nhp_ctx_destroy(nhp_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->d_partials2) (void)hipFree(ctx->d_partials2);
+    if (ctx->d_counter2) (void)hipFree(ctx->d_counter2);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->d_results) (void)hipFree(ctx->d_results);
     if (ctx->h_results) (void)hipHostFree(ctx->h_results);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);

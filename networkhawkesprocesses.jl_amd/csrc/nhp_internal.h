@@ -29,6 +29,14 @@ struct nhp_ctx {
     void *d_scratch = nullptr;          // general scratch (gradients, sampler output)
     size_t scratch_cap = 0;             // bytes
     unsigned int *d_counter = nullptr;  // arrival ticket of the fused last-block reduction (kept at 0 between launches)
+    // Second lane for independent evaluations inside one call (nhp_cont_loglik_batch): its own stream, partial sums and
+    // tickets.  A launch has fixed costs -- dispatch / completion, column staging, the reduction tail -- during which
+    // the chip idles; with two lanes they run under the other lane's pair loops (profiles/README.md: two streams).
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    double *d_partials2 = nullptr;
+    size_t partials2_cap = 0;
+    unsigned int *d_counter2 = nullptr;
     int cu_count = 256;
     std::string err;
 };

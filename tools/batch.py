@@ -15,12 +15,13 @@ for s in range(8):
     procs.append(p)
 ds = nhp.device_dataset(procs[0], (times, nodes, T), ctx)
 models = [p.device_model(ctx) for p in procs]
-arr = (C.c_void_p * 8)(*[m.h for m in models])
-out = np.empty(8)
+NB = int(os.environ.get('NB', 8))
+arr = (C.c_void_p * NB)(*[models[i % 8].h for i in range(NB)])
+out = np.empty(NB)
 for rep in range(3):
     ctx.synchronize()
     t0 = time.perf_counter()
     for _ in range(20):
-        _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, ds.h, arr, 8, 0, _lib.dptr(out)), ctx.h)
+        _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, ds.h, arr, NB, 0, _lib.dptr(out)), ctx.h)
     dt = (time.perf_counter() - t0) / 20
-    print(f"batch of 8: {1e6*dt:8.1f} us  = {1e6*dt/8:6.1f} us per evaluation   ll[0]={out[0]:.6f} ll[7]={out[7]:.6f}", flush=True)
+    print(f"batch of {NB}: {1e6*dt:8.1f} us  = {1e6*dt/NB:6.1f} us per evaluation   ll[0]={out[0]:.6f} ll[7]={out[7]:.6f}", flush=True)
