@@ -72,6 +72,16 @@ __device__ __forceinline__ double baseline_integral_part(const nhp_cont_args &a)
     return sb;
 }
 
+// One column's share of the same, spread over the threads of the workgroup (their block sum adds it up).
+__device__ __forceinline__ double baseline_integral_col(const nhp_cont_args &a, int c)
+{
+    if (a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) return threadIdx.x == 0 ? a.lambda0[c] * a.duration : 0.0;
+    const double *y = a.lambda0 + (size_t)c * a.grid_n;
+    double I = 0.0;
+    for (int i = threadIdx.x; i + 1 < a.grid_n; i += blockDim.x) I += 0.5 * (y[i] + y[i + 1]) * (a.grid[i + 1] - a.grid[i]);
+    return I;
+}
+
 // U children per group are in flight at once: their child records, then their parents'
 // packed (t, node) records, are fetched by independent loads before any is consumed, so the
 // dependent global-load chains of different children overlap.  Inactive slots are predicated
@@ -111,6 +121,9 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
         }
         if (it.first) integ += a.cnt[p] * wint;
     }
+    // the node's first item also carries the column's baseline integral (fused second stage only: the two-kernel path
+    // leaves it to k_finalize), so the last workgroup's tail has nothing to load but the partial sums
+    if (out && it.first && !NHP_SKIP(a, 2)) integ += baseline_integral_col(a, c);
     __syncthreads();
 
     // ---- children: G lanes per child, U children per group in flight
@@ -205,8 +218,9 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
     // ---- deferred logs: every lane busy, one child each
     double acc = 0.0;
     for (int k = tid; k < (NHP_SKIP(a, 4) ? 0 : nchild); k += NHP_WBLOCK) acc += nhp_log(lam_buf[k]);
-    const double blk = nhp_block_sum_n<NHP_WBLOCK / 64>(acc, red);
-    const double blk_int = nhp_block_sum_n<NHP_WBLOCK / 64>(integ, red);
+    static_assert(2 * (NHP_WBLOCK / 64) <= 16, "red[] holds 16 doubles ahead of the flag");
+    double blk = acc, blk_int = integ;
+    nhp_block_sum2_n<NHP_WBLOCK / 64>(blk, blk_int, red);
     if (!out) {
         if (tid == 0) {
             partials[2 * (size_t)blockIdx.x] = blk;
@@ -241,12 +255,9 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
         sl += __hip_atomic_load(&partials[2 * (size_t)i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         si += __hip_atomic_load(&partials[2 * (size_t)i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    double sb = baseline_integral_part(a);
-    sl = nhp_block_sum_n<NHP_WBLOCK / 64>(sl, red);
-    si = nhp_block_sum_n<NHP_WBLOCK / 64>(si, red);
-    sb = nhp_block_sum_n<NHP_WBLOCK / 64>(sb, red);
+    nhp_block_sum2_n<NHP_WBLOCK / 64>(sl, si, red);
     if (tid == 0) {
-        *out = (0.0 - sb) - si + sl;
+        *out = (0.0 - si) + sl;                  // si: baseline integrals + Σ cnt·w, column by column
     }
     if (tid <= NHP_SHARDS) __hip_atomic_store(&counter[32 * tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -280,6 +280,21 @@ __device__ __forceinline__ double nhp_block_sum_n(double v, double *red)
 
 __device__ __forceinline__ double nhp_block_sum(double v, double *red) { return nhp_block_sum_n<NHP_WAVES>(v, red); }
 
+// Two sums with one pair of barriers; results valid in thread 0.  `red` holds >= 2·NW doubles.
+template <int NW>
+__device__ __forceinline__ void nhp_block_sum2_n(double &x, double &y, double *red)
+{
+    x = nhp_wave_sum(x);
+    y = nhp_wave_sum(y);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = x; red[NW + (threadIdx.x >> 6)] = y; }
+    __syncthreads();
+    double sx = 0.0, sy = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < NW; ++w) { sx += red[w]; sy += red[NW + w]; }
+    x = sx; y = sy;
+}
+
 // Phase ablation for timing experiments (tools/ablate.sh): compiled in only with -DNHP_ABLATE,
 // where env NHP_DBG selects phases to skip (results are then wrong by design).
 #ifdef NHP_ABLATE
