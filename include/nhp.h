@@ -146,7 +146,10 @@ nhp_status nhp_cont_loglik_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds,
                                    const nhp_cont_model *model, int32_t flags, int32_t slot);
 nhp_status nhp_ctx_fetch(nhp_ctx *ctx, int32_t first_slot, int32_t n, double *out);
 /* nb log-likelihoods of nb device-resident models on one dataset (the 2P objective calls of a
- * finite-difference gradient, a population of chains): launched back to back, one synchronisation */
+ * finite-difference gradient, a population of chains), one synchronisation.  The evaluations are independent, so at
+ * short windows compatible models share one pass over the data (up to four per launch) and the launches alternate
+ * between the context's two internal streams; every result is the same as from nhp_cont_loglik on that model.
+ * NHP_BATCH_FUSE=1 / NHP_BATCH_LANES=1 in the environment turn either off. */
 nhp_status nhp_cont_loglik_batch(nhp_ctx *ctx, const nhp_cont_dataset *ds,
                                  const nhp_cont_model *const *models, int32_t nb, int32_t flags, double *ll);
 

@@ -227,3 +227,31 @@ def test_fused_batches_of_models(nhp, orc, kind, network, lgcp):
     for c, got in zip(cases, out):
         assert rel(got, orc.loglik_windowed(c["om"], data[0], data[1], data[2])) < TOL
 
+
+
+def test_batch_lanes_follow_parameter_updates(nhp, orc):
+    # the batch alternates its launches between the context's two internal streams: many launches per call, calls
+    # back to back, and a parameter upload between two calls (it must be seen by both streams)
+    import ctypes as C
+    from nhp_amd import _lib
+    ctx = nhp.default_context()
+    cases = [random_case(7, 3000, 150.0, "exponential", 1.0, seed=s, nhp=nhp, orc=orc) for s in range(80, 103)]
+    data = cases[0]["data"]
+    ds = nhp.device_dataset(cases[0]["proc"], data, ctx)
+    models = [c["proc"].device_model(ctx) for c in cases]
+    n = len(cases)
+    arr = (C.c_void_p * n)(*[m.h for m in models])
+    out = np.empty(n)
+    want = np.array([orc.loglik_windowed(c["om"], data[0], data[1], data[2]) for c in cases])
+    for _ in range(3):
+        out[:] = 0.0
+        _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, ds.h, arr, n, 0, _lib.dptr(out)), ctx.h)
+        assert np.max(np.abs(out - want) / np.abs(want)) < TOL
+    # models 1, 2, ... take model 0's parameters: every entry must now be model 0's value
+    x0 = cases[0]["proc"].params()
+    for m in models[1:]:
+        m.set_params(x0)
+    _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, ds.h, arr, n, 0, _lib.dptr(out)), ctx.h)
+    assert np.max(np.abs(out - want[0]) / abs(want[0])) < TOL
+    # and a plain evaluation right after a batch uses the main stream again
+    assert rel(nhp.loglikelihood(cases[3]["proc"], data, recursive=False), want[3]) < TOL
