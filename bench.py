@@ -239,9 +239,11 @@ def config_workloads(nhp, ctx, which):
             inference.resample_adjacency_matrix_(proc, ds, seed=1, step=step[0], model=model, fetch=False, ctx=ctx)
             step[0] += 1
         t_a = timed(adjacency, 5)
+        t_m = timed(lambda: _lib.check(_lib.lib().nhp_cont_model_moments_accumulate(ctx.h, model.h), ctx.h), 20)
         out.append({"workload": "c3 N=1024 M=1e6 logit-normal network, mcmc! step",
                     "device_gibbs_sweep_ms": 1e3 * t_d, "adjacency_sweep_ms": 1e3 * t_a,
-                    "mcmc_steps_per_sec": 1.0 / (t_d + t_a),
+                    "mcmc_steps_per_sec": 1.0 / (t_d + t_a), "sample_moments_on_device_ms": 1e3 * t_m,
+                    "params_per_sample": 4 * N * N + N + 1,
                     "parent_sampler_plus_stats_to_host_ms": 1e3 * t_s, "host_draw_gibbs_step_ms": 1e3 * t_g,
                     "pairs": int(ds.pairs)})
     if "c4" in which:      # discrete Gaussian-basis standard Hawkes, N=512, K=8, T=1e5
@@ -324,6 +326,7 @@ def chains_leg(nhp, ctx, rank, steps, sync):
     def step(k):
         _lib.check(_lib.lib().nhp_cont_gibbs_step(ctx.h, ds.h, model.h, C.byref(pri), seed, k), ctx.h)
         inference.resample_adjacency_matrix_(proc, ds, seed=seed, step=k, model=model, fetch=False, ctx=ctx)
+        _lib.check(_lib.lib().nhp_cont_model_moments_accumulate(ctx.h, model.h), ctx.h)     # the chain's sample store
     for k in range(3):
         step(k)
     ctx.synchronize()

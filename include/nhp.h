@@ -209,6 +209,15 @@ nhp_status nhp_cont_lgcp_loglik(nhp_ctx *ctx, const nhp_cont_dataset *ds, const 
                                 const double *grid_x, int32_t grid_n, const double *lam, double *ll);
 /* params(process) of the device-resident model: [λ0; θ | μ; τ; W]  src/continuous.jl:116-119 */
 nhp_status nhp_cont_model_get_params(nhp_ctx *ctx, const nhp_cont_model *model, double *x, int64_t len);
+/* Sample store on the device.  mcmc! appends params(process) after every sweep (src/inference.jl:61):
+ * 4N²+N doubles per step, 33.5 MB at N = 1024 -- more PCIe time than the sweep itself.  These keep Σx and Σx² of the
+ * device-resident parameters instead: _reset zeroes them, _accumulate adds the current [λ0; θ | μ; τ; W; vec(A) if the
+ * model has an adjacency matrix] (call it once per sweep), _fetch returns the two sums and the number of samples;
+ * len = N + N²·(1 | 2) + N² [+ N²].  Posterior mean = sum / count, second moment = sumsq / count. */
+nhp_status nhp_cont_model_moments_reset(nhp_ctx *ctx, nhp_cont_model *model);
+nhp_status nhp_cont_model_moments_accumulate(nhp_ctx *ctx, nhp_cont_model *model);
+nhp_status nhp_cont_model_moments_fetch(nhp_ctx *ctx, const nhp_cont_model *model, double *sum, double *sumsq,
+                                        int64_t len, int64_t *count);
 /* the uniform stream itself (host side, same bits as the kernel draws) */
 void nhp_uniform_stream(uint64_t seed, uint64_t step, int64_t n, double *u);
 

@@ -72,6 +72,9 @@ def _declare(lib):
     f("nhp_cont_model_update", i32, _vp, _vp, C.POINTER(ModelDesc))
     f("nhp_cont_model_set_params", i32, _vp, _vp, _dp, i64)
     f("nhp_cont_model_destroy", None, _vp)
+    f("nhp_cont_model_moments_reset", i32, _vp, _vp)
+    f("nhp_cont_model_moments_accumulate", i32, _vp, _vp)
+    f("nhp_cont_model_moments_fetch", i32, _vp, _vp, _dp, _dp, i64, C.POINTER(i64))
     f("nhp_cont_loglik", i32, _vp, _vp, _vp, i32, _dp)
     f("nhp_cont_loglik_enqueue", i32, _vp, _vp, _vp, i32, i32)
     f("nhp_ctx_fetch", i32, _vp, i32, i32, _dp)

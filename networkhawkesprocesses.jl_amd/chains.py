@@ -83,6 +83,16 @@ def run_chains(make_process, data, n_chains, nsteps, base_seed=0, burn=0, ctx=No
         process = make_process(k)
         if ds is None:
             ds = device_dataset(process, data, ctx)         # uploaded once per GPU, shared by its chains
-        res = mcmc_(process, ds, nsteps=nsteps, seed=chain_seed(base_seed, k), ctx=ctx, **mcmc_kwargs)
-        local[k] = summarize_chain(res.samples, burn)
+        # posterior summaries accumulate on the device when the whole sweep runs there (homogeneous baseline): no
+        # per-step transfer of params(process) (33.5 MB at N = 1024); otherwise from the kept samples
+        from .components import HomogeneousProcess
+        on_device = isinstance(process.baseline, HomogeneousProcess) and mcmc_kwargs.get("device_draws", True)
+        if on_device:
+            kw = {a: v for a, v in mcmc_kwargs.items() if a not in ("keep_samples", "moments", "burn")}
+            res = mcmc_(process, ds, nsteps=nsteps, seed=chain_seed(base_seed, k), ctx=ctx, keep_samples=False,
+                        moments=True, burn=burn, **kw)
+            local[k] = {"n": np.array([float(res.n)]), "mean": res.mean, "m2": res.m2}
+        else:
+            res = mcmc_(process, ds, nsteps=nsteps, seed=chain_seed(base_seed, k), ctx=ctx, **mcmc_kwargs)
+            local[k] = summarize_chain(res.samples, burn)
     return gather_summaries(local, n_chains)

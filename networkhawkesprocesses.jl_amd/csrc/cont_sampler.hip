@@ -19,6 +19,7 @@
 // child-parent delay.  A second kernel gives workgroup c the children of node c and lets
 // lane p scan them for parent node p: no atomics, every (p,c) cell accumulates in child time
 // order -- the order the reference's serial loops use -- so ΣΔt is reproducible bit for bit.
+#include <algorithm>
 #include <type_traits>
 #include "nhp_internal.h"
 #include "nhp_math.h"
@@ -559,6 +560,78 @@ extern "C" nhp_status nhp_cont_gibbs_step(nhp_ctx *ctx, const nhp_cont_dataset *
     hipLaunchKernelGGL(k_gibbs_draw, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, ctx->stream, ds->N, m->impulse_kind,
                        ds->duration, g, seed, step, o.cnt0, o.Mn, o.Mnm, o.X, o.V, m->d_lambda0, m->d_p1, m->d_p2, m->d_W);
     NHP_HIP(ctx, hipGetLastError());
+    return NHP_OK;
+}
+
+// ---- sample store: running first and second moments of the chain on the device.  mcmc! keeps
+// params(process) of every step (src/inference.jl:61) -- 4N²+N doubles, 33.5 MB per step at N = 1024, i.e. more PCIe
+// time than the whole sweep takes -- while what a chain is read for are posterior means and variances (chains.py
+// gathers exactly these).  Order: params(process) of the standard process, then vec(A) when the model has one.
+__global__ __launch_bounds__(256) void k_moments(int64_t N, int64_t nimp, const double *__restrict__ lambda0,
+                                                 const double *__restrict__ p1, const double *__restrict__ p2,
+                                                 const double *__restrict__ W, const double *__restrict__ A,
+                                                 int64_t len, double *__restrict__ mom)
+{
+    const int64_t NN = N * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) {
+        double x;
+        if (i < N) x = lambda0[i];
+        else if (i < N + NN) x = p1[i - N];
+        else if (i < N + nimp) x = p2[i - N - NN];
+        else if (i < N + nimp + NN) x = W[i - N - nimp];
+        else x = A[i - N - nimp - NN];
+        mom[i] += x;
+        mom[len + i] += x * x;
+    }
+}
+
+extern "C" nhp_status nhp_cont_model_moments_reset(nhp_ctx *ctx, nhp_cont_model *m)
+{
+    if (!ctx || !m) return NHP_EINVAL;
+    if (m->ctx != ctx) { nhp_set_error(ctx, "model belongs to another ctx"); return NHP_EINVAL; }
+    if (m->baseline_kind != NHP_BASELINE_HOMOGENEOUS) { nhp_set_error(ctx, "moments: homogeneous baseline only"); return NHP_ENOTIMPL; }
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t N = m->N, NN = N * N;
+    const int64_t len = N + (m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? NN : 2 * NN) + NN + (m->has_A ? NN : 0);
+    if (!m->d_mom || m->mom_len != len) {
+        if (m->d_mom) { NHP_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(m->d_mom); m->d_mom = nullptr; }
+        if (hipMalloc((void **)&m->d_mom, sizeof(double) * 2 * (size_t)len) != hipSuccess) {
+            nhp_set_error(ctx, "out of device memory (sample moments)");
+            return NHP_ENOMEM;
+        }
+        m->mom_len = len;
+    }
+    NHP_HIP(ctx, hipMemsetAsync(m->d_mom, 0, sizeof(double) * 2 * (size_t)len, ctx->stream));
+    m->mom_count = 0;
+    return NHP_OK;
+}
+
+extern "C" nhp_status nhp_cont_model_moments_accumulate(nhp_ctx *ctx, nhp_cont_model *m)
+{
+    if (!ctx || !m) return NHP_EINVAL;
+    if (m->ctx != ctx) { nhp_set_error(ctx, "model belongs to another ctx"); return NHP_EINVAL; }
+    if (!m->d_mom) NHP_TRY(nhp_cont_model_moments_reset(ctx, m));
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t N = m->N, NN = N * N, nimp = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? NN : 2 * NN;
+    const unsigned blocks = (unsigned)std::min<int64_t>((m->mom_len + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_moments, dim3(blocks), dim3(256), 0, ctx->stream, N, nimp, m->d_lambda0, m->d_p1, m->d_p2, m->d_W,
+                       m->has_A ? m->d_A : nullptr, m->mom_len, m->d_mom);
+    NHP_HIP(ctx, hipGetLastError());
+    ++m->mom_count;
+    return NHP_OK;
+}
+
+extern "C" nhp_status nhp_cont_model_moments_fetch(nhp_ctx *ctx, const nhp_cont_model *m, double *sum, double *sumsq,
+                                                   int64_t len, int64_t *count)
+{
+    if (!ctx || !m || !sum || !sumsq || !count) return NHP_EINVAL;
+    if (!m->d_mom) { nhp_set_error(ctx, "moments: nothing accumulated"); return NHP_EINVAL; }
+    if (len != m->mom_len) { nhp_set_error(ctx, "Parameter vector length does not match model parameter length."); return NHP_ESHAPE; }
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    NHP_HIP(ctx, hipMemcpyAsync(sum, m->d_mom, sizeof(double) * (size_t)len, hipMemcpyDeviceToHost, ctx->stream));
+    NHP_HIP(ctx, hipMemcpyAsync(sumsq, m->d_mom + len, sizeof(double) * (size_t)len, hipMemcpyDeviceToHost, ctx->stream));
+    NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *count = m->mom_count;
     return NHP_OK;
 }
 

@@ -119,6 +119,10 @@ struct nhp_cont_model {
     mutable uint64_t rec_version = 0;
     mutable int64_t rec_M = -1;         // the event count the cached bound was derived for
     mutable double rec_cut = 0.0;       // look-back beyond which the full-history sum is below 2^-60 of every λ_i (0: no bound)
+    // running sums of the chain's samples (nhp_cont_model_moments_*): Σx and Σx² over [λ0; θ | μ; τ; W; vec(A)], so a
+    // chain's posterior summaries never cross PCIe step by step
+    double *d_mom = nullptr;            // [2][mom_len]
+    int64_t mom_len = 0, mom_count = 0;
 };
 
 // Kernel-side view of model + data (passed by value).

@@ -210,18 +210,46 @@ def _pull_params(process, model, ctx):
     process.weights.params_(x[N + nimp:])
 
 
+def _fetch_moments(process, model, ctx, network, rho_sum, rho_sq):
+    """Mean and mean square of params(process) from the device-side running sums, in params(process) order."""
+    import ctypes as C
+    N = process.ndims()
+    nimp = N * N * (1 if isinstance(process.impulses, ExponentialImpulseResponse) else 2)
+    L = N + nimp + N * N + (N * N if network else 0)
+    s, q = np.empty(L), np.empty(L)
+    cnt = C.c_int64()
+    _lib.check(_lib.lib().nhp_cont_model_moments_fetch(ctx.h, model.h, _lib.dptr(s), _lib.dptr(q), L, C.byref(cnt)), ctx.h)
+    n = max(1, cnt.value)
+    mean, m2 = s / n, q / n
+    if network:        # device order [λ0; impulses; W; vec(A)] -> params(process) = [ρ; λ0; W; impulses; vec(A)] (src/continuous.jl:325-333)
+        k = len(process.network.params())
+        a, b, c = N, N + nimp, N + nimp + N * N
+
+        def order(v, rho):
+            return np.concatenate([np.full(k, rho), v[:a], v[b:c], v[a:b], v[c:]])
+        mean, m2 = order(mean, rho_sum / n), order(m2, rho_sq / n)
+    return mean, m2, cnt.value
+
+
 def mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, keep_samples=True, device_draws=True,
-          ctx=None):
+          ctx=None, moments=False, burn=0):
     """mcmc!(process, data; nsteps, log_freq, verbose) -- src/inference.jl:49-70.
 
     With `device_draws` (default) a whole sweep -- parents, statistics, conjugate draws -- stays on
     the GPU (nhp_cont_gibbs_step): parameters never cross PCIe unless samples are kept.  With
     device_draws=False the statistics come back and numpy draws the parameters (same
     distributions).  `seed` keys every random stream, so a chain is reproducible and chains with
-    different seeds are independent (one per GPU: chains.py)."""
+    different seeds are independent (one per GPU: chains.py).
+
+    `moments=True` (device draws only) keeps the chain's running sums on the device (nhp_cont_model_moments_*): after the
+    run `res.mean` and `res.m2` hold the mean and the mean square of params(process) over the steps >= `burn` -- the
+    summaries chains.py gathers -- with no per-step transfer; combine with keep_samples=False for long chains at large N
+    (a sample is 4N²+N doubles, 33.5 MB at N = 1024)."""
     import ctypes as C
     if not isinstance(process.baseline, HomogeneousProcess):
         device_draws = False      # nhp_cont_gibbs_step draws the homogeneous λ0; the LGCP curve is a host slice loop
+    if moments and not device_draws:
+        raise ValueError("moments=True needs the device-side draws (homogeneous baseline, device_draws=True)")
     ctx = ctx or _lib.default_context()
     ds = device_dataset(process, data, ctx)
     rng = np.random.default_rng(seed)
@@ -229,6 +257,10 @@ def mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, keep_
     start = time.time()
     model = process.device_model(ctx) if device_draws else None
     pri = _priors(process) if device_draws else None
+    network = isinstance(process, ContinuousNetworkHawkesProcess)
+    rho_sum = rho_sq = 0.0
+    if moments:
+        _lib.check(_lib.lib().nhp_cont_model_moments_reset(ctx.h, model.h), ctx.h)
     while res.steps < nsteps:
         if device_draws:
             _lib.check(_lib.lib().nhp_cont_gibbs_step(ctx.h, ds.h, model.h, C.byref(pri), seed, res.steps), ctx.h)
@@ -236,6 +268,11 @@ def mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, keep_
                 last = keep_samples or res.steps == nsteps - 1
                 links = resample_adjacency_matrix_(process, ds, seed=seed, step=res.steps, model=model, fetch=last, ctx=ctx)
                 process.network.resample_links_(links, process.ndims() ** 2, rng)
+            if moments and res.steps >= burn:
+                _lib.check(_lib.lib().nhp_cont_model_moments_accumulate(ctx.h, model.h), ctx.h)
+                if network:
+                    rho = float(np.mean(process.network.params()))
+                    rho_sum, rho_sq = rho_sum + rho, rho_sq + rho * rho
             if keep_samples or res.steps == nsteps - 1:
                 _pull_params(process, model, ctx)
             x = process.params() if keep_samples else None
@@ -251,4 +288,6 @@ def mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, keep_
     res.status = "complete"
     if not keep_samples:
         res.samples.append(process.params())
+    if moments:
+        res.mean, res.m2, res.n = _fetch_moments(process, model, ctx, network, rho_sum, rho_sq)
     return res

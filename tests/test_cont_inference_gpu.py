@@ -238,3 +238,41 @@ def test_gibbs_entry_points_on_empty_data(nhp):
     assert np.array_equal(proc.adjacency_matrix, (u <= 0.4).astype(float))
     res = nhp.mcmc_(proc, data, nsteps=3, seed=0)
     assert res.steps == 3 and all(np.all(np.isfinite(s)) for s in res.samples)
+
+
+@pytest.mark.parametrize("kind,network", [("exponential", False), ("logitnormal", True)])
+def test_device_moments_equal_the_moments_of_the_kept_samples(nhp, kind, network):
+    """The on-device sample store (nhp_cont_model_moments_*): mean and mean square of params(process) over the steps
+    after burn-in, with no per-step transfer, equal numpy's over the samples mcmc! keeps (same chain, same order)."""
+    c = random_case(5, 2500, 250.0, kind, 1.0, network=network, seed=31, nhp=nhp)
+    res = nhp.mcmc_(c["proc"], c["data"], nsteps=40, seed=3, keep_samples=True, moments=True, burn=10)
+    S = np.array(res.samples[10:])
+    assert res.n == 30 and res.mean.shape == S[0].shape
+    assert np.allclose(res.mean, S.mean(axis=0), rtol=1e-12, atol=1e-14)
+    assert np.allclose(res.m2, (S ** 2).mean(axis=0), rtol=1e-12, atol=1e-14)
+    # without kept samples the chain and its moments are the same
+    c2 = random_case(5, 2500, 250.0, kind, 1.0, network=network, seed=31, nhp=nhp)
+    r2 = nhp.mcmc_(c2["proc"], c2["data"], nsteps=40, seed=3, keep_samples=False, moments=True, burn=10)
+    assert np.array_equal(r2.mean, res.mean) and np.array_equal(r2.m2, res.m2)
+    assert np.array_equal(r2.samples[-1], res.samples[-1])
+    with pytest.raises(ValueError):
+        nhp.mcmc_(c2["proc"], c2["data"], nsteps=2, device_draws=False, moments=True)
+
+
+def test_run_chains_summaries(nhp):
+    """chains.run_chains (one process: every chain on this GPU): each chain's summary equals the mean / mean square of
+    the samples the same chain gives when it is run by hand and its samples are kept."""
+    from nhp_amd import chains
+
+    def make(k):
+        return random_case(4, 2000, 200.0, "logitnormal", 1.0, network=True, seed=41, nhp=nhp)["proc"]
+    data = random_case(4, 2000, 200.0, "logitnormal", 1.0, network=True, seed=41, nhp=nhp)["data"]
+    out = chains.run_chains(make, data, n_chains=3, nsteps=30, base_seed=5, burn=10)
+    assert sorted(out) == [0, 1, 2]
+    for k in range(3):
+        res = nhp.mcmc_(make(k), data, nsteps=30, seed=chains.chain_seed(5, k))
+        S = np.array(res.samples[10:])
+        assert out[k]["n"][0] == 20
+        assert np.allclose(out[k]["mean"], S.mean(axis=0), rtol=1e-12, atol=1e-14)
+        assert np.allclose(out[k]["m2"], (S ** 2).mean(axis=0), rtol=1e-12, atol=1e-14)
+    assert not np.array_equal(out[0]["mean"], out[1]["mean"])
