@@ -6,7 +6,7 @@ The directory name carries a dot, so it is loaded under the module name `nhp_amd
 Julia's `f!` becomes `f_`.
 """
 from ._lib import Context, DomainError, NhpError, default_context  # noqa: F401
-from .components import (BernoulliNetworkModel, DenseNetworkModel, DenseWeightModel,  # noqa: F401
+from .components import (BernoulliNetworkModel, DenseNetworkModel, DenseWeightModel, SparseWeightModel,  # noqa: F401
                          ExponentialImpulseResponse, GaussianProcess, HomogeneousProcess,
                          LogGaussianCoxProcess, LogitNormalImpulseResponse, OrnsteinUhlenbeckKernel,
                          PeriodicKernel, SquaredExponentialKernel, split_extract)

@@ -348,6 +348,24 @@ class DenseWeightModel(Weights):
         return np.concatenate([self.κv.ravel(order="F"), self.νv.ravel(order="F")])
 
 
+class SparseWeightModel(DenseWeightModel):
+    """SparseWeightModel(W) -- src/weights.jl:104-127: the weights of a network process, with separate Gamma priors
+    for absent (κ0, ν0) and present (κ1, ν1) links.  Its Gibbs update (src/weights.jl:133-139) is the dense one under
+    the present-link prior -- W ~ Gamma(κ1 + Mnm, 1/(ν1 + Mn[p])) -- so every kernel sees it as a DenseWeightModel with
+    (κ, ν) = (κ1, ν1).  The variational methods of the reference are broken (undefined `p`, `ν1`, `ρ`, field-name
+    mismatches: src/weights.jl:141-173) and raise here."""
+
+    def __init__(self, W, κ0=1.0, ν0=1.0, κ1=1.0, ν1=1.0):
+        super().__init__(W, κ1, ν1)
+        self.κ0, self.ν0, self.κ1, self.ν1 = float(κ0), float(ν0), float(κ1), float(ν1)
+        self.κv0, self.νv0 = np.ones_like(self.W), np.ones_like(self.W)
+        self.κv1, self.νv1 = np.ones_like(self.W), np.ones_like(self.W)
+
+    def variational_params(self):
+        """src/weights.jl:131"""
+        return np.concatenate([v.ravel(order="F") for v in (self.κv0, self.νv0, self.κv1, self.νv1)])
+
+
 # ------------------------------------------------------------------------------ networks
 class Network:
     pass

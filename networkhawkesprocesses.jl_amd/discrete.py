@@ -558,7 +558,9 @@ def update_(process, data, convolved, ctx=None, n_steps=1):
     """update!(process, data, convolved) -- src/discrete.jl:369-375: one mean-field step (or n_steps
     of them with the parameters resident on the device in between); the variational parameters of
     baseline, weights and impulses are overwritten in place."""
-    if not isinstance(process, DiscreteStandardHawkesProcess) or not isinstance(process.weights, DenseWeightModel):
+    from .components import SparseWeightModel
+    if (not isinstance(process, DiscreteStandardHawkesProcess) or not isinstance(process.weights, DenseWeightModel)
+            or isinstance(process.weights, SparseWeightModel)):
         raise NotImplementedError("VB exists only for DiscreteStandardHawkesProcess + DenseWeightModel "
                                   "(the reference's network / sparse variants are broken: SURVEY D6)")
     if not isinstance(process.baseline, DiscreteHomogeneousProcess):

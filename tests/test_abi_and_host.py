@@ -191,3 +191,21 @@ def test_fast_simulator_matches_the_generation_wise_one(nhp):
         nhp.synthetic.simulated_data(nhp.ContinuousStandardHawkesProcess(
             nhp.HomogeneousProcess(lam0), nhp.ExponentialImpulseResponse(th, 1.0, 1.0, np.inf), nhp.DenseWeightModel(W * 8)),
             200.0, seed=0, max_events=100_000)
+
+
+def test_sparse_weight_model_mirror(nhp):
+    """SparseWeightModel (src/weights.jl:104-139): constructor defaults, params, and a Gibbs update that is the dense
+    one under the present-link prior (κ1, ν1); its variational methods are broken in the reference (D6) and refused."""
+    W = np.arange(9.0).reshape(3, 3) / 10
+    m = nhp.SparseWeightModel(W, κ1=2.0, ν1=3.0)
+    assert (m.κ0, m.ν0, m.κ1, m.ν1) == (1.0, 1.0, 2.0, 3.0) and (m.κ, m.ν) == (2.0, 3.0)
+    assert np.array_equal(m.params(), W.ravel(order="F")) and len(m.variational_params()) == 36
+    Mn, Mnm = np.array([5.0, 0.0, 2.0]), np.array([[1.0, 0, 2], [0, 0, 0], [3, 1, 0]])
+    a = nhp.SparseWeightModel(W, κ1=2.0, ν1=3.0).resample_(Mn, Mnm, np.random.default_rng(1))
+    b = nhp.DenseWeightModel(W, 2.0, 3.0).resample_(Mn, Mnm, np.random.default_rng(1))
+    assert np.array_equal(a, b)
+    proc = nhp.DiscreteStandardHawkesProcess(nhp.DiscreteHomogeneousProcess(np.ones(3), 1.0),
+                                             nhp.DiscreteGaussianImpulseResponse(np.full((3, 3, 2), 0.5), 4, 1.0),
+                                             nhp.SparseWeightModel(W), 1.0)
+    with pytest.raises(NotImplementedError):
+        nhp.update_(proc, np.zeros((3, 10), dtype=np.int64), None)
