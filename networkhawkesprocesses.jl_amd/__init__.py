@@ -25,6 +25,7 @@ from .inference import (MarkovChainMonteCarlo, MaximumLikelihood, logprior,  # n
                         resample_adjacency_matrix_)
 from . import inference as _inf
 from . import synthetic  # noqa: F401
+from .synthetic import rand  # noqa: F401   rand(process, duration): the reference's exported simulator name
 from . import sharded  # noqa: F401
 from .sharded import ShardedDataset, sharded_loglikelihood, sharded_loglikelihood_gradient  # noqa: F401
 
