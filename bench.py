@@ -313,7 +313,8 @@ def sharded_leg(nhp, ctx, N, M, world, names):
 def chains_leg(nhp, ctx, rank, steps, sync):
     """N>1 only (BASELINE config 5): every rank runs its own mcmc! chain of the config-3 model -- parents, statistics,
     conjugate draws and the adjacency sweep on the device, chain seed = rank -- with no exchange between chains
-    (src/inference.jl:49-70 has no cross-chain term).  Returns this rank's wall time for `steps` steps."""
+    (src/inference.jl:49-70 has no cross-chain term).  Returns this rank's wall time for `steps` steps of its own chain
+    and for `steps` steps of ONE chain swept by all ranks together."""
     import ctypes as C
     from nhp_amd import _lib, inference, chains
     N, M = 1024, 1_000_000
@@ -336,7 +337,30 @@ def chains_leg(nhp, ctx, rank, steps, sync):
         step(k)
     ctx.synchronize()
     sync()
-    return time.perf_counter() - t0
+    wall = time.perf_counter() - t0
+    # the same chain swept by ALL ranks, each its columns (sharded.py / mcmc_ on a ShardedDataset): per step one scalar
+    # all-reduce (the link count for the network's ρ update)
+    from nhp_amd.sharded import ShardedDataset, _all_reduce_sum
+    import numpy as np
+    sproc = nhp.synthetic.s_metric_process(N, M, T, "logitnormal", 1.0, network=True)
+    sd = ShardedDataset(sproc, (times, nodes, T), ctx)
+    smodel = sproc.device_model(ctx)
+
+    def sstep(k):
+        _lib.check(_lib.lib().nhp_cont_gibbs_step(ctx.h, sd.local.h, smodel.h, C.byref(pri), 1, k), ctx.h)
+        links = inference.resample_adjacency_matrix_(sproc, sd.local, seed=1, step=k, model=smodel, fetch=False, ctx=ctx)
+        _all_reduce_sum(np.array([links]))
+        _lib.check(_lib.lib().nhp_cont_model_moments_accumulate(ctx.h, smodel.h), ctx.h)
+    for k in range(3):
+        sstep(k)
+    ctx.synchronize()
+    sync()
+    t0 = time.perf_counter()
+    for k in range(3, 3 + steps):
+        sstep(k)
+    ctx.synchronize()
+    sync()
+    return wall, time.perf_counter() - t0
 
 
 def main():
@@ -402,9 +426,9 @@ def main():
     wall_s = float(wall.item())
     chain_wall = None
     if world > 1 and args.chain_steps > 0:
-        tw = torch.tensor([chains_leg(nhp, ctx, rank, args.chain_steps, sync)], dtype=torch.float64, device=tdev)
+        tw = torch.tensor(list(chains_leg(nhp, ctx, rank, args.chain_steps, sync)), dtype=torch.float64, device=tdev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        chain_wall = float(tw.item())
+        chain_wall, one_chain_wall = float(tw[0].item()), float(tw[1].item())
     sharded = None
     if world > 1 and args.sharded:
         sharded = sharded_leg(nhp, ctx, args.nodes, args.events, world, [x for x in args.sharded.split(",") if x])
@@ -434,7 +458,8 @@ def main():
             out["config5_independent_chains"] = {
                 "workload": "c3 model (N=1024, M=1e6, logit-normal network), one mcmc! chain per rank, device-side sweep",
                 "chains": world, "steps_per_chain": args.chain_steps,
-                "mcmc_steps_per_sec": world * args.chain_steps / chain_wall, "ms_per_step": 1e3 * chain_wall / args.chain_steps}
+                "mcmc_steps_per_sec": world * args.chain_steps / chain_wall, "ms_per_step": 1e3 * chain_wall / args.chain_steps,
+                "one_chain_over_all_ranks_ms_per_step": 1e3 * one_chain_wall / args.chain_steps}
         if sharded is not None:
             out["one_evaluation_over_all_ranks"] = sharded
         if world == 1 and args.two_streams and not r["recursive"]:

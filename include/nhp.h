@@ -119,8 +119,13 @@ nhp_status nhp_cont_dataset_create(nhp_ctx *ctx, const double *events, const int
  * and the gradient is block-separable in the same columns.  The shard holds every event (all of them are parents) but
  * evaluates only the children on the 0-based nodes [col_begin, col_end); nhp_cont_loglik / _enqueue / _batch / _grad
  * on it return that part (gradient entries of other columns are 0), so the parts of a partition of [0, n_nodes) add up
- * to the whole -- one scalar (or P-vector) all-reduce per evaluation.  The sampler / statistics / adjacency entry
- * points need every column and return NHP_ENOTIMPL on a shard. */
+ * to the whole -- one scalar (or P-vector) all-reduce per evaluation.  The Gibbs sweep is separable in the same way
+ * (parents of the children on c, the statistics and conjugate draws of column c and the sweep of A[:, c] involve column c
+ * only, and every random stream is keyed by global event / entry indices), so nhp_cont_resample_parents,
+ * nhp_cont_gibbs_step and nhp_cont_resample_adjacency on a shard update exactly their columns -- with the same values
+ * a whole-dataset sweep gives them -- and leave the rest untouched (returned parents / statistics of other columns are
+ * 0; n_links counts the shard's links).  nhp_cont_event_intensity and nhp_cont_lgcp_loglik need every column and
+ * return NHP_ENOTIMPL on a shard. */
 nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double *events, const int64_t *nodes,
                                            int64_t n_events, int32_t n_nodes, double duration, double dt_max,
                                            int32_t col_begin, int32_t col_end, nhp_cont_dataset **out);

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_build(nhp_cont_args a, const 
                                                          unsigned char *__restrict__ col_group, int max_children)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int N = a.N, c = blockIdx.x, tid = threadIdx.x;
+    const int N = a.N, c = a.col_begin + blockIdx.x, tid = threadIdx.x;
     // `group` lanes share a child (the dataset's lanes-per-child width, a power of two <= 64), so a wave
     // has 64/group windows in flight instead of one
     const int gl = tid & (group - 1), gid = tid / group, ngroups = NHP_BLOCK / group;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_eval(nhp_cont_args a, const d
                                                         int max_children, double *__restrict__ lam_g)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int N = a.N, c = blockIdx.x, tid = threadIdx.x;
+    const int N = a.N, c = a.col_begin + blockIdx.x, tid = threadIdx.x;
     double2 *col = reinterpret_cast<double2 *>(smem);                      // [N] exp {θ, W}; logit {μ, √τ}
     double *colw = reinterpret_cast<double *>(col + N);                    // [N] logit: W
     double *acol = colw + (IMP == NHP_IMPULSE_EXPONENTIAL ? 0 : N);        // [N] A[·, c]
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64) void k_adj_sweep(nhp_cont_args a, double *__res
                                                   int max_children, double *__restrict__ col_links)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int N = a.N, c = blockIdx.x, lane = threadIdx.x;
+    const int N = a.N, c = a.col_begin + blockIdx.x, lane = threadIdx.x;
     double *lam = reinterpret_cast<double *>(smem);                        // [max_children] current λ_k
     double *dx = lam + max_children;                                       // [max_children] Σ x_kp of the current p
     int *marker = reinterpret_cast<int *>(dx + max_children);              // [max_children]
@@ -352,7 +352,6 @@ extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_d
                                                   uint64_t seed, uint64_t step, double *A_out, double *n_links)
 {
     NHP_TRY(nhp_check_pair(ctx, ds, m));
-    NHP_WHOLE_DATASET(ctx, ds, "resample_adjacency");
     if (!m->has_A) { nhp_set_error(ctx, "resample_adjacency: the model has no adjacency matrix"); return NHP_EINVAL; }
     if (!rho_matrix && !(rho >= 0.0 && rho <= 1.0)) { nhp_set_error(ctx, "link probability must lie in [0, 1]"); return NHP_EDOMAIN; }
     NHP_HIP(ctx, hipSetDevice(ctx->device));
@@ -369,6 +368,8 @@ extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_d
     }
     hipStream_t st = ctx->stream;
     nhp_cont_args a = nhp_make_args(ds, m);
+    // a column shard sweeps its own columns: the columns of A are independent given the data (src/continuous.jl:444-470)
+    const unsigned ncol = (unsigned)(ds->col_end - ds->col_begin);
     // ---- the data-only pair lists, built on first use and kept with the dataset
     if (!ds->d_adj_k) {
         nhp_cont_dataset *mds = const_cast<nhp_cont_dataset *>(ds);
@@ -382,7 +383,7 @@ extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_d
         }
         NHP_HIP(ctx, hipMemcpyAsync(mds->d_adj_off, ds->h_pair_off.data(), 8 * (N + 1), hipMemcpyHostToDevice, st));
         if (lds_build > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
-        hipLaunchKernelGGL(k_adj_build, dim3((unsigned)N), dim3(NHP_BLOCK), lds_build, st, a, ds->d_adj_off, ds->group, mds->d_adj_k,
+        hipLaunchKernelGGL(k_adj_build, dim3(ncol), dim3(NHP_BLOCK), lds_build, st, a, ds->d_adj_off, ds->group, mds->d_adj_k,
                            mds->d_adj_p, mds->d_adj_dt, mds->d_adj_start, mds->d_adj_group, max_children);
         NHP_HIP(ctx, hipGetLastError());
     }
@@ -397,21 +398,22 @@ extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_d
     const double *d_u = u ? (const double *)(base + o_u) : nullptr;
     const double *d_rho = rho_matrix ? (const double *)(base + o_rho) : nullptr;
     double *d_links = (double *)(base + o_links);
+    if (ncol != (unsigned)N) NHP_HIP(ctx, hipMemsetAsync(d_links, 0, 8 * N, st));        // links of the columns this shard does not own
     const int64_t *d_off = ds->d_adj_off;
     const int32_t *d_k = ds->d_adj_k, *d_start = ds->d_adj_start;
     double *d_x = (double *)(base + o_x), *d_lam = (double *)(base + o_lam);
     if (expo) {
         if (lds_eval > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_eval<NHP_IMPULSE_EXPONENTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval));
-        hipLaunchKernelGGL((k_adj_eval<NHP_IMPULSE_EXPONENTIAL>), dim3((unsigned)N), dim3(NHP_BLOCK), lds_eval, st, a, m->d_A,
+        hipLaunchKernelGGL((k_adj_eval<NHP_IMPULSE_EXPONENTIAL>), dim3(ncol), dim3(NHP_BLOCK), lds_eval, st, a, m->d_A,
                            d_off, d_k, ds->d_adj_p, ds->d_adj_dt, d_x, max_children, d_lam);
     } else {
         if (lds_eval > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_eval<NHP_IMPULSE_LOGITNORMAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval));
-        hipLaunchKernelGGL((k_adj_eval<NHP_IMPULSE_LOGITNORMAL>), dim3((unsigned)N), dim3(NHP_BLOCK), lds_eval, st, a, m->d_A,
+        hipLaunchKernelGGL((k_adj_eval<NHP_IMPULSE_LOGITNORMAL>), dim3(ncol), dim3(NHP_BLOCK), lds_eval, st, a, m->d_A,
                            d_off, d_k, ds->d_adj_p, ds->d_adj_dt, d_x, max_children, d_lam);
     }
     NHP_HIP(ctx, hipGetLastError());
     if (lds_sweep > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sweep));
-    hipLaunchKernelGGL(k_adj_sweep, dim3((unsigned)N), dim3(64), lds_sweep, st, a, m->d_A, d_off, d_k, d_x, d_start, ds->d_adj_group, d_lam,
+    hipLaunchKernelGGL(k_adj_sweep, dim3(ncol), dim3(64), lds_sweep, st, a, m->d_A, d_off, d_k, d_x, d_start, ds->d_adj_group, d_lam,
                        d_rho, rho, d_u, seed, step, max_children, d_links);
     NHP_HIP(ctx, hipGetLastError());
     std::vector<double> links(N);

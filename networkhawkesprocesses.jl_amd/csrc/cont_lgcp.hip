@@ -56,6 +56,7 @@ extern "C" nhp_status nhp_cont_lgcp_loglik(nhp_ctx *ctx, const nhp_cont_dataset 
 {
     if (!ctx || !ds || !grid_x || !lam || !ll) { if (ctx) nhp_set_error(ctx, "lgcp_loglik: null argument"); return NHP_EINVAL; }
     if (ds->ctx != ctx) { nhp_set_error(ctx, "lgcp_loglik: dataset belongs to another context"); return NHP_EINVAL; }
+    NHP_WHOLE_DATASET(ctx, ds, "lgcp_loglik");          // reads the parent assignment of every node
     if (grid_n < 2 || grid_n > 4096) { nhp_set_error(ctx, "lgcp_loglik: grid_n = %d outside [2, 4096]", grid_n); return NHP_ESHAPE; }
     for (int g = 0; g + 1 < grid_n; ++g)
         if (!(grid_x[g + 1] > grid_x[g])) { nhp_set_error(ctx, "lgcp_loglik: grid points must be strictly increasing"); return NHP_EDOMAIN; }

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_stats(nhp_cont_args a, const int3
 {
 #pragma clang fp contract(off)
     extern __shared__ __align__(16) unsigned char smem[];
-    const int c = blockIdx.x, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = a.col_begin + blockIdx.x, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *cnt = reinterpret_cast<double *>(smem);          // [N] events on c attributed to p
     double *sx = cnt + N;                                    // [N] Σ value, then the mean
     double *sv = sx + N;                                     // [N] Σ (value - mean)²
@@ -447,6 +447,12 @@ static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
     hipStream_t st = ctx->stream;
     NHP_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(int), st));
     if (u && M) NHP_HIP(ctx, hipMemcpyAsync(d_u, u, 8 * M, hipMemcpyHostToDevice, st));
+    if (nhp_is_column_shard(ds)) {
+        // a shard samples the parents of the children on its own nodes; everything it does not own reads as "no parent",
+        // and the statistics of the other columns as zero
+        if (want_parents) { NHP_HIP(ctx, hipMemsetAsync(o->parents, 0, 8 * Mp, st)); NHP_HIP(ctx, hipMemsetAsync(o->pnodes, 0, 8 * Mp, st)); }
+        if (want_stats) NHP_HIP(ctx, hipMemsetAsync(base + o_cnt0, 0, off - o_cnt0, st));
+    }
 
     nhp_cont_args a = nhp_make_args(ds, m);
     const bool expo = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
@@ -472,7 +478,7 @@ static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
         const size_t lds_stats = 8 * (3 * N + NHP_BLOCK + NHP_WAVES) + 4 * NHP_BLOCK + 4 * N + 16;
         if (lds_stats > 160 * 1024) { nhp_set_error(ctx, "statistics: n_nodes = %d exceeds the LDS budget", ds->N); return NHP_ENOTIMPL; }
         if (lds_stats > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_stats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stats);
-        hipLaunchKernelGGL(k_stats, dim3((unsigned)N), dim3(NHP_BLOCK), lds_stats, st, a, o->pn_b, o->dt_b, o->cnt0, o->Mn, o->Mnm, o->X, o->V);
+        hipLaunchKernelGGL(k_stats, dim3((unsigned)(ds->col_end - ds->col_begin)), dim3(NHP_BLOCK), lds_stats, st, a, o->pn_b, o->dt_b, o->cnt0, o->Mn, o->Mnm, o->X, o->V);
         NHP_HIP(ctx, hipGetLastError());
     }
     int h_err = 0;
@@ -491,7 +497,6 @@ extern "C" nhp_status nhp_cont_resample_parents(nhp_ctx *ctx, const nhp_cont_dat
                                                 int64_t *parents, int64_t *parentnodes, nhp_cont_stats *stats)
 {
     NHP_TRY(nhp_check_pair(ctx, ds, m));
-    NHP_WHOLE_DATASET(ctx, ds, "resample_parents");
     samp_out o;
     NHP_TRY(run_sampler(ctx, ds, m, u, seed, step, parents || parentnodes, stats != nullptr, &o));
     const size_t M = (size_t)ds->M, N = (size_t)ds->N, NN = N * N;
@@ -513,7 +518,9 @@ extern "C" nhp_status nhp_cont_resample_parents(nhp_ctx *ctx, const nhp_cont_dat
 // ---- device-side conjugate draws: the counter-based Gamma / Normal generators live in nhp_rng.h
 struct gibbs_priors { double alpha0, beta0, kappa, nu, a, b, mu_mu, kappa_mu; };
 
-__global__ __launch_bounds__(256) void k_gibbs_draw(int N, int impulse_kind, double duration, gibbs_priors pr,
+// A column shard draws the parameters of its own columns (λ0_c and column c of W, θ | μ, τ); Mn[p], the events on the
+// PARENT node, comes from the dataset's counts, which a shard has for every node.
+__global__ __launch_bounds__(256) void k_gibbs_draw(int N, int col_begin, int col_end, int impulse_kind, double duration, gibbs_priors pr,
                                                     uint64_t seed, uint64_t step,
                                                     const double *__restrict__ cnt0, const double *__restrict__ Mn,
                                                     const double *__restrict__ Mnm, const double *__restrict__ X,
@@ -522,9 +529,11 @@ __global__ __launch_bounds__(256) void k_gibbs_draw(int N, int impulse_kind, dou
 {
     const size_t NN = (size_t)N * N;
     const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (k < (size_t)N)      // λ0_c ~ Gamma(α0 + cnt0_c, 1/(β0 + T))
+    if (k < (size_t)N && (int)k >= col_begin && (int)k < col_end)      // λ0_c ~ Gamma(α0 + cnt0_c, 1/(β0 + T))
         lambda0[k] = dev_gamma(pr.alpha0 + cnt0[k], rng_rcp(pr.beta0 + duration), seed ^ 0x243F6A8885A308D3ull, step, k);
     if (k >= NN) return;
+    const int col = (int)((uint32_t)k / (uint32_t)N);
+    if (col < col_begin || col >= col_end) return;
     const double m = Mnm[k];
     // W[p,c] ~ Gamma(κ + Mnm, 1/(ν + Mn[p]))
     W[k] = dev_gamma(pr.kappa + m, rng_rcp(pr.nu + Mn[(uint32_t)k % (uint32_t)N]), seed ^ 0x13198A2E03707344ull, step, k);
@@ -549,7 +558,6 @@ extern "C" nhp_status nhp_cont_gibbs_step(nhp_ctx *ctx, const nhp_cont_dataset *
                                           const nhp_gibbs_priors *pr, uint64_t seed, uint64_t step)
 {
     NHP_TRY(nhp_check_pair(ctx, ds, m));
-    NHP_WHOLE_DATASET(ctx, ds, "gibbs_step");
     if (!pr) return NHP_EINVAL;
     if (m->baseline_kind != NHP_BASELINE_HOMOGENEOUS) { nhp_set_error(ctx, "gibbs_step: homogeneous baseline only"); return NHP_ENOTIMPL; }
     samp_out o;
@@ -557,8 +565,8 @@ extern "C" nhp_status nhp_cont_gibbs_step(nhp_ctx *ctx, const nhp_cont_dataset *
     gibbs_priors g{pr->alpha0, pr->beta0, pr->kappa, pr->nu, pr->a, pr->b, pr->mu_mu, pr->kappa_mu};
     const size_t NN = (size_t)ds->N * ds->N;
     ++m->version;
-    hipLaunchKernelGGL(k_gibbs_draw, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, ctx->stream, ds->N, m->impulse_kind,
-                       ds->duration, g, seed, step, o.cnt0, o.Mn, o.Mnm, o.X, o.V, m->d_lambda0, m->d_p1, m->d_p2, m->d_W);
+    hipLaunchKernelGGL(k_gibbs_draw, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, ctx->stream, ds->N, ds->col_begin, ds->col_end,
+                       m->impulse_kind, ds->duration, g, seed, step, o.cnt0, ds->d_cnt, o.Mnm, o.X, o.V, m->d_lambda0, m->d_p1, m->d_p2, m->d_W);
     NHP_HIP(ctx, hipGetLastError());
     return NHP_OK;
 }

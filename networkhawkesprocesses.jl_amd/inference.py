@@ -231,6 +231,37 @@ def _fetch_moments(process, model, ctx, network, rho_sum, rho_sq):
     return mean, m2, cnt.value
 
 
+def _owned_mask(process, shard, network):
+    """1 on the entries of params(process) this rank owns (its columns; rank 0 also the network's ρ), 0 elsewhere."""
+    N = process.ndims()
+    c0, c1 = shard.ranges[shard.rank]
+    col = np.zeros(N)
+    col[c0:c1] = 1.0
+    mat = np.repeat(col, N)                                   # vec of an N x N matrix, column-major: index p + c·N
+    nmat = 1 if isinstance(process.impulses, ExponentialImpulseResponse) else 2
+    if not network:                                           # [λ0; impulses; W]
+        return np.concatenate([col] + [mat] * (nmat + 1))
+    k = len(process.network.params())                         # [ρ; λ0; W; impulses; vec(A)]
+    return np.concatenate([np.full(k, 1.0 if shard.rank == 0 else 0.0), col] + [mat] * (nmat + 2))
+
+
+def _merge_shards(process, shard, network):
+    """After a sharded chain every rank holds the final values of its own columns: put the full state on every rank."""
+    from .sharded import _all_reduce_sum
+    N = process.ndims()
+    full = _all_reduce_sum(process.params() * _owned_mask(process, shard, network))
+    k = len(process.network.params()) if network else 0
+    nimp = N * N * (1 if isinstance(process.impulses, ExponentialImpulseResponse) else 2)
+    process.baseline.λ = full[k:k + N].copy()
+    if network:
+        process.weights.params_(full[k + N:k + N + N * N])
+        process.impulses.params_(full[k + N + N * N:k + N + N * N + nimp])
+        process.adjacency_matrix = full[k + N + N * N + nimp:].reshape((N, N), order="F").copy()
+    else:
+        process.impulses.params_(full[N:N + nimp])
+        process.weights.params_(full[N + nimp:])
+
+
 def mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, keep_samples=True, device_draws=True,
           ctx=None, moments=False, burn=0):
     """mcmc!(process, data; nsteps, log_freq, verbose) -- src/inference.jl:49-70.
@@ -244,14 +275,24 @@ def mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, keep_
     `moments=True` (device draws only) keeps the chain's running sums on the device (nhp_cont_model_moments_*): after the
     run `res.mean` and `res.m2` hold the mean and the mean square of params(process) over the steps >= `burn` -- the
     summaries chains.py gathers -- with no per-step transfer; combine with keep_samples=False for long chains at large N
-    (a sample is 4N²+N doubles, 33.5 MB at N = 1024)."""
+    (a sample is 4N²+N doubles, 33.5 MB at N = 1024).
+
+    ONE chain over several GPUs: pass a `sharded.ShardedDataset` (device draws, keep_samples=False).  A sweep is
+    separable by child-node column -- the parents of the children on c, column c's statistics and conjugate draws and
+    the sweep of A[:, c] touch column c only, and every random stream is keyed by global event / entry indices -- so
+    each rank sweeps its own columns and the chain is the single-GPU chain, value for value; the only exchange per step
+    is the scalar link count the network's ρ update needs, and at the end the ranks' columns (and moments) are merged."""
     import ctypes as C
+    from .sharded import ShardedDataset, _all_reduce_sum
+    shard = data if isinstance(data, ShardedDataset) else None
     if not isinstance(process.baseline, HomogeneousProcess):
         device_draws = False      # nhp_cont_gibbs_step draws the homogeneous λ0; the LGCP curve is a host slice loop
     if moments and not device_draws:
         raise ValueError("moments=True needs the device-side draws (homogeneous baseline, device_draws=True)")
-    ctx = ctx or _lib.default_context()
-    ds = device_dataset(process, data, ctx)
+    if shard is not None and (not device_draws or keep_samples):
+        raise ValueError("a sharded chain runs with the device-side draws and keep_samples=False (use moments=True)")
+    ctx = (shard.ctx if shard else ctx) or _lib.default_context()
+    ds = shard.local if shard else device_dataset(process, data, ctx)
     rng = np.random.default_rng(seed)
     res = MarkovChainMonteCarlo()
     start = time.time()
@@ -267,6 +308,8 @@ def mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, keep_
             if isinstance(process, ContinuousNetworkHawkesProcess):
                 last = keep_samples or res.steps == nsteps - 1
                 links = resample_adjacency_matrix_(process, ds, seed=seed, step=res.steps, model=model, fetch=last, ctx=ctx)
+                if shard is not None:                        # the shards' link counts: the one exchange of a step
+                    links = float(_all_reduce_sum(np.array([links]))[0])
                 process.network.resample_links_(links, process.ndims() ** 2, rng)
             if moments and res.steps >= burn:
                 _lib.check(_lib.lib().nhp_cont_model_moments_accumulate(ctx.h, model.h), ctx.h)
@@ -286,8 +329,13 @@ def mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, keep_
             print(f" > step: {res.steps}, elapsed: {res.elapsed}")
     res.elapsed = time.time() - start
     res.status = "complete"
+    if shard is not None and shard.world > 1:
+        _merge_shards(process, shard, network)
     if not keep_samples:
         res.samples.append(process.params())
     if moments:
         res.mean, res.m2, res.n = _fetch_moments(process, model, ctx, network, rho_sum, rho_sq)
+        if shard is not None and shard.world > 1:
+            mask = _owned_mask(process, shard, network)
+            res.mean, res.m2 = _all_reduce_sum(res.mean * mask), _all_reduce_sum(res.m2 * mask)
     return res

@@ -13,6 +13,11 @@ per event, nothing next to 288 GB) but builds work only for the children on its 
 "gloo" in the CPU tests.  The time axis is not cut: the recursive formulation carries its state over all history
 (SURVEY 8e), columns work for both formulations, and the per-column work is what the kernels already partition by.
 
+The Gibbs sweep of mcmc! separates by the same columns (the parents of the children on c, column c's statistics and
+conjugate draws, the sweep of A[:, c]), so `mcmc_` on a ShardedDataset runs ONE chain on all ranks, each its columns,
+with one scalar exchanged per step -- and, the random streams being keyed by global indices, it is the single-GPU chain
+value for value (inference.mcmc_).
+
 The reference has no distributed code (README.md:42); independent chains / restarts shard without any exchange
 (chains.py) and remain the primary way to use several GPUs.
 """

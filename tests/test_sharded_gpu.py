@@ -88,9 +88,13 @@ def test_batch_on_a_shard_and_what_a_shard_refuses(nhp, orc):
         tot += out[0]
     assert rel(tot, nhp.loglikelihood(proc, data, recursive=False)) < 1e-12
     with pytest.raises(NotImplementedError, match="column shard"):
-        nhp.resample_parents(proc, shards[0].local, seed=1, step=0)
-    with pytest.raises(NotImplementedError, match="column shard"):
         nhp.total_intensity(proc, shards[0].local)
+    # the parent sampler on a shard: the parents of the children on its nodes, exactly as the whole dataset gives them
+    par, pn = nhp.resample_parents(proc, data, seed=1, step=0)[:2]
+    par0, pn0 = nhp.resample_parents(proc, shards[0].local, seed=1, step=0)[:2]
+    own = (data[1] - 1 >= shards[0].ranges[0][0]) & (data[1] - 1 < shards[0].ranges[0][1])
+    assert np.array_equal(par[own], par0[own]) and np.array_equal(pn[own], pn0[own])
+    assert not par0[~own].any() and not pn0[~own].any()
     # a query-time intensity table needs no children: allowed
     q = np.array([10.0, 20.0])
     assert np.allclose(nhp.intensity(proc, shards[1].local, q), nhp.intensity(proc, data, q), rtol=1e-13)
@@ -166,3 +170,99 @@ def test_two_ranks_evaluate_one_loglikelihood_together(tmp_path):
                          capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-8000:]
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+
+
+CHAIN_WORKER = '''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+import __graft_entry__ as entry
+nhp = entry.load_package()
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(6)
+N, M, T = 12, 6000, 700.0
+t = np.sort(rng.uniform(0, T, M)); n = rng.integers(1, N + 1, M).astype(np.int64)
+def make(kind):
+    r = np.random.default_rng(9)
+    imp = (nhp.ExponentialImpulseResponse(r.uniform(1, 5, (N, N)), 1.0, 1.0, 1.0) if kind == "exp"
+           else nhp.LogitNormalImpulseResponse(r.normal(0, 1, (N, N)), r.uniform(0.5, 2, (N, N)), 1.0))
+    base, w = nhp.HomogeneousProcess(r.uniform(0.5, 1.5, N)), nhp.DenseWeightModel(r.uniform(0, 1, (N, N)) / N)
+    if kind == "exp":
+        return nhp.ContinuousStandardHawkesProcess(base, imp, w)
+    return nhp.ContinuousNetworkHawkesProcess(base, imp, w, (r.uniform(size=(N, N)) < 0.5).astype(np.float64), nhp.BernoulliNetworkModel(0.5, N))
+data = (t, n, T)
+for kind in ("exp", "logit"):
+    one = make(kind)
+    a = nhp.mcmc_(one, data, nsteps=12, seed=4, keep_samples=False, moments=True, burn=3)          # the whole chain on this GPU
+    two = make(kind)
+    sd = nhp.ShardedDataset(two, data)
+    b = nhp.mcmc_(two, sd, nsteps=12, seed=4, keep_samples=False, moments=True, burn=3)            # each rank its columns
+    assert np.array_equal(a.samples[-1], b.samples[-1]), (kind, np.max(np.abs(a.samples[-1] - b.samples[-1])))
+    assert np.array_equal(a.mean, b.mean) and np.array_equal(a.m2, b.m2) and a.n == b.n == 9
+    assert np.array_equal(one.params(), two.params())
+    try:
+        nhp.mcmc_(two, sd, nsteps=2, seed=4)                 # kept samples would cross PCIe and the ranks every step
+        raise SystemExit("expected ValueError")
+    except ValueError:
+        pass
+dist.barrier()
+dist.destroy_process_group()
+os.write(1, ("rank %d ok" % rank + chr(10)).encode())
+'''
+
+
+def test_two_ranks_run_one_chain_together(tmp_path):
+    """ONE mcmc! chain swept by two ranks, each its columns: the chain is the single-GPU chain value for value."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(CHAIN_WORKER.format(root=root))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", NHP_DEVICE="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-8000:]
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+
+
+def test_gibbs_sweep_on_a_shard_updates_its_columns_only(nhp, orc):
+    """Single process: a sweep on a column shard equals the whole-dataset sweep on the shard's columns and leaves the
+    other columns of the model untouched."""
+    import ctypes as C
+    from nhp_amd import _lib, inference
+    ctx = _lib.default_context()
+    proc, om, data = build(nhp, orc, 10, 5000, 400.0, "logitnormal", 1.0, True, seed=77)
+    proc2, _, _ = build(nhp, orc, 10, 5000, 400.0, "logitnormal", 1.0, True, seed=77)
+    before = proc.params().copy()
+    whole = nhp.device_dataset(proc, data, ctx)
+    m1, pri = proc.device_model(ctx), inference._priors(proc)
+    _lib.check(_lib.lib().nhp_cont_gibbs_step(ctx.h, whole.h, m1.h, C.byref(pri), 3, 0), ctx.h)
+    l1 = inference.resample_adjacency_matrix_(proc, whole, seed=3, step=0, model=m1, ctx=ctx)
+    inference._pull_params(proc, m1, ctx)
+    sd = nhp.ShardedDataset(proc2, data, rank=1, world=3)
+    c0, c1 = sd.ranges[1]
+    m2 = proc2.device_model(ctx)
+    _lib.check(_lib.lib().nhp_cont_gibbs_step(ctx.h, sd.local.h, m2.h, C.byref(pri), 3, 0), ctx.h)
+    l2 = inference.resample_adjacency_matrix_(proc2, sd.local, seed=3, step=0, model=m2, ctx=ctx)
+    inference._pull_params(proc2, m2, ctx)
+    N = 10
+    for name in ("W", "μ", "τ", "A"):
+        get = lambda p: (p.adjacency_matrix if name == "A" else getattr(p.weights if name == "W" else p.impulses, name))
+        x1, x2 = get(proc), get(proc2)
+        assert np.array_equal(x1[:, c0:c1], x2[:, c0:c1]), name
+    assert np.array_equal(proc.baseline.λ[c0:c1], proc2.baseline.λ[c0:c1])
+    # the other columns keep their initial values
+    init, _, _ = build(nhp, orc, 10, 5000, 400.0, "logitnormal", 1.0, True, seed=77)
+    keep = np.r_[0:c0, c1:N]
+    assert np.array_equal(proc2.weights.W[:, keep], init.weights.W[:, keep])
+    assert np.array_equal(proc2.adjacency_matrix[:, keep], init.adjacency_matrix[:, keep])
+    assert l2 == proc2.adjacency_matrix[:, c0:c1].sum() and l1 == proc.adjacency_matrix.sum()
