@@ -260,7 +260,9 @@ def loglikelihood_gradient(process, data, recursive=True, ctx=None, model=None):
     ctx = ctx or _lib.default_context()
     ds = device_dataset(process, data, ctx)
     model = model or process.device_model(ctx)
-    P = len(process.params())
+    N = process.ndims()                        # len(params(process)) without building the vector (column-major copies)
+    P = (N if isinstance(process.baseline, HomogeneousProcess) else N * len(process.baseline.x)) \
+        + N * N * (2 if isinstance(process.impulses, ExponentialImpulseResponse) else 3)
     g = np.empty(P)
     ll = C.c_double()
     _lib.check(_lib.lib().nhp_cont_loglik_grad(ctx.h, ds.h, model.h, _check_recursive(process, recursive),

@@ -418,8 +418,8 @@ extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_d
     NHP_HIP(ctx, hipGetLastError());
     std::vector<double> links(N);
     NHP_HIP(ctx, hipMemcpyAsync(links.data(), d_links, 8 * N, hipMemcpyDeviceToHost, st));
-    if (A_out) NHP_HIP(ctx, hipMemcpyAsync(A_out, m->d_A, 8 * NN, hipMemcpyDeviceToHost, st));
     NHP_HIP(ctx, hipStreamSynchronize(st));
+    if (A_out) NHP_TRY(nhp_download(ctx, A_out, m->d_A, 8 * NN));
     if (n_links) {
         double s = 0.0;
         for (double v : links) s += v;

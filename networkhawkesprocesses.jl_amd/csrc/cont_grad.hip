@@ -329,6 +329,6 @@ extern "C" nhp_status nhp_cont_loglik_grad(nhp_ctx *ctx, const nhp_cont_dataset 
         else launch_grad_group<NHP_IMPULSE_LOGITNORMAL>(G, grid, lds, st, a, d_lambda, d_grad);
         NHP_HIP(ctx, hipGetLastError());
     }
-    NHP_HIP(ctx, hipMemcpyAsync(grad, d_grad, 8 * P, hipMemcpyDeviceToHost, st));
+    NHP_TRY(nhp_download(ctx, grad, d_grad, 8 * P));
     return nhp_ctx_fetch(ctx, 0, 1, ll);
 }

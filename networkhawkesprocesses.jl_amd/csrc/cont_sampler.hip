@@ -636,9 +636,8 @@ extern "C" nhp_status nhp_cont_model_moments_fetch(nhp_ctx *ctx, const nhp_cont_
     if (!m->d_mom) { nhp_set_error(ctx, "moments: nothing accumulated"); return NHP_EINVAL; }
     if (len != m->mom_len) { nhp_set_error(ctx, "Parameter vector length does not match model parameter length."); return NHP_ESHAPE; }
     NHP_HIP(ctx, hipSetDevice(ctx->device));
-    NHP_HIP(ctx, hipMemcpyAsync(sum, m->d_mom, sizeof(double) * (size_t)len, hipMemcpyDeviceToHost, ctx->stream));
-    NHP_HIP(ctx, hipMemcpyAsync(sumsq, m->d_mom + len, sizeof(double) * (size_t)len, hipMemcpyDeviceToHost, ctx->stream));
-    NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    NHP_TRY(nhp_download(ctx, sum, m->d_mom, sizeof(double) * (size_t)len));
+    NHP_TRY(nhp_download(ctx, sumsq, m->d_mom + len, sizeof(double) * (size_t)len));
     *count = m->mom_count;
     return NHP_OK;
 }
@@ -653,10 +652,10 @@ extern "C" nhp_status nhp_cont_model_get_params(nhp_ctx *ctx, const nhp_cont_mod
     if ((size_t)len != N + nimp + NN) { nhp_set_error(ctx, "Parameter vector length does not match model parameter length."); return NHP_ESHAPE; }
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    NHP_HIP(ctx, hipMemcpyAsync(x, m->d_lambda0, 8 * N, hipMemcpyDeviceToHost, st));
-    NHP_HIP(ctx, hipMemcpyAsync(x + N, m->d_p1, 8 * NN, hipMemcpyDeviceToHost, st));
-    if (m->impulse_kind == NHP_IMPULSE_LOGITNORMAL) NHP_HIP(ctx, hipMemcpyAsync(x + N + NN, m->d_p2, 8 * NN, hipMemcpyDeviceToHost, st));
-    NHP_HIP(ctx, hipMemcpyAsync(x + N + nimp, m->d_W, 8 * NN, hipMemcpyDeviceToHost, st));
-    NHP_HIP(ctx, hipStreamSynchronize(st));
+    (void)st;
+    NHP_TRY(nhp_download(ctx, x, m->d_lambda0, 8 * N));
+    NHP_TRY(nhp_download(ctx, x + N, m->d_p1, 8 * NN));
+    if (m->impulse_kind == NHP_IMPULSE_LOGITNORMAL) NHP_TRY(nhp_download(ctx, x + N + NN, m->d_p2, 8 * NN));
+    NHP_TRY(nhp_download(ctx, x + N + nimp, m->d_W, 8 * NN));
     return NHP_OK;
 }

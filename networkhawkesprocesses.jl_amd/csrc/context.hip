@@ -76,6 +76,7 @@ extern "C" void nhp_ctx_destroy(nhp_ctx *ctx)
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->d_results) (void)hipFree(ctx->d_results);
     if (ctx->h_results) (void)hipHostFree(ctx->h_results);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
@@ -129,6 +130,28 @@ nhp_status nhp_ctx_reserve_partials(nhp_ctx *ctx, size_t n)
     ctx->partials_cap = 0;
     NHP_HIP(ctx, hipMalloc(&ctx->d_partials, sizeof(double) * n));
     ctx->partials_cap = n;
+    return NHP_OK;
+}
+
+nhp_status nhp_download(nhp_ctx *ctx, void *dst, const void *d_src, size_t bytes)
+{
+    if (bytes == 0) { NHP_HIP(ctx, hipStreamSynchronize(ctx->stream)); return NHP_OK; }
+    if (bytes > ctx->stage_cap) {
+        NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+        ctx->h_stage = nullptr; ctx->stage_cap = 0;
+        const size_t cap = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        if (hipHostMalloc(&ctx->h_stage, cap) != hipSuccess) {       // no pinned memory: fall back to the direct copy
+            ctx->h_stage = nullptr;
+            NHP_HIP(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            return NHP_OK;
+        }
+        ctx->stage_cap = cap;
+    }
+    NHP_HIP(ctx, hipMemcpyAsync(ctx->h_stage, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(dst, ctx->h_stage, bytes);
     return NHP_OK;
 }
 

@@ -32,6 +32,8 @@ struct nhp_ctx {
     // Second lane for independent evaluations inside one call (nhp_cont_loglik_batch): its own stream, partial sums and
     // tickets.  A launch has fixed costs -- dispatch / completion, column staging, the reduction tail -- during which
     // the chip idles; with two lanes they run under the other lane's pair loops (profiles/README.md: two streams).
+    void *h_stage = nullptr;            // pinned staging buffer for large downloads (gradients, parameters, moments)
+    size_t stage_cap = 0;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     double *d_partials2 = nullptr;
@@ -205,6 +207,9 @@ nhp_status nhp_launch_windowed_as(nhp_ctx *ctx, const nhp_cont_dataset *ds, cons
 nhp_status nhp_ctx_reserve_scratch(nhp_ctx *ctx, size_t bytes);
 nhp_cont_args nhp_make_args(const nhp_cont_dataset *ds, const nhp_cont_model *m);
 nhp_status nhp_check_pair(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m);
+// Device -> caller memory through the context's pinned staging buffer: DMA at link speed into pinned memory, then one
+// host copy (a direct copy into pageable caller memory ran at ~1 GB/s here).  Synchronises the stream.
+nhp_status nhp_download(nhp_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 bool nhp_is_column_shard(const nhp_cont_dataset *ds);
 // entry points that need every column (samplers, intensity tables): refuse a column shard
 #define NHP_WHOLE_DATASET(ctx, ds, what)                                                                       \
