@@ -501,17 +501,16 @@ extern "C" nhp_status nhp_cont_resample_parents(nhp_ctx *ctx, const nhp_cont_dat
     NHP_TRY(run_sampler(ctx, ds, m, u, seed, step, parents || parentnodes, stats != nullptr, &o));
     const size_t M = (size_t)ds->M, N = (size_t)ds->N, NN = N * N;
     hipStream_t st = ctx->stream;
-    if (stats) {
-        if (stats->cnt0) NHP_HIP(ctx, hipMemcpyAsync(stats->cnt0, o.cnt0, 8 * N, hipMemcpyDeviceToHost, st));
-        if (stats->Mn) NHP_HIP(ctx, hipMemcpyAsync(stats->Mn, o.Mn, 8 * N, hipMemcpyDeviceToHost, st));
-        if (stats->Mnm) NHP_HIP(ctx, hipMemcpyAsync(stats->Mnm, o.Mnm, 8 * NN, hipMemcpyDeviceToHost, st));
-        if (stats->Xnm) NHP_HIP(ctx, hipMemcpyAsync(stats->Xnm, o.X, 8 * NN, hipMemcpyDeviceToHost, st));
-        if (stats->Vnm && m->impulse_kind == NHP_IMPULSE_LOGITNORMAL)
-            NHP_HIP(ctx, hipMemcpyAsync(stats->Vnm, o.V, 8 * NN, hipMemcpyDeviceToHost, st));
+    (void)st;
+    if (stats) {                                   // through the pinned staging buffer (nhp_download synchronises)
+        if (stats->cnt0) NHP_TRY(nhp_download(ctx, stats->cnt0, o.cnt0, 8 * N));
+        if (stats->Mn) NHP_TRY(nhp_download(ctx, stats->Mn, o.Mn, 8 * N));
+        if (stats->Mnm) NHP_TRY(nhp_download(ctx, stats->Mnm, o.Mnm, 8 * NN));
+        if (stats->Xnm) NHP_TRY(nhp_download(ctx, stats->Xnm, o.X, 8 * NN));
+        if (stats->Vnm && m->impulse_kind == NHP_IMPULSE_LOGITNORMAL) NHP_TRY(nhp_download(ctx, stats->Vnm, o.V, 8 * NN));
     }
-    if (parents && M) NHP_HIP(ctx, hipMemcpyAsync(parents, o.parents, 8 * M, hipMemcpyDeviceToHost, st));
-    if (parentnodes && M) NHP_HIP(ctx, hipMemcpyAsync(parentnodes, o.pnodes, 8 * M, hipMemcpyDeviceToHost, st));
-    NHP_HIP(ctx, hipStreamSynchronize(st));
+    if (parents && M) NHP_TRY(nhp_download(ctx, parents, o.parents, 8 * M));
+    if (parentnodes && M) NHP_TRY(nhp_download(ctx, parentnodes, o.pnodes, 8 * M));
     return NHP_OK;
 }
 
