@@ -191,6 +191,11 @@ typedef struct {
     double a, b;             /* ExponentialImpulseResponse.α, β  |  LogitNormalImpulseResponse.α0, β0 */
     double mu_mu, kappa_mu;  /* LogitNormalImpulseResponse.μμ, κμ */
 } nhp_gibbs_priors;
+/* Asynchronous: the sweep is enqueued and the call returns without draining the GPU, so a chain keeps one sweep in
+ * flight.  The sampler's only run-time failure (the weights of some event do not sum to a positive finite value, the
+ * error nhp_cont_resample_parents reports at once) therefore surfaces as NHP_EDOMAIN from the NEXT nhp_cont_gibbs_step
+ * on this context, or from the next call that synchronises it (nhp_ctx_synchronize, the parameter / moment / result
+ * downloads), once. */
 nhp_status nhp_cont_gibbs_step(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_model *model,
                                const nhp_gibbs_priors *priors, uint64_t seed, uint64_t step);
 /* resample_adjacency_matrix!(process, data)  src/continuous.jl:444-487: one Gibbs sweep over the

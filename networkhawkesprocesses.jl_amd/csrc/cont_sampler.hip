@@ -426,7 +426,8 @@ struct samp_out {
 };
 
 static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, const double *u,
-                              uint64_t seed, uint64_t step, bool want_parents, bool want_stats, samp_out *o)
+                              uint64_t seed, uint64_t step, bool want_parents, bool want_stats, samp_out *o,
+                              nhp_status *deferred = nullptr)      // non-null: do not synchronise; *deferred = the PREVIOUS sweep's verdict
 {
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t M = (size_t)ds->M, N = (size_t)ds->N, NN = N * N, Mp = M ? M : 1;
@@ -443,7 +444,8 @@ static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
     o->cnt0 = (double *)(base + o_cnt0); o->Mn = (double *)(base + o_Mn); o->Mnm = (double *)(base + o_Mnm);
     o->X = (double *)(base + o_X); o->V = (double *)(base + o_V);
     double *d_u = u ? (double *)(base + o_u) : nullptr;
-    int *d_err = (int *)(base + o_err);
+    (void)o_err;
+    int *d_err = ctx->d_err;                 // the context's own word: the deferred check outlives the scratch layout
     hipStream_t st = ctx->stream;
     NHP_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(int), st));
     if (u && M) NHP_HIP(ctx, hipMemcpyAsync(d_u, u, 8 * M, hipMemcpyHostToDevice, st));
@@ -481,10 +483,19 @@ static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
         hipLaunchKernelGGL(k_stats, dim3((unsigned)(ds->col_end - ds->col_begin)), dim3(NHP_BLOCK), lds_stats, st, a, o->pn_b, o->dt_b, o->cnt0, o->Mn, o->Mnm, o->X, o->V);
         NHP_HIP(ctx, hipGetLastError());
     }
-    int h_err = 0;
-    NHP_HIP(ctx, hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    // the flag of the sweep before this one (if it was deferred) is on the host by now: this sweep is enqueued behind it
+    const nhp_status earlier = nhp_check_deferred(ctx);
+    NHP_HIP(ctx, hipMemcpyAsync(ctx->h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (deferred) {
+        NHP_HIP(ctx, hipEventRecord(ctx->ev_err, st));
+        ctx->err_pending = true;
+        *deferred = earlier;
+        return NHP_OK;
+    }
     NHP_HIP(ctx, hipStreamSynchronize(st));
-    if (h_err) {
+    if (earlier != NHP_OK) return earlier;
+    if (*ctx->h_err) {
+        *ctx->h_err = 0;
         nhp_set_error(ctx, "resample_parents: weights of some event do not sum to a positive finite value");
         return NHP_EDOMAIN;
     }
@@ -560,14 +571,16 @@ extern "C" nhp_status nhp_cont_gibbs_step(nhp_ctx *ctx, const nhp_cont_dataset *
     if (!pr) return NHP_EINVAL;
     if (m->baseline_kind != NHP_BASELINE_HOMOGENEOUS) { nhp_set_error(ctx, "gibbs_step: homogeneous baseline only"); return NHP_ENOTIMPL; }
     samp_out o;
-    NHP_TRY(run_sampler(ctx, ds, m, nullptr, seed, step, false, true, &o));
+    // no synchronisation inside a sweep: its error flag is looked at one sweep later (nhp_check_deferred)
+    nhp_status earlier = NHP_OK;
+    NHP_TRY(run_sampler(ctx, ds, m, nullptr, seed, step, false, true, &o, &earlier));
     gibbs_priors g{pr->alpha0, pr->beta0, pr->kappa, pr->nu, pr->a, pr->b, pr->mu_mu, pr->kappa_mu};
     const size_t NN = (size_t)ds->N * ds->N;
     ++m->version;
     hipLaunchKernelGGL(k_gibbs_draw, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, ctx->stream, ds->N, ds->col_begin, ds->col_end,
                        m->impulse_kind, ds->duration, g, seed, step, o.cnt0, ds->d_cnt, o.Mnm, o.X, o.V, m->d_lambda0, m->d_p1, m->d_p2, m->d_W);
     NHP_HIP(ctx, hipGetLastError());
-    return NHP_OK;
+    return earlier;
 }
 
 // ---- sample store: running first and second moments of the chain on the device.  mcmc! keeps

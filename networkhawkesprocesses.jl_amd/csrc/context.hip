@@ -52,6 +52,10 @@ extern "C" nhp_status nhp_ctx_create(int32_t device, nhp_ctx **out)
     NHP_HIP(ctx, hipHostMalloc(&ctx->h_results, sizeof(double) * NHP_MAX_SLOTS));
     NHP_HIP(ctx, hipMalloc(&ctx->d_counter, 128 * 80));
     NHP_HIP(ctx, hipMemsetAsync(ctx->d_counter, 0, 128 * 80, ctx->stream));
+    NHP_HIP(ctx, hipMalloc((void **)&ctx->d_err, sizeof(int)));
+    NHP_HIP(ctx, hipHostMalloc((void **)&ctx->h_err, sizeof(int)));
+    *ctx->h_err = 0;
+    NHP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_err, hipEventDisableTiming));
     NHP_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     NHP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     NHP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
@@ -77,6 +81,9 @@ extern "C" void nhp_ctx_destroy(nhp_ctx *ctx)
     if (ctx->d_results) (void)hipFree(ctx->d_results);
     if (ctx->h_results) (void)hipHostFree(ctx->h_results);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->d_err) (void)hipFree(ctx->d_err);
+    if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+    if (ctx->ev_err) (void)hipEventDestroy(ctx->ev_err);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
@@ -90,7 +97,7 @@ extern "C" nhp_status nhp_ctx_synchronize(nhp_ctx *ctx)
 {
     if (!ctx) return NHP_EINVAL;
     NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return NHP_OK;
+    return nhp_check_deferred(ctx);
 }
 
 extern "C" nhp_status nhp_ctx_timer_start(nhp_ctx *ctx)
@@ -133,8 +140,22 @@ nhp_status nhp_ctx_reserve_partials(nhp_ctx *ctx, size_t n)
     return NHP_OK;
 }
 
+nhp_status nhp_check_deferred(nhp_ctx *ctx)
+{
+    if (!ctx->err_pending) return NHP_OK;
+    ctx->err_pending = false;
+    NHP_HIP(ctx, hipEventSynchronize(ctx->ev_err));
+    if (*ctx->h_err) {
+        *ctx->h_err = 0;
+        nhp_set_error(ctx, "gibbs_step (an earlier sweep): weights of some event do not sum to a positive finite value");
+        return NHP_EDOMAIN;
+    }
+    return NHP_OK;
+}
+
 nhp_status nhp_download(nhp_ctx *ctx, void *dst, const void *d_src, size_t bytes)
 {
+    NHP_TRY(nhp_check_deferred(ctx));
     if (bytes == 0) { NHP_HIP(ctx, hipStreamSynchronize(ctx->stream)); return NHP_OK; }
     if (bytes > ctx->stage_cap) {
         NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));

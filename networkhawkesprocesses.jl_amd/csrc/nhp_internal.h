@@ -32,6 +32,12 @@ struct nhp_ctx {
     // Second lane for independent evaluations inside one call (nhp_cont_loglik_batch): its own stream, partial sums and
     // tickets.  A launch has fixed costs -- dispatch / completion, column staging, the reduction tail -- during which
     // the chip idles; with two lanes they run under the other lane's pair loops (profiles/README.md: two streams).
+    // Deferred sampler error (nhp_cont_gibbs_step): the sweep's "weights do not sum to a positive finite value" flag is
+    // copied to a pinned word behind the sweep and looked at when the NEXT sweep has been enqueued (or at any call that
+    // synchronises), so a chain keeps one step in flight instead of draining the GPU every step.
+    int *d_err = nullptr, *h_err = nullptr;
+    hipEvent_t ev_err = nullptr;
+    bool err_pending = false;
     void *h_stage = nullptr;            // pinned staging buffer for large downloads (gradients, parameters, moments)
     size_t stage_cap = 0;
     hipStream_t stream2 = nullptr;
@@ -210,6 +216,8 @@ nhp_status nhp_check_pair(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_co
 // Device -> caller memory through the context's pinned staging buffer: DMA at link speed into pinned memory, then one
 // host copy (a direct copy into pageable caller memory ran at ~1 GB/s here).  Synchronises the stream.
 nhp_status nhp_download(nhp_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+// report (once) the deferred sampler error of an earlier nhp_cont_gibbs_step, waiting for that sweep if need be
+nhp_status nhp_check_deferred(nhp_ctx *ctx);
 bool nhp_is_column_shard(const nhp_cont_dataset *ds);
 // entry points that need every column (samplers, intensity tables): refuse a column shard
 #define NHP_WHOLE_DATASET(ctx, ds, what)                                                                       \

@@ -276,3 +276,39 @@ def test_run_chains_summaries(nhp):
         assert np.allclose(out[k]["mean"], S.mean(axis=0), rtol=1e-12, atol=1e-14)
         assert np.allclose(out[k]["m2"], (S ** 2).mean(axis=0), rtol=1e-12, atol=1e-14)
     assert not np.array_equal(out[0]["mean"], out[1]["mean"])
+
+
+def test_sampler_error_is_reported_immediately_or_one_sweep_late(nhp):
+    """Weights that sum to zero (λ0 = 0, W = 0): resample_parents raises at once; nhp_cont_gibbs_step does not drain the
+    GPU inside a sweep, so its flag surfaces at the next sweep or at the next call that synchronises -- and only once."""
+    import ctypes as C
+    from nhp_amd import _lib, inference
+    ctx = nhp.Context(0)
+    rng = np.random.default_rng(3)
+    N, M, T = 3, 400, 50.0
+    data = (np.sort(rng.uniform(0, T, M)), rng.integers(1, N + 1, M).astype(np.int64), T)
+
+    def make(zero):
+        lam0 = np.zeros(N) if zero else np.ones(N)
+        W = np.zeros((N, N)) if zero else np.full((N, N), 0.1)
+        return nhp.ContinuousStandardHawkesProcess(nhp.HomogeneousProcess(lam0), nhp.ExponentialImpulseResponse(np.ones((N, N)), 1.0, 1.0, 1.0),
+                                                   nhp.DenseWeightModel(W))
+    bad, good = make(True), make(False)
+    with pytest.raises(nhp.DomainError, match="positive finite"):
+        nhp.resample_parents(bad, data, seed=1, step=0, ctx=ctx)
+    ds = nhp.device_dataset(bad, data, ctx)
+    mb, mg = bad.device_model(ctx), good.device_model(ctx)
+    pri = inference._priors(bad)
+    lib = _lib.lib()
+    assert lib.nhp_cont_gibbs_step(ctx.h, ds.h, mb.h, C.byref(pri), 1, 0) == _lib.OK          # enqueued, not yet judged
+    assert lib.nhp_cont_gibbs_step(ctx.h, ds.h, mg.h, C.byref(pri), 1, 1) == _lib.EDOMAIN     # the sweep before this one
+    assert b"earlier sweep" in lib.nhp_last_error(ctx.h)
+    assert lib.nhp_cont_gibbs_step(ctx.h, ds.h, mg.h, C.byref(pri), 1, 2) == _lib.OK          # reported once
+    ctx.synchronize()
+    mb = bad.device_model(ctx)                           # (the first sweep drew new parameters into the device model)
+    assert lib.nhp_cont_gibbs_step(ctx.h, ds.h, mb.h, C.byref(pri), 1, 3) == _lib.OK
+    with pytest.raises(nhp.DomainError, match="earlier sweep"):
+        ctx.synchronize()                                                                     # a synchronising call reports it too
+    ctx.synchronize()
+    res = nhp.mcmc_(make(False), data, nsteps=5, seed=2, ctx=ctx)                             # the context is usable afterwards
+    assert res.steps == 5 and np.all(np.isfinite(res.samples[-1]))
