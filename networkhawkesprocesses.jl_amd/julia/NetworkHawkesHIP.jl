@@ -151,4 +151,87 @@ function lgcp_loglikelihood(b::NHP.LogGaussianCoxProcess, ds::Dataset, Y::Matrix
     ll
 end
 
+# --- mle!(process, data; ...)  src/continuous.jl:144-198 --------------------------------------------------------
+# Same objective, box [1e-6, 10] and stopping rule; the objective and its ANALYTIC gradient come from one call on a
+# device-resident model whose parameters are overwritten in place with the optimiser's vector (the reference hands
+# Optim no gradient, so Fminbox(BFGS) spends 2P log-likelihood calls on finite differences per step).
+struct Priors   # nhp_gibbs_priors
+    α0::Float64; β0::Float64; κ::Float64; ν::Float64; a::Float64; b::Float64; μμ::Float64; κμ::Float64
+end
+
+function mle!(p::NHP.ContinuousStandardHawkesProcess, data; f_abstol=1e-6, guess=nothing, recursive=true, ctx=context(),
+              ds=Dataset(ctx, data, NHP.ndims(p), p.impulses.Δtmax), optimizer=nothing)
+    Optim = Base.require(Base.PkgId(Base.UUID("429524aa-4258-5aef-a3af-852621145aeb"), "Optim"))   # the package's own dependency
+    x0 = guess === nothing ? NHP._rand_init_(p) : guess
+    P = length(x0)
+    flags = Int32(recursive && p.impulses isa NHP.ExponentialImpulseResponse ? 1 : 0)
+    result = with_model(ctx, p) do m
+        function fg!(F, G, x)
+            check(ccall((:nhp_cont_model_set_params, libnhp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Int64),
+                        ctx.h, m, x, P), ctx.h)
+            ll, g = Ref{Float64}(0.0), Vector{Float64}(undef, P)
+            check(ccall((:nhp_cont_loglik_grad, libnhp), Int32,
+                        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ref{Float64}, Ptr{Float64}, Int64),
+                        ctx.h, ds.h, m, flags, ll, g, P), ctx.h)
+            G === nothing || (G .= .-g)
+            return -ll[]
+        end
+        inner = optimizer === nothing ? Optim.LBFGS() : optimizer
+        Optim.optimize(Optim.only_fg!(fg!), fill(1e-6, P), fill(10.0, P), clamp.(x0, 1e-6, 10.0), Optim.Fminbox(inner),
+                       Optim.Options(f_abstol=f_abstol))
+    end
+    NHP.params!(p, Optim.minimizer(result))            # "all inference methods overwrite model parameters"
+    result
+end
+
+# --- mcmc!(process, data; nsteps)  src/inference.jl:49-70 -------------------------------------------------------
+# A sweep -- parents, sufficient statistics, conjugate draws, (network) adjacency -- stays on the device; what comes
+# back per step is what the caller asks for: nothing (posterior moments accumulate on the device), or params(process).
+priors(p) = p.impulses isa NHP.ExponentialImpulseResponse ?
+    Priors(p.baseline.α0, p.baseline.β0, p.weights.κ, p.weights.ν, p.impulses.α, p.impulses.β, 0.0, 1.0) :
+    Priors(p.baseline.α0, p.baseline.β0, p.weights.κ, p.weights.ν, p.impulses.α0, p.impulses.β0, p.impulses.μμ, p.impulses.κμ)
+
+function mcmc!(p::NHP.ContinuousHawkesProcess, data; nsteps=1000, seed::UInt64=UInt64(0), keep_samples=false, ctx=context(),
+               ds=Dataset(ctx, data, NHP.ndims(p), p.impulses.Δtmax))
+    N = NHP.ndims(p)
+    network = p isa NHP.ContinuousNetworkHawkesProcess
+    nimp = N * N * (p.impulses isa NHP.ExponentialImpulseResponse ? 1 : 2)
+    L = N + nimp + N * N
+    samples = Vector{Vector{Float64}}()
+    pr = Ref(priors(p))
+    sum1, sum2, count = zeros(L + (network ? N * N : 0)), zeros(L + (network ? N * N : 0)), Ref{Int64}(0)
+    with_model(ctx, p) do m
+        check(ccall((:nhp_cont_model_moments_reset, libnhp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.h, m), ctx.h)
+        for step in 0:nsteps-1
+            check(ccall((:nhp_cont_gibbs_step, libnhp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Priors}, UInt64, UInt64),
+                        ctx.h, ds.h, m, pr, seed, UInt64(step)), ctx.h)
+            if network
+                links = Ref{Float64}(0.0)
+                last = keep_samples || step == nsteps - 1
+                Aout = last ? Matrix{Float64}(undef, N, N) : nothing
+                GC.@preserve Aout check(ccall((:nhp_cont_resample_adjacency, libnhp), Int32,
+                            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Float64, Ptr{Float64}, UInt64, UInt64, Ptr{Float64}, Ref{Float64}),
+                            ctx.h, ds.h, m, C_NULL, p.network.ρ, C_NULL, seed, UInt64(step),
+                            last ? pointer(Aout) : Ptr{Float64}(C_NULL), links), ctx.h)
+                last && (p.adjacency_matrix = Aout)
+                # resample_connection_probability!: ρ ~ Beta(α + links, β + N² - links)  src/networks.jl:70-76
+                p.network.ρ = rand(NHP.Beta(p.network.α + links[], p.network.β + N * N - links[]))
+            end
+            check(ccall((:nhp_cont_model_moments_accumulate, libnhp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.h, m), ctx.h)
+            if keep_samples || step == nsteps - 1
+                x = Vector{Float64}(undef, L)
+                check(ccall((:nhp_cont_model_get_params, libnhp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Int64), ctx.h, m, x, L), ctx.h)
+                keep_samples && push!(samples, x)
+                if step == nsteps - 1                                # in place, component by component: [λ0; θ | μ; τ; W]
+                    NHP.params!(p.baseline, x[1:N]); NHP.params!(p.impulses, x[N+1:N+nimp]); NHP.params!(p.weights, x[N+nimp+1:end])
+                end
+            end
+        end
+        check(ccall((:nhp_cont_model_moments_fetch, libnhp), Int32,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{Int64}),
+                    ctx.h, m, sum1, sum2, length(sum1), count), ctx.h)
+    end
+    (samples=samples, mean=sum1 ./ max(count[], 1), m2=sum2 ./ max(count[], 1), n=count[])
+end
+
 end # module
