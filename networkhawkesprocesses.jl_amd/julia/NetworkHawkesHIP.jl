@@ -8,6 +8,7 @@
 module NetworkHawkesHIP
 
 using NetworkHawkesProcesses
+import Optim                      # already a dependency of NetworkHawkesProcesses (Project.toml)
 const NHP = NetworkHawkesProcesses
 
 const libnhp = get(ENV, "NHP_LIB", joinpath(@__DIR__, "..", "libnhp.so"))
@@ -161,7 +162,6 @@ end
 
 function mle!(p::NHP.ContinuousStandardHawkesProcess, data; f_abstol=1e-6, guess=nothing, recursive=true, ctx=context(),
               ds=Dataset(ctx, data, NHP.ndims(p), p.impulses.Δtmax), optimizer=nothing)
-    Optim = Base.require(Base.PkgId(Base.UUID("429524aa-4258-5aef-a3af-852621145aeb"), "Optim"))   # the package's own dependency
     x0 = guess === nothing ? NHP._rand_init_(p) : guess
     P = length(x0)
     flags = Int32(recursive && p.impulses isa NHP.ExponentialImpulseResponse ? 1 : 0)
