@@ -48,12 +48,20 @@ struct gemm_args {
 };
 
 // C[m,n] = Σ_k Aop[m,k]·B[k + n·ldb];  A_MCONTIG: Aop[m,k] = A[m + k·lda], else A[k + m·lda].
-template <bool A_MCONTIG, int EPI>
+// TBM = rows of the output tile: 128, or 160 for the m-contiguous GEMM-1 when that fills the last round of workgroups
+// better (gemm1_tile_m): 5 instead of 4 MFMA row-fragments per wave, everything else alike.
+template <bool A_MCONTIG, int EPI, int TBM = BM>
 __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 waves/SIMD: <= 256 VGPR+AGPR
 {
+    static_assert(TBM % 32 == 0 && (A_MCONTIG || TBM == BM), "the k-contiguous A staging covers 128 rows");
+    static_assert(TBM == BM || BK == 16, "wide tiles are staged one 16-row k-slab at a time");
+    constexpr int MI = TBM / 32;                                   // MFMA row fragments per wave (2 x 2 waves)
+    constexpr int MS = TBM / 16;                                   // 16-row m-slots of the staged A tile
+    constexpr int EA = A_MCONTIG ? MS * (BK / 16) : EPT;            // staged A elements per thread
+    constexpr int A_LD = TBM + 16;                                 // m-contiguous image: row stride ≡ 128 B (mod 256)
     extern __shared__ __align__(16) double gsm[];
-    double *As = gsm;                                              // [A_MCONTIG ? BK * A_MC_LD : BM * KC_LD]
-    double *Bs = As + (A_MCONTIG ? BK * A_MC_LD : BM * KC_LD);     // [BN * KC_LD]
+    double *As = gsm;                                              // [A_MCONTIG ? BK * A_LD : BM * KC_LD]
+    double *Bs = As + (A_MCONTIG ? BK * A_LD : BM * KC_LD);        // [BN * KC_LD]
     double *red = Bs + BN * KC_LD;                                 // [NHP_WAVES]
     double(*wcol)[64] = reinterpret_cast<double(*)[64]>(red + NHP_WAVES);   // [NHP_WAVES][64]
 
@@ -67,13 +75,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
     const unsigned xq = nbk / 8, xr = nbk % 8, xcd = lin % 8, pos = lin / 8;
     const unsigned logical = xcd * xq + (xcd < xr ? xcd : xr) + pos;
     const int bx = (int)(logical % gridDim.x), by = (int)(logical / gridDim.x);
-    const int m0 = by * BM, n0 = bx * BN;                    // n-tiles fastest: tiles sharing an A panel are adjacent
+    const int m0 = by * TBM, n0 = bx * BN;                    // n-tiles fastest: tiles sharing an A panel are adjacent
     const int kbeg = blockIdx.z * g.k_chunk;
     const int kend = min(g.K, kbeg + g.k_chunk);
 
-    v4d acc[4][4];
+    v4d acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
@@ -83,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
     const int a_k = A_MCONTIG ? tid >> 4 : (tid & 1) * EPT;        // m-contig: k row;  k-contig: k offset
     const int a_m = A_MCONTIG ? (tid & 15) : tid >> 1;             // m-contig: m offset; k-contig: m row
     const int b_k = (tid & 1) * EPT, b_n = tid >> 1;
-    double ra[EPT], rb[EPT];
+    double ra[EA], rb[EPT];
 
     // Per-thread operand pointers advance by one tile per iteration; the 8 elements of a thread sit
     // at compile-time offsets from them, so the loop carries no 64-bit index arithmetic (with one
@@ -94,17 +102,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
     const size_t a_step = A_MCONTIG ? (size_t)BK * g.lda : (size_t)BK;
     unsigned a_ok = 0;                       // bit e: row of element e is inside the matrix
 #pragma unroll
-    for (int e = 0; e < 8; ++e) a_ok |= ((A_MCONTIG ? m0 + a_m + 16 * e : m0 + a_m) < g.M ? 1u : 0u) << e;   // bit e: m-slot e
+    for (int e = 0; e < (A_MCONTIG ? MS : 8); ++e) a_ok |= ((A_MCONTIG ? m0 + a_m + 16 * e : m0 + a_m) < g.M ? 1u : 0u) << e;   // bit e: m-slot e
     const bool b_ok = n0 + b_n < g.N;
 
     auto load_tiles = [&](int k0) {
         const bool full = k0 + BK <= kend;   // only the last tile of a ragged K needs per-element checks
 #pragma unroll
+        for (int e = 0; e < EA; ++e) {
+            // m-contig: element e = (m-slot e % MS, k-row a_k + 16 (e / MS)); k-contig: k offset a_k + e
+            const bool ka = full || (A_MCONTIG ? k0 + a_k + 16 * (e / MS) : k0 + a_k + e) < kend;
+            const bool ma = A_MCONTIG ? ((a_ok >> (e % MS)) & 1u) : (a_ok & 1u);
+            ra[e] = ma && ka ? (A_MCONTIG ? pa[16 * (e % MS) + (size_t)(16 * (e / MS)) * g.lda] : pa[e]) : 0.0;
+        }
+#pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            // m-contig: element e = (m-slot e % 8, k-row a_k + 16 (e / 8)); k-contig: k offset a_k + e
-            const bool ka = full || (A_MCONTIG ? k0 + a_k + 16 * (e >> 3) : k0 + a_k + e) < kend;
-            const bool ma = A_MCONTIG ? ((a_ok >> (e & 7)) & 1u) : (a_ok & 1u);
-            ra[e] = ma && ka ? (A_MCONTIG ? pa[16 * (e & 7) + (size_t)(16 * (e >> 3)) * g.lda] : pa[e]) : 0.0;
             const bool kb = full || k0 + b_k + e < kend;
             rb[e] = b_ok && kb ? pb[e] : 0.0;
         }
@@ -113,11 +124,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            if (A_MCONTIG) As[(a_k + 16 * (e >> 3)) * A_MC_LD + a_m + 16 * (e & 7)] = ra[e];
+        for (int e = 0; e < EA; ++e) {
+            if (A_MCONTIG) As[(a_k + 16 * (e / MS)) * A_LD + a_m + 16 * (e % MS)] = ra[e];
             else As[a_m * KC_LD + a_k + e] = ra[e];
-            Bs[b_n * KC_LD + b_k + e] = rb[e];
         }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) Bs[b_n * KC_LD + b_k + e] = rb[e];
     };
 
     load_tiles(kbeg);
@@ -128,23 +140,26 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
         if (k0 + BK < kend) load_tiles(k0 + BK);   // prefetch under the MFMAs
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
-            double a[4], b[4];
+            double a[MI], b[4];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = wm * (TBM / 2) + i * 16 + r16;
+                a[i] = A_MCONTIG ? As[(ks * 4 + kk) * A_LD + m] : As[m * KC_LD + ks * 4 + kk];
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int m = wm * 64 + i * 16 + r16;
-                a[i] = A_MCONTIG ? As[(ks * 4 + kk) * A_MC_LD + m] : As[m * KC_LD + ks * 4 + kk];
                 const int n = wn * 64 + i * 16 + r16;
                 b[i] = Bs[n * KC_LD + ks * 4 + kk];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
 
-    // ---- epilogue.  acc[i][j][r] is C[row, col], row = wm*64 + i*16 + kk + 4r, col = wn*64 + j*16 + r16
+    // ---- epilogue.  acc[i][j][r] is C[row, col], row = wm*(TBM/2) + i*16 + kk + 4r, col = wn*64 + j*16 + r16
     double t_sum = 0.0, t_sum2 = 0.0;
     double colp[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -152,10 +167,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
         const int col = n0 + wn * 64 + j * 16 + r16;
         const double base_c = (EPI != EPI_SLAB && col < g.N && !g.baseT) ? g.base[col] : 0.0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 64 + i * 16 + kk + 4 * r;
+                const int row = m0 + wm * (TBM / 2) + i * 16 + kk + 4 * r;
                 if (row < g.M && col < g.N) {
                     const size_t o = (size_t)row + (size_t)col * g.M;
                     const double v = acc[i][j][r];
@@ -547,9 +562,29 @@ extern "C" nhp_status nhp_disc_convolve(nhp_ctx *ctx, nhp_disc_dataset *ds, cons
     return NHP_OK;
 }
 
-template <bool AMC, int EPI>
-static void launch_gemm(const gemm_args &g, int splits, hipStream_t st)
+// Rows per output tile of the m-contiguous GEMM-1 (M = T bins): the workgroups of a launch run in rounds of 2 per CU,
+// and the last round is rarely full -- 3128 tiles of 128 rows on 512 slots are 6.1 rounds, i.e. 7; the same matrix in
+// 160-row tiles is 2500 tiles = 4.9 rounds, i.e. 5 x 1.25: 11 % less.  Pick the cheaper of the two (NHP_GEMM_BM forces).
+static int gemm1_tile_m(int64_t M, int N, int cu_count)
 {
+    static const int forced = getenv("NHP_GEMM_BM") ? atoi(getenv("NHP_GEMM_BM")) : 0;
+    if (forced == 128 || forced == 160) return forced;
+    const int64_t slots = 2 * (int64_t)(cu_count > 0 ? cu_count : 256), nt = (N + BN - 1) / BN;
+    auto cost = [&](int bm) { const int64_t tiles = ((M + bm - 1) / bm) * nt; return ((tiles + slots - 1) / slots) * bm; };
+    return cost(160) < cost(128) ? 160 : 128;
+}
+
+template <bool AMC, int EPI>
+static void launch_gemm(const gemm_args &g, int splits, hipStream_t st, int bm = BM)
+{
+    if (AMC && bm == 160) {
+        dim3 grid((unsigned)((g.N + BN - 1) / BN), (unsigned)((g.M + 159) / 160), (unsigned)splits);
+        const size_t lds = 8 * (BK * (160 + 16) + BN * KC_LD + NHP_WAVES + NHP_WAVES * 64);
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)k_gemm_f64<AMC, EPI, (AMC ? 160 : BM)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_gemm_f64<AMC, EPI, (AMC ? 160 : BM)>), grid, dim3(256), lds, st, g);
+        return;
+    }
     dim3 grid((unsigned)((g.N + BN - 1) / BN), (unsigned)((g.M + BM - 1) / BM), (unsigned)splits);
     const size_t lds = 8 * ((AMC ? BK * A_MC_LD : BM * KC_LD) + BN * KC_LD + NHP_WAVES + NHP_WAVES * 64);
     if (lds > 64 * 1024)
@@ -597,7 +632,7 @@ nhp_status nhp_disc_launch_intensity(nhp_ctx *ctx, const nhp_disc_dataset *ds, c
     g.A = ds->d_conv; g.lda = (size_t)ds->T; g.B = E; g.ldb = (size_t)ds->N * ds->B;
     g.M = (int)ds->T; g.N = ds->N; g.K = ds->N * ds->B; g.k_chunk = g.K;
     g.base = base; g.baseT = per_bin_baseline ? ds->d_baseT : nullptr; g.out = dlam;
-    launch_gemm<true, EPI_INTENSITY>(g, 1, ctx->stream);
+    launch_gemm<true, EPI_INTENSITY>(g, 1, ctx->stream, gemm1_tile_m(g.M, g.N, ctx->cu_count));
     NHP_HIP(ctx, hipGetLastError());
     return NHP_OK;
 }
@@ -615,7 +650,7 @@ extern "C" nhp_status nhp_disc_intensity(nhp_ctx *ctx, const nhp_disc_dataset *d
     g.A = ds->d_conv; g.lda = (size_t)ds->T; g.B = E; g.ldb = (size_t)ds->N * ds->B;
     g.M = (int)ds->T; g.N = ds->N; g.K = ds->N * ds->B; g.k_chunk = g.K;
     g.base = base; g.baseT = lambda0 ? nullptr : ds->d_baseT; g.out = dlam;
-    launch_gemm<true, EPI_INTENSITY>(g, 1, ctx->stream);
+    launch_gemm<true, EPI_INTENSITY>(g, 1, ctx->stream, gemm1_tile_m(g.M, g.N, ctx->cu_count));
     NHP_HIP(ctx, hipGetLastError());
     NHP_HIP(ctx, hipMemcpyAsync(lam, dlam, 8 * TN, hipMemcpyDeviceToHost, ctx->stream));
     NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -633,10 +668,11 @@ extern "C" nhp_status nhp_disc_loglik(nhp_ctx *ctx, const nhp_disc_dataset *ds, 
     g.A = ds->d_conv; g.lda = (size_t)ds->T; g.B = E; g.ldb = (size_t)ds->N * ds->B;
     g.M = (int)ds->T; g.N = ds->N; g.K = ds->N * ds->B; g.k_chunk = g.K;
     g.base = base; g.baseT = lambda0 ? nullptr : ds->d_baseT; g.dataT = ds->d_dataT;
-    const int blocks = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    const int bm = gemm1_tile_m(g.M, g.N, ctx->cu_count);
+    const int blocks = ((g.M + bm - 1) / bm) * ((g.N + BN - 1) / BN);
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)blocks));
     g.partials = ctx->d_partials;
-    launch_gemm<true, EPI_LOGLIK>(g, 1, ctx->stream);
+    launch_gemm<true, EPI_LOGLIK>(g, 1, ctx->stream, bm);
     NHP_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_sum_pairs, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, blocks, ds->lgamma_sum, ctx->d_results);
     NHP_HIP(ctx, hipGetLastError());
@@ -747,7 +783,8 @@ extern "C" nhp_status nhp_disc_loglik_grad(nhp_ctx *ctx, const nhp_disc_dataset 
     const size_t nbase = lambda0 ? N : G * N;                    // params(baseline): λ or vec(λ) (G x N)
     if ((size_t)grad_len != nbase + NN * B) { nhp_set_error(ctx, "Parameter vector length does not match model parameter length."); return NHP_ESHAPE; }
     if (!ds->d_convsum) { nhp_set_error(ctx, "convolve(process, data) must run before the gradient"); return NHP_EINVAL; }
-    const int row_blocks = (int)((T + BM - 1) / BM);
+    const int bm = gemm1_tile_m((int64_t)T, (int)N, ctx->cu_count);
+    const int row_blocks = (int)((T + bm - 1) / bm);
     const int tiles2 = (int)(((K + BM - 1) / BM) * ((N + BN - 1) / BN));
     int splits = (2 * ctx->cu_count + tiles2 - 1) / tiles2;
     splits = std::max(1, std::min(splits, (int)((T + 4 * BK - 1) / (4 * BK))));
@@ -765,11 +802,11 @@ extern "C" nhp_status nhp_disc_loglik_grad(nhp_ctx *ctx, const nhp_disc_dataset 
     gemm_args g{};
     g.A = ds->d_conv; g.lda = T; g.B = E; g.ldb = K; g.M = (int)T; g.N = (int)N; g.K = (int)K; g.k_chunk = (int)K;
     g.base = base; g.baseT = lambda0 ? nullptr : ds->d_baseT; g.dataT = ds->d_dataT;
-    const int blocks = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    const int blocks = ((g.M + bm - 1) / bm) * ((g.N + BN - 1) / BN);
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)blocks));
     g.partials2 = ctx->d_partials;
     g.out = dR; g.partials = dcolp;
-    launch_gemm<true, EPI_GRAD>(g, 1, st);
+    launch_gemm<true, EPI_GRAD>(g, 1, st, bm);
     hipLaunchKernelGGL(k_sum_pairs, dim3(1), dim3(256), 0, st, ctx->d_partials, blocks, ds->lgamma_sum, ctx->d_results);
     // then Gᵀ·R in T-slabs
     gemm_args g2{};
@@ -809,7 +846,8 @@ extern "C" nhp_status nhp_disc_vb_run(nhp_ctx *ctx, const nhp_disc_dataset *ds, 
     if (!ds->d_conv) { nhp_set_error(ctx, "convolve(process, data) must run before update!"); return NHP_EINVAL; }
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t N = (size_t)ds->N, NN = N * N, B = (size_t)ds->B, K = N * B, T = (size_t)ds->T;
-    const int row_blocks = (int)((T + BM - 1) / BM);
+    const int bm = gemm1_tile_m((int64_t)T, (int)N, ctx->cu_count);
+    const int row_blocks = (int)((T + bm - 1) / bm);
     // split the T-long reduction of GEMM-2 so that the grid fills the chip
     const int tiles2 = (int)(((K + BM - 1) / BM) * ((N + BN - 1) / BN));
     int splits = (2 * ctx->cu_count + tiles2 - 1) / tiles2;
@@ -843,7 +881,7 @@ extern "C" nhp_status nhp_disc_vb_run(nhp_ctx *ctx, const nhp_disc_dataset *ds, 
         gemm_args g1{};
         g1.A = ds->d_conv; g1.lda = T; g1.B = dE; g1.ldb = K; g1.M = (int)T; g1.N = (int)N; g1.K = (int)K; g1.k_chunk = (int)K;
         g1.base = de0; g1.dataT = ds->d_dataT; g1.out = dR; g1.partials = dcolp;
-        launch_gemm<true, EPI_VB_Z>(g1, 1, st);
+        launch_gemm<true, EPI_VB_Z>(g1, 1, st, bm);
         NHP_HIP(ctx, hipGetLastError());
         // GEMM-2: slabs_z = Gᵀ·R over T-chunk z
         gemm_args g2{};
