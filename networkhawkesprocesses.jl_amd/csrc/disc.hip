@@ -567,7 +567,8 @@ extern "C" nhp_status nhp_disc_convolve(nhp_ctx *ctx, nhp_disc_dataset *ds, cons
 // 160-row tiles is 2500 tiles = 4.9 rounds, i.e. 5 x 1.25: 11 % less.  Pick the cheaper of the two (NHP_GEMM_BM forces).
 static int gemm1_tile_m(int64_t M, int N, int cu_count)
 {
-    static const int forced = getenv("NHP_GEMM_BM") ? atoi(getenv("NHP_GEMM_BM")) : 0;
+    const char *env = getenv("NHP_GEMM_BM");                     // read per call: tests force both tile heights
+    const int forced = env ? atoi(env) : 0;
     if (forced == 128 || forced == 160) return forced;
     const int64_t slots = 2 * (int64_t)(cu_count > 0 ? cu_count : 256), nt = (N + BN - 1) / BN;
     auto cost = [&](int bm) { const int64_t tiles = ((M + bm - 1) / bm) * nt; return ((tiles + slots - 1) / slots) * bm; };

@@ -160,3 +160,26 @@ def test_discrete_mle_finds_the_rates_of_independent_poisson_data(nhp):
     assert np.allclose(proc.impulses.θ.sum(axis=2), 1.0)
     with pytest.raises(NotImplementedError):
         nhp.mle_(proc, data, regularize=True)
+
+
+@pytest.mark.parametrize("N,T,B,L", [(5, 300, 3, 7), (130, 997, 2, 3)])
+def test_both_gemm_tile_heights_agree(nhp, orc, N, T, B, L, monkeypatch):
+    """GEMM-1 picks 128- or 160-row output tiles by how they fill the last round of workgroups (gemm1_tile_m); both give
+    the oracle's intensity / log-likelihood, and the same gradient and VB step (ragged T: partial tiles in both)."""
+    proc, data, lam0, W, th, _ = make(nhp, N, T, B, L, seed=N + 1)
+    want = orc.disc_intensity(orc.disc_convolve(data, proc.impulses.basis()), lam0, W, th, 1.0)
+    got = {}
+    for bm in ("128", "160"):
+        monkeypatch.setenv("NHP_GEMM_BM", bm)
+        ds = nhp.convolve(proc, data)
+        lam = nhp.intensity(proc, ds)
+        assert np.max(np.abs(lam - want) / want) < 1e-12
+        ll, g = nhp.loglikelihood_gradient(proc, data, convolved=ds)
+        import copy
+        p2 = copy.deepcopy(proc)
+        nhp.update_(p2, data, ds)
+        got[bm] = (nhp.loglikelihood(proc, data, convolved=ds), ll, g, p2.weights.κv.copy(), p2.impulses.γv.copy(), p2.baseline.αv.copy())
+    a, b = got["128"], got["160"]
+    assert abs(a[0] - b[0]) < 1e-12 * abs(a[0]) and abs(a[1] - b[1]) < 1e-12 * abs(a[1])
+    for x, y in zip(a[2:], b[2:]):
+        assert np.allclose(x, y, rtol=1e-12, atol=1e-13)
