@@ -164,16 +164,31 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_eval(nhp_cont_args a, const d
     for (int k = tid; k < nchild; k += NHP_BLOCK) lam[k] = adj_baseline(a, c, a.child[kb + k].t);
     __syncthreads();
     const int64_t e0 = pair_off[c], e1 = pair_off[c + 1];
-    for (int64_t e = e0 + tid; e < e1; e += NHP_BLOCK) {
-        const int p = ent_p[e];
-        const double dt = ent_dt[e];
-        const double2 q = col[p];
-        double x;
-        if (IMP == NHP_IMPULSE_EXPONENTIAL) x = q.y * nhp_pdf_exponential(q.x, dt);
-        else x = colw[p] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
-        ent_x[e] = x;
-        const double av = acol[p];
-        if (av != 0.0) atomicAdd(&lam[ent_k[e]], av * x);
+    // four entries per thread and trip: their loads are in flight together and the four pdf evaluations are independent
+    // instruction streams (the one-entry loop exposed one global-load latency per entry)
+    constexpr int EU = 4;
+    for (int64_t eb = e0 + tid; eb < e1; eb += EU * NHP_BLOCK) {
+        int p[EU], k[EU];
+        double dt[EU], x[EU];
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            const int64_t e = eb + u * NHP_BLOCK < e1 ? eb + u * NHP_BLOCK : eb;       // clamped: value unused
+            p[u] = ent_p[e]; dt[u] = ent_dt[e]; k[u] = ent_k[e];
+        }
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            const double2 q = col[p[u]];
+            if (IMP == NHP_IMPULSE_EXPONENTIAL) x[u] = q.y * nhp_pdf_exponential(q.x, dt[u]);
+            else x[u] = colw[p[u]] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            if (eb + u * NHP_BLOCK < e1) {
+                ent_x[eb + u * NHP_BLOCK] = x[u];
+                const double av = acol[p[u]];
+                if (av != 0.0) atomicAdd(&lam[k[u]], av * x[u]);
+            }
+        }
     }
     __syncthreads();
     for (int k = tid; k < nchild; k += NHP_BLOCK) lam_g[kb + k] = lam[k];
