@@ -199,15 +199,21 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_grad_recursive(nhp_cont_args a, d
     double prev_t = 0.0, logsum = 0.0, gsum = 0.0;
     for (int k = kb; k < ke; ++k) {
         const nhp_child ch = a.child[k];
-        for (int j = prev_idx + tid; j < ch.idx; j += NHP_BLOCK) {
-            const double tj = a.times[j];
-            if (tj > 0.0) {
-                const int p = a.nodes[j];
-                const double d = ch.t - tj;
-                const double e = nhp_exp_neg(-(th[p] * d));
-                atomicAdd(&nS[p], e);
-                atomicAdd(&nR[p], d * e);
-            }
+        // four packed event records per thread in flight, exponentials evaluated unconditionally, atomics predicated
+        // (the scheme of k_recursive's fold)
+        for (int j0 = prev_idx + tid; j0 < ch.idx; j0 += 4 * NHP_BLOCK) {
+            nhp_event ev[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ev[u] = a.ev[j0 + u * NHP_BLOCK < ch.idx ? j0 + u * NHP_BLOCK : j0];
+            double d[4], e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { d[u] = ch.t - ev[u].t; e[u] = nhp_exp_neg(-(th[ev[u].node] * d[u])); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j0 + u * NHP_BLOCK < ch.idx && ev[u].t > 0.0) {
+                    atomicAdd(&nS[ev[u].node], e[u]);
+                    atomicAdd(&nR[ev[u].node], d[u] * e[u]);
+                }
         }
         __syncthreads();
         const double gap = ch.t - prev_t;
