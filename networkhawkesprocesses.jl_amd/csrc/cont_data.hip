@@ -90,6 +90,18 @@ extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double
         pairs += i - f;
     }
     ds->pairs = pairs;
+    if (M > 1 && events[M - 1] > events[0]) {
+        const double span = events[M - 1] - events[0];
+        for (double L = span / (double)M; L < span; L *= 2.0) {
+            int64_t best = 1, lo = 0;
+            for (int64_t i = 0; i < M; ++i) {
+                while (events[i] - events[lo] > L) ++lo;
+                best = std::max<int64_t>(best, i - lo + 1);
+            }
+            ds->h_slab_len.push_back(L);
+            ds->h_slab_max.push_back(best);
+        }
+    }
     for (int64_t i = 0; i < M && events[i] == 0.0; ++i) ds->n_zero_time = i + 1;
     for (int64_t i = 0; i < M; ++i) ds->max_window = std::max<int32_t>(ds->max_window, (int32_t)(i - first[i]));
     ds->h_pair_off.assign((size_t)N + 1, 0);

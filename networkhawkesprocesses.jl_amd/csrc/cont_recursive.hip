@@ -269,7 +269,15 @@ static nhp_status rec_cut_for(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
     }
     double c = 0.0;
     if (tmin > 0.0 && lmin > 0.0 && wmax >= 0.0 && tmin < __builtin_inf() && lmin < __builtin_inf() && wmax < __builtin_inf()) {
-        const double mass = (double)(ds->M > 0 ? ds->M : 1) * wmax;
+        // events older than `cut` before a child: at most M of them, or -- counted in slabs of length L going back from
+        // the cut, at most slab_max(L) events each, every one at least cut + s·L away -- slab_max(L) / (1 - e^{-θmin·L})
+        // "events at distance cut"; the smaller count bounds the dropped tail
+        double count = (double)(ds->M > 0 ? ds->M : 1);
+        for (size_t q = 0; q < ds->h_slab_len.size(); ++q) {
+            const double geo = 1.0 - exp(-tmin * ds->h_slab_len[q]);
+            if (geo > 0.0) count = std::min(count, (double)ds->h_slab_max[q] / geo);
+        }
+        const double mass = count * wmax;
         c = mass > 0.0 ? (log(mass / lmin) + 60.0 * 0.6931471805599453) / tmin : 1e-300;
         if (!(c > 0.0)) c = 1e-300;                          // no excitation at all: an empty window is exact
     }

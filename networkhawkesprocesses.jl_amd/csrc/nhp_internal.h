@@ -110,6 +110,11 @@ struct nhp_cont_dataset {
     // host copies kept for host-side helpers
     std::vector<int32_t> h_boff;
     std::vector<double> h_cnt;
+    // crowding of the data: h_slab_max[k] = most events inside any closed time window of length h_slab_len[k]
+    // (lengths double from the mean gap up to the duration).  Tightens the truncated-window bound of the recursive
+    // formulation (cont_recursive.hip): events older than `cut` arrive at most h_slab_max per slab.
+    std::vector<double> h_slab_len;
+    std::vector<int64_t> h_slab_max;
     std::vector<int64_t> h_pair_off;    // [N+1] prefix of window pairs per child node (adjacency sweep scratch)
 };
 
