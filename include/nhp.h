@@ -42,7 +42,8 @@ typedef enum {
     NHP_ESHAPE = 3,   /* array length does not match the model */
     NHP_ENOMEM = 4,
     NHP_EHIP = 5,     /* HIP runtime error (no device, launch failure, ...) */
-    NHP_ENOTIMPL = 6
+    NHP_ENOTIMPL = 6,
+    NHP_ERCCL = 7     /* RCCL unavailable (librccl.so.1 not loadable) or a collective failed */
 } nhp_status;
 
 enum { NHP_BASELINE_HOMOGENEOUS = 0, NHP_BASELINE_LGCP = 1 };
@@ -62,6 +63,7 @@ typedef struct nhp_ctx nhp_ctx;
 typedef struct nhp_cont_dataset nhp_cont_dataset;
 typedef struct nhp_cont_model nhp_cont_model;
 typedef struct nhp_disc_dataset nhp_disc_dataset;
+typedef struct nhp_comm nhp_comm;      /* RCCL communicator bound to a ctx (multi-GPU section at the end) */
 
 /* The lowered form of (Baseline, ImpulseResponse, Weights, adjacency_matrix):
  *   HomogeneousProcess.λ                      src/baselines.jl:27-39
@@ -106,6 +108,16 @@ nhp_status nhp_ctx_synchronize(nhp_ctx *ctx);
 nhp_status nhp_ctx_timer_start(nhp_ctx *ctx);
 nhp_status nhp_ctx_timer_stop(nhp_ctx *ctx, double *elapsed_ms);
 int32_t nhp_abi_version(void);
+/* sizeof / offsetof of every struct that crosses this boundary, so a binding (ctypes Structure, Julia `struct`) can
+ * assert its layout against the library it loaded instead of trusting a header it cannot include.  Writes up to `cap`
+ * int32 entries into `out` and returns the number of entries the library has (NHP_ABI_LAYOUT_LEN):
+ *   [0] sizeof(nhp_cont_model_desc), then offsetof n_nodes, baseline_kind, lambda0, grid_x, grid_n, impulse_kind, theta, mu,
+ *       tau, dt_max, W, A                                                            (entries 1..12)
+ *   [13] sizeof(nhp_gibbs_priors), then offsetof alpha0, beta0, kappa, nu, a, b, mu_mu, kappa_mu   (14..21)
+ *   [22] sizeof(nhp_cont_stats), then offsetof cnt0, Mn, Mnm, Xnm, Vnm                             (23..27)
+ *   [28] NHP_MAX_SLOTS, [29] NHP_COMM_ID_BYTES */
+#define NHP_ABI_LAYOUT_LEN 30
+int32_t nhp_abi_layout(int32_t *out, int32_t cap);
 
 /* ---- continuous data: (events, nodes, duration)  src/continuous.jl:14,29-36 ----------- */
 /* Validates (sorted, >= 0, nodes in 1..N, duration >= 0), runs the look-back pre-pass for
@@ -219,6 +231,8 @@ nhp_status nhp_cont_lgcp_loglik(nhp_ctx *ctx, const nhp_cont_dataset *ds, const 
                                 const double *grid_x, int32_t grid_n, const double *lam, double *ll);
 /* params(process) of the device-resident model: [λ0; θ | μ; τ; W]  src/continuous.jl:116-119 */
 nhp_status nhp_cont_model_get_params(nhp_ctx *ctx, const nhp_cont_model *model, double *x, int64_t len);
+/* process.adjacency_matrix of the device-resident model (after nhp_cont_network_step / nhp_cont_mcmc_run): [N*N] 0.0/1.0 */
+nhp_status nhp_cont_model_get_adjacency(nhp_ctx *ctx, const nhp_cont_model *model, double *A, int64_t len);
 /* Sample store on the device.  mcmc! appends params(process) after every sweep (src/inference.jl:61):
  * 4N²+N doubles per step, 33.5 MB at N = 1024 -- more PCIe time than the sweep itself.  These keep Σx and Σx² of the
  * device-resident parameters instead: _reset zeroes them, _accumulate adds the current [λ0; θ | μ; τ; W; vec(A) if the
@@ -317,6 +331,71 @@ nhp_status nhp_disc_lgcp_loglik(nhp_ctx *ctx, const nhp_disc_dataset *ds, const 
 nhp_status nhp_disc_vb_run(nhp_ctx *ctx, const nhp_disc_dataset *ds, double dt,
                            double alpha0, double beta0, double kappa, double nu, double gamma, int32_t n_steps,
                            double *alpha_v, double *beta_v, double *kappa_v, double *nu_v, double *gamma_v);
+
+/* ---- several GPUs: RCCL over xGMI   ------------------------------------------------------------
+ * One process (or host thread) per GPU, one nhp_ctx each.  The reference has no distributed code (README.md:42 lists
+ * "multiple-trial inference" as future work; mcmc! has no cross-chain term, src/inference.jl:49-70), so these entry
+ * points replace nothing: they are the exchange steps of the two ways the path shards --
+ *   independent units (chains, restarts): no data-path collective, one gather of per-chain summaries at the end;
+ *   one evaluation / one chain over all ranks by child-node column: one all-reduce per evaluation / per step --
+ * and they hand RCCL DEVICE pointers: results are reduced where the kernels left them, on the ctx stream, and cross
+ * PCIe once, reduced.  librccl.so.1 is opened on first use (dlopen): a single-GPU host needs no RCCL installed.
+ * Rendezvous: rank 0 calls nhp_comm_unique_id and gives the 128 bytes to the other ranks through whatever channel
+ * the host has (Julia: Distributed / a file / MPI.bcast; Python: torch.distributed or a TCP store); every rank then
+ * calls nhp_comm_create -- collectively, it blocks until all `world` ranks have joined. */
+#define NHP_COMM_ID_BYTES 128
+nhp_status nhp_comm_unique_id(uint8_t *id /* [NHP_COMM_ID_BYTES] */);
+nhp_status nhp_comm_create(nhp_ctx *ctx, const uint8_t *id, int32_t rank, int32_t world, nhp_comm **out);
+void nhp_comm_destroy(nhp_comm *comm);
+int32_t nhp_comm_rank(const nhp_comm *comm);
+int32_t nhp_comm_world(const nhp_comm *comm);
+/* host vectors through a device staging buffer (small control data: link counts, log-likelihood traces, flags) */
+nhp_status nhp_allreduce_sum(nhp_ctx *ctx, nhp_comm *comm, double *x, int64_t n);                 /* in place */
+nhp_status nhp_allgather(nhp_ctx *ctx, nhp_comm *comm, const double *mine, int64_t n, double *all /* [world*n] */);
+/* loglikelihood(process, data; recursive) by all ranks together: `ds` is this rank's column shard
+ * (nhp_cont_dataset_create_columns); the partial result is all-reduced in place on the device and fetched once.
+ * Every rank returns the same value. */
+nhp_status nhp_cont_loglik_allreduce(nhp_ctx *ctx, nhp_comm *comm, const nhp_cont_dataset *ds, const nhp_cont_model *model,
+                                     int32_t flags, double *ll);
+/* the mle! objective and its gradient (nhp_cont_loglik_grad) over all ranks: each rank's gradient is exact zeros outside
+ * its columns, so the sum is the gradient; [ll; grad] is all-reduced on the device (P+1 doubles, 16.8 MB at N = 1024)
+ * before the one download. */
+nhp_status nhp_cont_loglik_grad_allreduce(nhp_ctx *ctx, nhp_comm *comm, const nhp_cont_dataset *ds, const nhp_cont_model *model,
+                                          int32_t flags, double *ll, double *grad, int64_t grad_len);
+/* BASELINE config 5: the per-chain posterior summaries (the running sums of nhp_cont_model_moments_*, still on each
+ * rank's device) all-gathered over RCCL: sum_all / sumsq_all [world * len] (rank r at r*len), counts [world],
+ * rho_all [world * 3] (ρ, Σρ, Σρ² of nhp_cont_model_get_rho; zeros for a model without a device-side ρ). */
+nhp_status nhp_gather_moments(nhp_ctx *ctx, nhp_comm *comm, const nhp_cont_model *model, double *sum_all, double *sumsq_all,
+                              int64_t len, int64_t *counts, double *rho_all);
+
+/* ---- network model on the device + chain driver  (src/networks.jl:54-78, src/inference.jl:49-70) ---------------
+ * BernoulliNetworkModel.ρ kept next to the model on the device so that a network mcmc! step never drains the stream:
+ * _set_rho uploads it, _get_rho returns {ρ, Σρ, Σρ²} (the sums follow nhp_cont_model_moments_accumulate / _reset). */
+nhp_status nhp_cont_model_set_rho(nhp_ctx *ctx, nhp_cont_model *model, double rho);
+nhp_status nhp_cont_model_get_rho(nhp_ctx *ctx, const nhp_cont_model *model, double *out /* [3] */);
+/* resample_adjacency_matrix!(process, data) with the device-resident ρ (src/continuous.jl:444-487), then
+ * resample!(network, A): ρ ~ Beta(α + ΣA, β + N² - ΣA) (src/networks.jl:70-78) drawn on the device as X/(X+Y) from two
+ * Philox-keyed Gammas.  Asynchronous.  With a communicator, `ds` is a column shard: the shards' link counts are
+ * all-reduced on the device and every rank draws the same ρ (same Philox key). */
+/* alpha = beta = 0: ρ is held fixed (DenseNetworkModel, src/networks.jl:13-31: set ρ = 1). */
+nhp_status nhp_cont_network_step(nhp_ctx *ctx, nhp_comm *comm /* nullable */, const nhp_cont_dataset *ds, nhp_cont_model *model,
+                                 double alpha, double beta, uint64_t seed, uint64_t step);
+/* The same step in two halves, for a host that exchanges the shards' link counts itself (no RCCL clique: ranks sharing
+ * one GPU, a CPU-side rehearsal): _sweep runs the adjacency sweep with the device-resident ρ and returns this dataset's
+ * link count (synchronises); _rho draws ρ ~ Beta(alpha + n_links, beta + n_entries - n_links) on the device with the same
+ * Philox key as nhp_cont_network_step, so both routes give the same chain. */
+nhp_status nhp_cont_network_sweep(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_model *model, uint64_t seed, uint64_t step,
+                                  double *n_links);
+nhp_status nhp_cont_network_rho(nhp_ctx *ctx, nhp_cont_model *model, double alpha, double beta, double n_links, double n_entries,
+                                uint64_t seed, uint64_t step);
+/* The body of mcmc!(process, data; nsteps) (src/inference.jl:55-62) for steps [step0, step0 + n_steps): per step one
+ * nhp_cont_gibbs_step, for a network model one nhp_cont_network_step (net_alpha, net_beta = the Beta prior of ρ), and --
+ * from chain step `burn` on -- one nhp_cont_model_moments_accumulate in place of push!(res.samples, params(process)).
+ * Nothing crosses PCIe and the host synchronises once, at the end (where a sampler error of any step is reported).
+ * comm (nullable): ONE chain swept by all ranks, each its column shard. */
+nhp_status nhp_cont_mcmc_run(nhp_ctx *ctx, nhp_comm *comm /* nullable */, const nhp_cont_dataset *ds, nhp_cont_model *model,
+                             const nhp_gibbs_priors *priors, double net_alpha, double net_beta, uint64_t seed,
+                             uint64_t step0, int64_t n_steps, int64_t burn);
 
 #ifdef __cplusplus
 }

@@ -41,16 +41,19 @@ def gather_summaries(local, n_chains, device=None):
     if not (dist.is_available() and dist.is_initialized()):
         return dict(local)
     world, rank = dist.get_world_size(), dist.get_rank()
-    per_rank = max(len(chains_for_rank(n_chains, r, world)) for r in range(world))
-    if not local:
-        raise ValueError("every rank must own at least one chain (n_chains >= world size)")
+    if n_chains < world:          # checked from the arguments, identically on every rank, BEFORE any collective: a rank
+        raise ValueError("every rank must own at least one chain (n_chains >= world size)")   # without chains would
+    per_rank = max(len(chains_for_rank(n_chains, r, world)) for r in range(world))             # leave the others blocked
     P = len(next(iter(local.values()))["mean"])
     width = 2 + 2 * P                                       # [chain id, n, mean(P), m2(P)]
     buf = np.full((per_rank, width), -1.0)
     for slot, (k, s) in enumerate(sorted(local.items())):
         buf[slot, 0], buf[slot, 1] = k, s["n"][0]
         buf[slot, 2:2 + P], buf[slot, 2 + P:] = s["mean"], s["m2"]
-    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    if device is None and dist.get_backend() == "nccl":     # stage on THIS rank's GPU (the context's), not on torch's current one
+        from . import _lib
+        device = torch.device("cuda", _lib.default_context().device)
+    dev = device if device is not None else "cpu"
     mine = torch.from_numpy(buf).to(dev)
     parts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine)
@@ -77,8 +80,14 @@ def run_chains(make_process, data, n_chains, nsteps, base_seed=0, burn=0, ctx=No
             rank, world = dist.get_rank(), dist.get_world_size()
     except ImportError:                       # pragma: no cover
         pass
+    if n_chains < world:
+        raise ValueError("every rank must own at least one chain (n_chains >= world size)")
+    from . import _lib
+    ctx = ctx or _lib.default_context()
+    comm = _lib.comm_for(ctx)
     local = {}
     ds = None
+    device_models = {}
     for k in chains_for_rank(n_chains, rank, world):
         process = make_process(k)
         if ds is None:
@@ -92,7 +101,35 @@ def run_chains(make_process, data, n_chains, nsteps, base_seed=0, burn=0, ctx=No
             res = mcmc_(process, ds, nsteps=nsteps, seed=chain_seed(base_seed, k), ctx=ctx, keep_samples=False,
                         moments=True, burn=burn, **kw)
             local[k] = {"n": np.array([float(res.n)]), "mean": res.mean, "m2": res.m2}
+            device_models[k] = (process, process._dev)
         else:
             res = mcmc_(process, ds, nsteps=nsteps, seed=chain_seed(base_seed, k), ctx=ctx, **mcmc_kwargs)
             local[k] = summarize_chain(res.samples, burn)
-    return gather_summaries(local, n_chains)
+    if comm is not None and n_chains % world == 0 and len(device_models) == len(local):
+        return gather_device_summaries(device_models, n_chains, ctx, comm)
+    return gather_summaries(local, n_chains, device=None)
+
+
+def gather_device_summaries(device_models, n_chains, ctx, comm):
+    """BASELINE config 5's exchange through the library: the chains' running sums are all-gathered device to device over
+    RCCL / xGMI (nhp_gather_moments) -- one collective per chain slot, every rank contributing its slot-th chain -- and
+    divided into means on the host afterwards.  Needs the same number of chains on every rank."""
+    import ctypes as C
+    from . import _lib
+    from .inference import _moments_in_params_order, moments_length
+    from .continuous import ContinuousNetworkHawkesProcess
+    world, rank = comm.world, comm.rank
+    out = {}
+    for slot, k in enumerate(sorted(device_models)):
+        process, model = device_models[k]
+        L = moments_length(process)
+        s, q = np.empty((world, L)), np.empty((world, L))
+        counts, rho = np.empty(world, dtype=np.int64), np.empty((world, 3))
+        _lib.check(_lib.lib().nhp_gather_moments(ctx.h, comm.h, model.h, _lib.dptr(s), _lib.dptr(q), L, _lib.iptr(counts), _lib.dptr(rho)), ctx.h)
+        network = isinstance(process, ContinuousNetworkHawkesProcess)
+        for r in range(world):
+            chain = chains_for_rank(n_chains, r, world)[slot]
+            mean, m2 = _moments_in_params_order(process, s[r], q[r], int(counts[r]), network, rho[r, 1], rho[r, 2])
+            out[chain] = {"n": np.array([float(counts[r])]), "mean": mean, "m2": m2}
+    assert sorted(out) == list(range(n_chains)), (rank, sorted(out))
+    return out

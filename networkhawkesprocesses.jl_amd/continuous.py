@@ -250,6 +250,13 @@ def intensity(process, data, times, ctx=None):
     return res[0] if scalar else res
 
 
+def gradient_length(process):
+    """len(params(process)) of the standard process, without building the vector (three column-major N x N copies)."""
+    N = process.ndims()
+    return (N if isinstance(process.baseline, HomogeneousProcess) else N * len(process.baseline.x)) \
+        + N * N * (2 if isinstance(process.impulses, ExponentialImpulseResponse) else 3)
+
+
 def loglikelihood_gradient(process, data, recursive=True, ctx=None, model=None):
     """(ll, ∇ll) with the gradient in params! order [λ0; θ | μ; τ; W].  The reference supplies no
     gradient to Optim (src/continuous.jl:190), which then spends 2P objective calls on finite
@@ -260,9 +267,7 @@ def loglikelihood_gradient(process, data, recursive=True, ctx=None, model=None):
     ctx = ctx or _lib.default_context()
     ds = device_dataset(process, data, ctx)
     model = model or process.device_model(ctx)
-    N = process.ndims()                        # len(params(process)) without building the vector (column-major copies)
-    P = (N if isinstance(process.baseline, HomogeneousProcess) else N * len(process.baseline.x)) \
-        + N * N * (2 if isinstance(process.impulses, ExponentialImpulseResponse) else 3)
+    P = gradient_length(process)
     g = np.empty(P)
     ll = C.c_double()
     _lib.check(_lib.lib().nhp_cont_loglik_grad(ctx.h, ds.h, model.h, _check_recursive(process, recursive),

@@ -239,11 +239,13 @@ __global__ __launch_bounds__(64) void k_adj_sweep(nhp_cont_args a, double *__res
                                                   const int32_t *__restrict__ ent_k, const double *__restrict__ ent_x,
                                                   const int32_t *__restrict__ col_start, const unsigned char *__restrict__ col_group,
                                                   const double *__restrict__ lam_g,
-                                                  const double *__restrict__ rho_mat, double rho_scalar,
+                                                  const double *__restrict__ rho_mat, double rho_host,
+                                                  const double *__restrict__ rho_dev,
                                                   const double *__restrict__ u, uint64_t seed, uint64_t step,
                                                   int max_children, double *__restrict__ col_links)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    const double rho_scalar = rho_dev ? *rho_dev : rho_host;          // device-resident ρ of the network model, if any
     const int N = a.N, c = a.col_begin + blockIdx.x, lane = threadIdx.x;
     double *lam = reinterpret_cast<double *>(smem);                        // [max_children] current λ_k
     double *dx = lam + max_children;                                       // [max_children] Σ x_kp of the current p
@@ -362,13 +364,14 @@ __global__ __launch_bounds__(64) void k_adj_sweep(nhp_cont_args a, double *__res
     if (lane == 0 && col_links) col_links[c] = links;
 }
 
-extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_model *m,
-                                                  const double *rho_matrix, double rho, const double *u,
-                                                  uint64_t seed, uint64_t step, double *A_out, double *n_links)
+// One sweep of A, enqueued on the ctx stream; the per-column link counts are left at *d_links_out [N] in the scratch.
+// Link probabilities: rho_matrix (host, N*N) | d_rho_scalar (device scalar) | rho.
+nhp_status nhp_adj_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_model *m, const double *rho_matrix, double rho,
+                           const double *d_rho_scalar, const double *u, uint64_t seed, uint64_t step, double **d_links_out)
 {
     NHP_TRY(nhp_check_pair(ctx, ds, m));
     if (!m->has_A) { nhp_set_error(ctx, "resample_adjacency: the model has no adjacency matrix"); return NHP_EINVAL; }
-    if (!rho_matrix && !(rho >= 0.0 && rho <= 1.0)) { nhp_set_error(ctx, "link probability must lie in [0, 1]"); return NHP_EDOMAIN; }
+    if (!rho_matrix && !d_rho_scalar && !(rho >= 0.0 && rho <= 1.0)) { nhp_set_error(ctx, "link probability must lie in [0, 1]"); return NHP_EDOMAIN; }
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t N = (size_t)ds->N, NN = N * N, P = (size_t)(ds->pairs > 0 ? ds->pairs : 1);
     int max_children = 1;
@@ -429,8 +432,20 @@ extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_d
     NHP_HIP(ctx, hipGetLastError());
     if (lds_sweep > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sweep));
     hipLaunchKernelGGL(k_adj_sweep, dim3(ncol), dim3(64), lds_sweep, st, a, m->d_A, d_off, d_k, d_x, d_start, ds->d_adj_group, d_lam,
-                       d_rho, rho, d_u, seed, step, max_children, d_links);
+                       d_rho, rho, d_rho_scalar, d_u, seed, step, max_children, d_links);
     NHP_HIP(ctx, hipGetLastError());
+    *d_links_out = d_links;
+    return NHP_OK;
+}
+
+extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_model *m,
+                                                  const double *rho_matrix, double rho, const double *u,
+                                                  uint64_t seed, uint64_t step, double *A_out, double *n_links)
+{
+    double *d_links = nullptr;
+    NHP_TRY(nhp_adj_enqueue(ctx, ds, m, rho_matrix, rho, nullptr, u, seed, step, &d_links));
+    const size_t N = (size_t)ds->N, NN = N * N;
+    hipStream_t st = ctx->stream;
     std::vector<double> links(N);
     NHP_HIP(ctx, hipMemcpyAsync(links.data(), d_links, 8 * N, hipMemcpyDeviceToHost, st));
     NHP_HIP(ctx, hipStreamSynchronize(st));
@@ -441,4 +456,122 @@ extern "C" nhp_status nhp_cont_resample_adjacency(nhp_ctx *ctx, const nhp_cont_d
         *n_links = s;
     }
     return NHP_OK;
+}
+
+
+// ---- BernoulliNetworkModel on the device: resample!(network, A) (src/networks.jl:70-78) -----------------------------
+// ρ ~ Beta(α + ΣA, β + N² - ΣA) as X / (X + Y), X ~ Gamma(α + ΣA), Y ~ Gamma(β + N² - ΣA), Philox-keyed (seed, step); the
+// link counts of the columns are added in a fixed order (one workgroup: deterministic).  state = {ρ, Σρ, Σρ², ΣA}.
+#include "nhp_rng.h"
+__global__ __launch_bounds__(256) void k_links_total(const double *__restrict__ col_links, int N, double *__restrict__ state)
+{
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int c = threadIdx.x; c < N; c += 256) s += col_links[c];
+    s = nhp_block_sum_n<4>(s, red);
+    if (threadIdx.x == 0) state[3] = s;
+}
+
+__global__ void k_rho_draw(double *__restrict__ state, double alpha, double beta, double nn, uint64_t seed, uint64_t step)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double links = state[3];
+    const double x = dev_gamma(alpha + links, 1.0, seed ^ 0x3F84D5B5B5470917ull, step, 0);
+    const double y = dev_gamma(beta + nn - links, 1.0, seed ^ 0x3F84D5B5B5470917ull, step, 1);
+    state[0] = x / (x + y);
+}
+
+static nhp_status ensure_rho(nhp_ctx *ctx, nhp_cont_model *m)
+{
+    if (m->d_rho) return NHP_OK;
+    NHP_HIP(ctx, hipMalloc((void **)&m->d_rho, 4 * sizeof(double)));
+    NHP_HIP(ctx, hipMemsetAsync(m->d_rho, 0, 4 * sizeof(double), ctx->stream));
+    return NHP_OK;
+}
+
+extern "C" nhp_status nhp_cont_model_set_rho(nhp_ctx *ctx, nhp_cont_model *m, double rho)
+{
+    if (!ctx || !m) return NHP_EINVAL;
+    if (m->ctx != ctx) { nhp_set_error(ctx, "model belongs to another ctx"); return NHP_EINVAL; }
+    if (!(rho >= 0.0 && rho <= 1.0)) { nhp_set_error(ctx, "link probability must lie in [0, 1]"); return NHP_EDOMAIN; }
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    NHP_TRY(ensure_rho(ctx, m));
+    NHP_HIP(ctx, hipMemcpyAsync(m->d_rho, &rho, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));          // `rho` is a stack value
+    return NHP_OK;
+}
+
+extern "C" nhp_status nhp_cont_model_get_rho(nhp_ctx *ctx, const nhp_cont_model *m, double *out)
+{
+    if (!ctx || !m || !out) return NHP_EINVAL;
+    if (m->ctx != ctx) { nhp_set_error(ctx, "model belongs to another ctx"); return NHP_EINVAL; }
+    if (!m->d_rho) { nhp_set_error(ctx, "get_rho: the model has no device-side link probability (nhp_cont_model_set_rho)"); return NHP_EINVAL; }
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    return nhp_download(ctx, out, m->d_rho, 3 * sizeof(double));
+}
+
+extern "C" nhp_status nhp_cont_network_step(nhp_ctx *ctx, nhp_comm *comm, const nhp_cont_dataset *ds, nhp_cont_model *m,
+                                            double alpha, double beta, uint64_t seed, uint64_t step)
+{
+    if (!ctx || !m) return NHP_EINVAL;
+    if (!m->d_rho) { nhp_set_error(ctx, "network_step: set the link probability first (nhp_cont_model_set_rho)"); return NHP_EINVAL; }
+    const bool fixed = alpha == 0.0 && beta == 0.0;                                         // DenseNetworkModel: ρ stays
+    if (!fixed && !(alpha > 0.0 && beta > 0.0)) { nhp_set_error(ctx, "network_step: the Beta prior needs alpha, beta > 0"); return NHP_EDOMAIN; }
+    if (!comm && ds && nhp_is_column_shard(ds)) { nhp_set_error(ctx, "network_step: a column shard needs the communicator of its ranks"); return NHP_EINVAL; }
+    double *d_links = nullptr;
+    NHP_TRY(nhp_adj_enqueue(ctx, ds, m, nullptr, 0.5, m->d_rho, nullptr, seed, step, &d_links));
+    hipLaunchKernelGGL(k_links_total, dim3(1), dim3(256), 0, ctx->stream, d_links, ds->N, m->d_rho);
+    NHP_HIP(ctx, hipGetLastError());
+    if (comm && comm->world > 1) NHP_TRY(nhp_comm_allreduce_dev(ctx, comm, m->d_rho + 3, 1));      // the shards' link counts
+    const double nn = (double)ds->N * (double)ds->N;
+    if (!fixed) {
+        hipLaunchKernelGGL(k_rho_draw, dim3(1), dim3(64), 0, ctx->stream, m->d_rho, alpha, beta, nn, seed, step);
+        NHP_HIP(ctx, hipGetLastError());
+    }
+    return NHP_OK;
+}
+
+extern "C" nhp_status nhp_cont_network_sweep(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_model *m, uint64_t seed, uint64_t step,
+                                             double *n_links)
+{
+    if (!ctx || !m || !n_links) return NHP_EINVAL;
+    if (!m->d_rho) { nhp_set_error(ctx, "network_sweep: set the link probability first (nhp_cont_model_set_rho)"); return NHP_EINVAL; }
+    double *d_links = nullptr;
+    NHP_TRY(nhp_adj_enqueue(ctx, ds, m, nullptr, 0.5, m->d_rho, nullptr, seed, step, &d_links));
+    hipLaunchKernelGGL(k_links_total, dim3(1), dim3(256), 0, ctx->stream, d_links, ds->N, m->d_rho);
+    NHP_HIP(ctx, hipGetLastError());
+    return nhp_download(ctx, n_links, m->d_rho + 3, sizeof(double));
+}
+
+extern "C" nhp_status nhp_cont_network_rho(nhp_ctx *ctx, nhp_cont_model *m, double alpha, double beta, double n_links, double n_entries,
+                                           uint64_t seed, uint64_t step)
+{
+    if (!ctx || !m) return NHP_EINVAL;
+    if (m->ctx != ctx) { nhp_set_error(ctx, "model belongs to another ctx"); return NHP_EINVAL; }
+    if (!m->d_rho) { nhp_set_error(ctx, "network_rho: set the link probability first (nhp_cont_model_set_rho)"); return NHP_EINVAL; }
+    if (alpha == 0.0 && beta == 0.0) return NHP_OK;
+    if (!(alpha > 0.0 && beta > 0.0) || !(n_links >= 0.0 && n_links <= n_entries)) { nhp_set_error(ctx, "network_rho: bad Beta parameters"); return NHP_EDOMAIN; }
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    NHP_HIP(ctx, hipMemcpyAsync(m->d_rho + 3, &n_links, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_rho_draw, dim3(1), dim3(64), 0, ctx->stream, m->d_rho, alpha, beta, n_entries, seed, step);
+    NHP_HIP(ctx, hipGetLastError());
+    NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));                       // n_links is a stack value
+    return NHP_OK;
+}
+
+// ---- chain driver: the loop body of mcmc! (src/inference.jl:55-62), device-resident end to end ------------------------
+extern "C" nhp_status nhp_cont_mcmc_run(nhp_ctx *ctx, nhp_comm *comm, const nhp_cont_dataset *ds, nhp_cont_model *m,
+                                        const nhp_gibbs_priors *pr, double net_alpha, double net_beta, uint64_t seed,
+                                        uint64_t step0, int64_t n_steps, int64_t burn)
+{
+    if (!ctx || !m || !pr || n_steps < 0) return NHP_EINVAL;
+    NHP_TRY(nhp_check_pair(ctx, ds, m));
+    if (m->has_A && !m->d_rho) { nhp_set_error(ctx, "mcmc_run: set the network's link probability first (nhp_cont_model_set_rho)"); return NHP_EINVAL; }
+    for (int64_t k = 0; k < n_steps; ++k) {
+        const uint64_t step = step0 + (uint64_t)k;
+        NHP_TRY(nhp_cont_gibbs_step(ctx, ds, m, pr, seed, step));           // (reports a sampler error one sweep late)
+        if (m->has_A) NHP_TRY(nhp_cont_network_step(ctx, comm, ds, m, net_alpha, net_beta, seed, step));
+        if (burn >= 0 && (int64_t)step >= burn) NHP_TRY(nhp_cont_model_moments_accumulate(ctx, m));
+    }
+    return nhp_ctx_synchronize(ctx);
 }

@@ -359,7 +359,7 @@ extern "C" void nhp_cont_model_destroy(nhp_cont_model *m)
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
-    (void)hipFree(m->d_mom);
+    (void)hipFree(m->d_mom); (void)hipFree(m->d_rho);
     (void)hipFree(m->d_lambda0); (void)hipFree(m->d_grid); (void)hipFree(m->d_p1);
     (void)hipFree(m->d_p2); (void)hipFree(m->d_W); (void)hipFree(m->d_A);
     delete m;

@@ -282,11 +282,13 @@ static void launch_grad_group(int G, dim3 grid, size_t lds, hipStream_t st, cons
 #undef NHP_CASE
 }
 
-extern "C" nhp_status nhp_cont_loglik_grad(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m,
-                                           int32_t flags, double *ll, double *grad, int64_t grad_len)
+// Enqueue log-likelihood (-> ctx->d_results[0]) and gradient (-> *d_grad_out, P doubles inside ctx->d_scratch; the two
+// doubles in front of it are spare, so the multi-GPU path can put the log-likelihood at (*d_grad_out)[-1] and all-reduce
+// [ll; grad] as one vector).
+nhp_status nhp_grad_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, int32_t flags, int64_t grad_len,
+                            double **d_grad_out)
 {
     NHP_TRY(nhp_check_pair(ctx, ds, m));
-    if (!ll || !grad) return NHP_EINVAL;
     const size_t N = (size_t)ds->N, NN = N * N;
     const bool exp_imp = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
     const bool lgcp = m->baseline_kind != NHP_BASELINE_HOMOGENEOUS;
@@ -294,8 +296,9 @@ extern "C" nhp_status nhp_cont_loglik_grad(nhp_ctx *ctx, const nhp_cont_dataset 
     if ((size_t)grad_len != P) { nhp_set_error(ctx, "Parameter vector length does not match model parameter length."); return NHP_ESHAPE; }
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t M = (size_t)(ds->M > 0 ? ds->M : 1);
-    NHP_TRY(nhp_ctx_reserve_scratch(ctx, 8 * (P + M)));
-    double *d_grad = (double *)ctx->d_scratch, *d_lambda = d_grad + P;
+    NHP_TRY(nhp_ctx_reserve_scratch(ctx, 8 * (2 + P + M)));
+    double *d_grad = (double *)ctx->d_scratch + 2, *d_lambda = d_grad + P;
+    *d_grad_out = d_grad;
     nhp_cont_args a = nhp_make_args(ds, m);
     hipStream_t st = ctx->stream;
     // the recursive formulation through its truncated window when the bound allows (cont_recursive.hip): the windowed
@@ -335,6 +338,15 @@ extern "C" nhp_status nhp_cont_loglik_grad(nhp_ctx *ctx, const nhp_cont_dataset 
         else launch_grad_group<NHP_IMPULSE_LOGITNORMAL>(G, grid, lds, st, a, d_lambda, d_grad);
         NHP_HIP(ctx, hipGetLastError());
     }
-    NHP_TRY(nhp_download(ctx, grad, d_grad, 8 * P));
+    return NHP_OK;
+}
+
+extern "C" nhp_status nhp_cont_loglik_grad(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m,
+                                           int32_t flags, double *ll, double *grad, int64_t grad_len)
+{
+    if (!ll || !grad) return NHP_EINVAL;
+    double *d_grad = nullptr;
+    NHP_TRY(nhp_grad_enqueue(ctx, ds, m, flags, grad_len, &d_grad));
+    NHP_TRY(nhp_download(ctx, grad, d_grad, 8 * (size_t)grad_len));
     return nhp_ctx_fetch(ctx, 0, 1, ll);
 }

@@ -590,7 +590,7 @@ extern "C" nhp_status nhp_cont_gibbs_step(nhp_ctx *ctx, const nhp_cont_dataset *
 __global__ __launch_bounds__(256) void k_moments(int64_t N, int64_t nimp, const double *__restrict__ lambda0,
                                                  const double *__restrict__ p1, const double *__restrict__ p2,
                                                  const double *__restrict__ W, const double *__restrict__ A,
-                                                 int64_t len, double *__restrict__ mom)
+                                                 int64_t len, double *__restrict__ mom, double *__restrict__ rho)
 {
     const int64_t NN = N * N;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) {
@@ -603,6 +603,7 @@ __global__ __launch_bounds__(256) void k_moments(int64_t N, int64_t nimp, const 
         mom[i] += x;
         mom[len + i] += x * x;
     }
+    if (rho && blockIdx.x == 0 && threadIdx.x == 0) { rho[1] += rho[0]; rho[2] += rho[0] * rho[0]; }
 }
 
 extern "C" nhp_status nhp_cont_model_moments_reset(nhp_ctx *ctx, nhp_cont_model *m)
@@ -622,6 +623,7 @@ extern "C" nhp_status nhp_cont_model_moments_reset(nhp_ctx *ctx, nhp_cont_model 
         m->mom_len = len;
     }
     NHP_HIP(ctx, hipMemsetAsync(m->d_mom, 0, sizeof(double) * 2 * (size_t)len, ctx->stream));
+    if (m->d_rho) NHP_HIP(ctx, hipMemsetAsync(m->d_rho + 1, 0, 2 * sizeof(double), ctx->stream));
     m->mom_count = 0;
     return NHP_OK;
 }
@@ -635,7 +637,7 @@ extern "C" nhp_status nhp_cont_model_moments_accumulate(nhp_ctx *ctx, nhp_cont_m
     const int64_t N = m->N, NN = N * N, nimp = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? NN : 2 * NN;
     const unsigned blocks = (unsigned)std::min<int64_t>((m->mom_len + 255) / 256, 4096);
     hipLaunchKernelGGL(k_moments, dim3(blocks), dim3(256), 0, ctx->stream, N, nimp, m->d_lambda0, m->d_p1, m->d_p2, m->d_W,
-                       m->has_A ? m->d_A : nullptr, m->mom_len, m->d_mom);
+                       m->has_A ? m->d_A : nullptr, m->mom_len, m->d_mom, m->d_rho);
     NHP_HIP(ctx, hipGetLastError());
     ++m->mom_count;
     return NHP_OK;
@@ -670,4 +672,15 @@ extern "C" nhp_status nhp_cont_model_get_params(nhp_ctx *ctx, const nhp_cont_mod
     if (m->impulse_kind == NHP_IMPULSE_LOGITNORMAL) NHP_TRY(nhp_download(ctx, x + N + NN, m->d_p2, 8 * NN));
     NHP_TRY(nhp_download(ctx, x + N + nimp, m->d_W, 8 * NN));
     return NHP_OK;
+}
+
+extern "C" nhp_status nhp_cont_model_get_adjacency(nhp_ctx *ctx, const nhp_cont_model *m, double *A, int64_t len)
+{
+    if (!ctx || !m || !A) return NHP_EINVAL;
+    if (m->ctx != ctx) { nhp_set_error(ctx, "model belongs to another ctx"); return NHP_EINVAL; }
+    if (!m->has_A) { nhp_set_error(ctx, "get_adjacency: the model has no adjacency matrix"); return NHP_EINVAL; }
+    const size_t NN = (size_t)m->N * (size_t)m->N;
+    if ((size_t)len != NN) { nhp_set_error(ctx, "Parameter vector length does not match model parameter length."); return NHP_ESHAPE; }
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    return nhp_download(ctx, A, m->d_A, 8 * NN);
 }

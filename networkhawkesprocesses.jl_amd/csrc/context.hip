@@ -18,7 +18,31 @@ void nhp_set_error(nhp_ctx *ctx, const char *fmt, ...)
     if (ctx) ctx->err = buf;
 }
 
-extern "C" int32_t nhp_abi_version(void) { return 1; }
+extern "C" int32_t nhp_abi_version(void) { return 2; }
+
+#include <stddef.h>
+extern "C" int32_t nhp_abi_layout(int32_t *out, int32_t cap)
+{
+    const int32_t v[NHP_ABI_LAYOUT_LEN] = {
+        (int32_t)sizeof(nhp_cont_model_desc),
+        (int32_t)offsetof(nhp_cont_model_desc, n_nodes), (int32_t)offsetof(nhp_cont_model_desc, baseline_kind),
+        (int32_t)offsetof(nhp_cont_model_desc, lambda0), (int32_t)offsetof(nhp_cont_model_desc, grid_x),
+        (int32_t)offsetof(nhp_cont_model_desc, grid_n), (int32_t)offsetof(nhp_cont_model_desc, impulse_kind),
+        (int32_t)offsetof(nhp_cont_model_desc, theta), (int32_t)offsetof(nhp_cont_model_desc, mu),
+        (int32_t)offsetof(nhp_cont_model_desc, tau), (int32_t)offsetof(nhp_cont_model_desc, dt_max),
+        (int32_t)offsetof(nhp_cont_model_desc, W), (int32_t)offsetof(nhp_cont_model_desc, A),
+        (int32_t)sizeof(nhp_gibbs_priors),
+        (int32_t)offsetof(nhp_gibbs_priors, alpha0), (int32_t)offsetof(nhp_gibbs_priors, beta0),
+        (int32_t)offsetof(nhp_gibbs_priors, kappa), (int32_t)offsetof(nhp_gibbs_priors, nu),
+        (int32_t)offsetof(nhp_gibbs_priors, a), (int32_t)offsetof(nhp_gibbs_priors, b),
+        (int32_t)offsetof(nhp_gibbs_priors, mu_mu), (int32_t)offsetof(nhp_gibbs_priors, kappa_mu),
+        (int32_t)sizeof(nhp_cont_stats),
+        (int32_t)offsetof(nhp_cont_stats, cnt0), (int32_t)offsetof(nhp_cont_stats, Mn), (int32_t)offsetof(nhp_cont_stats, Mnm),
+        (int32_t)offsetof(nhp_cont_stats, Xnm), (int32_t)offsetof(nhp_cont_stats, Vnm),
+        NHP_MAX_SLOTS, NHP_COMM_ID_BYTES};
+    for (int32_t i = 0; out && i < cap && i < NHP_ABI_LAYOUT_LEN; ++i) out[i] = v[i];
+    return NHP_ABI_LAYOUT_LEN;
+}
 
 extern "C" const char *nhp_last_error(const nhp_ctx *ctx)
 {

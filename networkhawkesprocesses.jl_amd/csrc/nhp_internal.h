@@ -136,7 +136,28 @@ struct nhp_cont_model {
     // chain's posterior summaries never cross PCIe step by step
     double *d_mom = nullptr;            // [2][mom_len]
     int64_t mom_len = 0, mom_count = 0;
+    // BernoulliNetworkModel.ρ on the device (nhp_cont_model_set_rho / nhp_cont_network_step): {ρ, Σρ, Σρ², ΣA of the
+    // latest sweep}; the sums follow the moments above
+    double *d_rho = nullptr;
 };
+
+// RCCL communicator of one rank (comm.hip); librccl.so.1 is dlopen'ed on first use
+struct nhp_comm {
+    nhp_ctx *ctx = nullptr;
+    void *nccl = nullptr;               // ncclComm_t
+    int rank = 0, world = 1;
+};
+// in-place sum / gather of device doubles over the ranks, on the ctx stream (asynchronous)
+nhp_status nhp_comm_allreduce_dev(nhp_ctx *ctx, nhp_comm *comm, double *d_buf, size_t n);
+nhp_status nhp_comm_allgather_dev(nhp_ctx *ctx, nhp_comm *comm, const double *d_mine, size_t n, double *d_all);
+// cont_grad.hip: enqueue log-likelihood (-> ctx->d_results[0]) + gradient (-> *d_grad, P doubles in ctx->d_scratch, with one
+// spare double in front of it at (*d_grad)[-1] for the packed [ll; grad] exchange)
+nhp_status nhp_grad_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, int32_t flags, int64_t grad_len,
+                            double **d_grad);
+// cont_adjacency.hip: enqueue one sweep of A; per-column link counts land at *d_links [N] (scratch)
+nhp_status nhp_adj_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_model *m, const double *rho_matrix, double rho,
+                           const double *d_rho_scalar, const double *u, uint64_t seed, uint64_t step, double **d_links);
+
 
 // Kernel-side view of model + data (passed by value).
 struct nhp_cont_args {

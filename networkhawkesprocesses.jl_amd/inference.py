@@ -94,7 +94,7 @@ def mle_(process, data, optimizer="L-BFGS-B", verbose=False, f_abstol=1e-6, regu
     rng = np.random.default_rng(seed)
     x0 = _rand_init_(process, rng) if guess is None else np.array(guess, dtype=np.float64)
     if shard is not None and shard.world > 1:                        # rank 0's start everywhere
-        x0 = _all_reduce_sum(x0 if shard.rank == 0 else np.zeros_like(x0))
+        x0 = _all_reduce_sum(x0 if shard.rank == 0 else np.zeros_like(x0), ctx)
     lower, upper = 1e-6, 1e1
     state = {"minloss": np.inf, "steps": 0, "converged": False, "last": None}
     start = time.time()
@@ -104,6 +104,7 @@ def mle_(process, data, optimizer="L-BFGS-B", verbose=False, f_abstol=1e-6, regu
     model = process.device_model(ctx)
     flags = _check_recursive(process, recursive)
     P = len(x0)
+    comm = _lib.comm_for(ctx) if shard is not None else None
 
     def fg(x):
         # params!(process, x) straight into the device-resident model: x already is the reference's
@@ -111,11 +112,15 @@ def mle_(process, data, optimizer="L-BFGS-B", verbose=False, f_abstol=1e-6, regu
         model.set_params(x)
         g = np.empty(P)
         ll_c = C.c_double()
-        _lib.check(_lib.lib().nhp_cont_loglik_grad(ctx.h, ds.h, model.h, flags, C.byref(ll_c), _lib.dptr(g), P), ctx.h)
-        ll = ll_c.value
-        if shard is not None:                                        # the other ranks' columns (sharded.py)
-            tot = _all_reduce_sum(np.concatenate([[ll], g]))
-            ll, g = float(tot[0]), tot[1:]
+        if comm is not None:           # the other ranks' columns: [ll; ∇ll] summed on the device over RCCL, one download
+            _lib.check(_lib.lib().nhp_cont_loglik_grad_allreduce(ctx.h, comm.h, ds.h, model.h, flags, C.byref(ll_c), _lib.dptr(g), P), ctx.h)
+            ll = ll_c.value
+        else:
+            _lib.check(_lib.lib().nhp_cont_loglik_grad(ctx.h, ds.h, model.h, flags, C.byref(ll_c), _lib.dptr(g), P), ctx.h)
+            ll = ll_c.value
+            if shard is not None:                                    # (gloo rehearsal) the other ranks' columns through the host
+                tot = _all_reduce_sum(np.concatenate([[ll], g]), ctx)
+                ll, g = float(tot[0]), tot[1:]
         if regularize:
             process.params_(x)
             ll += logprior(process)
@@ -219,7 +224,22 @@ def _fetch_moments(process, model, ctx, network, rho_sum, rho_sq):
     s, q = np.empty(L), np.empty(L)
     cnt = C.c_int64()
     _lib.check(_lib.lib().nhp_cont_model_moments_fetch(ctx.h, model.h, _lib.dptr(s), _lib.dptr(q), L, C.byref(cnt)), ctx.h)
-    n = max(1, cnt.value)
+    mean, m2 = _moments_in_params_order(process, s, q, cnt.value, network, rho_sum, rho_sq)
+    return mean, m2, cnt.value
+
+
+def moments_length(process):
+    """Length of the device-side running sums of nhp_cont_model_moments_*: [λ0; impulses; W; vec(A) if any]."""
+    N = process.ndims()
+    nimp = N * N * (1 if isinstance(process.impulses, ExponentialImpulseResponse) else 2)
+    return N + nimp + N * N + (N * N if isinstance(process, ContinuousNetworkHawkesProcess) else 0)
+
+
+def _moments_in_params_order(process, s, q, count, network, rho_sum, rho_sq):
+    """Σx, Σx² in the device order -> mean and mean square in params(process) order."""
+    N = process.ndims()
+    nimp = N * N * (1 if isinstance(process.impulses, ExponentialImpulseResponse) else 2)
+    n = max(1, count)
     mean, m2 = s / n, q / n
     if network:        # device order [λ0; impulses; W; vec(A)] -> params(process) = [ρ; λ0; W; impulses; vec(A)] (src/continuous.jl:325-333)
         k = len(process.network.params())
@@ -228,7 +248,7 @@ def _fetch_moments(process, model, ctx, network, rho_sum, rho_sq):
         def order(v, rho):
             return np.concatenate([np.full(k, rho), v[:a], v[b:c], v[a:b], v[c:]])
         mean, m2 = order(mean, rho_sum / n), order(m2, rho_sq / n)
-    return mean, m2, cnt.value
+    return mean, m2
 
 
 def _owned_mask(process, shard, network):
@@ -249,7 +269,7 @@ def _merge_shards(process, shard, network):
     """After a sharded chain every rank holds the final values of its own columns: put the full state on every rank."""
     from .sharded import _all_reduce_sum
     N = process.ndims()
-    full = _all_reduce_sum(process.params() * _owned_mask(process, shard, network))
+    full = _all_reduce_sum(process.params() * _owned_mask(process, shard, network), shard.ctx)
     k = len(process.network.params()) if network else 0
     nimp = N * N * (1 if isinstance(process.impulses, ExponentialImpulseResponse) else 2)
     process.baseline.λ = full[k:k + N].copy()
@@ -284,6 +304,7 @@ def mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, keep_
     is the scalar link count the network's ρ update needs, and at the end the ranks' columns (and moments) are merged."""
     import ctypes as C
     from .sharded import ShardedDataset, _all_reduce_sum
+    from .components import BernoulliNetworkModel, DenseNetworkModel
     shard = data if isinstance(data, ShardedDataset) else None
     if not isinstance(process.baseline, HomogeneousProcess):
         device_draws = False      # nhp_cont_gibbs_step draws the homogeneous λ0; the LGCP curve is a host slice loop
@@ -296,28 +317,74 @@ def mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, keep_
     rng = np.random.default_rng(seed)
     res = MarkovChainMonteCarlo()
     start = time.time()
+    lib = _lib.lib()
     model = process.device_model(ctx) if device_draws else None
     pri = _priors(process) if device_draws else None
     network = isinstance(process, ContinuousNetworkHawkesProcess)
-    rho_sum = rho_sq = 0.0
+    # the network's link probability lives on the device too (nhp_cont_model_set_rho): ρ ~ Beta(α + ΣA, β + N² - ΣA) is
+    # drawn there (src/networks.jl:70-78), so a network step needs no synchronisation; DenseNetworkModel keeps ρ = 1
+    net = process.network if network else None
+    net_a, net_b = (net.α, net.β) if isinstance(net, BernoulliNetworkModel) else (0.0, 0.0)
+    device_net = device_draws and isinstance(net, (BernoulliNetworkModel, DenseNetworkModel))
+    if device_net:
+        _lib.check(lib.nhp_cont_model_set_rho(ctx.h, model.h, net.ρ if isinstance(net, BernoulliNetworkModel) else 1.0), ctx.h)
+    comm = _lib.comm_for(ctx) if shard is not None else None
+    host_exchange = shard is not None and shard.world > 1 and comm is None        # gloo rehearsal: link counts through the host
     if moments:
-        _lib.check(_lib.lib().nhp_cont_model_moments_reset(ctx.h, model.h), ctx.h)
+        _lib.check(lib.nhp_cont_model_moments_reset(ctx.h, model.h), ctx.h)
+
+    def pull_rho():
+        if device_net and isinstance(net, BernoulliNetworkModel):
+            r3 = np.empty(3)
+            _lib.check(lib.nhp_cont_model_get_rho(ctx.h, model.h, _lib.dptr(r3)), ctx.h)
+            net.ρ = float(r3[0])
+            return r3
+        return np.zeros(3)
+
+    def pull_adjacency():
+        N = process.ndims()
+        A = np.empty(N * N)
+        _lib.check(lib.nhp_cont_model_get_adjacency(ctx.h, model.h, _lib.dptr(A), N * N), ctx.h)
+        process.adjacency_matrix = A.reshape((N, N), order="F")
+
+    # The whole chain inside the library (nhp_cont_mcmc_run: the body of src/inference.jl:55-62, one synchronisation per
+    # call) when no step needs the host: no samples kept, device-side network.  `verbose` cuts it at the log points.
+    resident = device_draws and not keep_samples and (not network or device_net) and not host_exchange
+    if resident:
+        while res.steps < nsteps:
+            n = min(nsteps - res.steps, log_freq if verbose else nsteps)
+            _lib.check(lib.nhp_cont_mcmc_run(ctx.h, comm.h if comm is not None else None, ds.h, model.h, C.byref(pri), net_a, net_b,
+                                             seed, res.steps, n, burn if moments else -1), ctx.h)
+            res.steps += n
+            if verbose and res.steps % log_freq == 0:
+                res.elapsed = time.time() - start
+                print(f" > step: {res.steps}, elapsed: {res.elapsed}")
+        _pull_params(process, model, ctx)
+        if network:
+            pull_adjacency()
+            pull_rho()
     while res.steps < nsteps:
         if device_draws:
-            _lib.check(_lib.lib().nhp_cont_gibbs_step(ctx.h, ds.h, model.h, C.byref(pri), seed, res.steps), ctx.h)
-            if isinstance(process, ContinuousNetworkHawkesProcess):
-                last = keep_samples or res.steps == nsteps - 1
+            _lib.check(lib.nhp_cont_gibbs_step(ctx.h, ds.h, model.h, C.byref(pri), seed, res.steps), ctx.h)
+            last = keep_samples or res.steps == nsteps - 1
+            if network and device_net and not host_exchange:
+                _lib.check(lib.nhp_cont_network_step(ctx.h, comm.h if comm is not None else None, ds.h, model.h, net_a, net_b,
+                                                     seed, res.steps), ctx.h)
+            elif network and device_net:                     # ranks without an RCCL clique: the one exchange of a step, by hand
+                nl = C.c_double()
+                _lib.check(lib.nhp_cont_network_sweep(ctx.h, ds.h, model.h, seed, res.steps, C.byref(nl)), ctx.h)
+                links = float(_all_reduce_sum(np.array([nl.value]), ctx)[0])
+                _lib.check(lib.nhp_cont_network_rho(ctx.h, model.h, net_a, net_b, links, float(process.ndims()) ** 2, seed, res.steps), ctx.h)
+            elif network:                                    # a network model the library does not hold: host-side ρ
                 links = resample_adjacency_matrix_(process, ds, seed=seed, step=res.steps, model=model, fetch=last, ctx=ctx)
-                if shard is not None:                        # the shards' link counts: the one exchange of a step
-                    links = float(_all_reduce_sum(np.array([links]))[0])
                 process.network.resample_links_(links, process.ndims() ** 2, rng)
             if moments and res.steps >= burn:
-                _lib.check(_lib.lib().nhp_cont_model_moments_accumulate(ctx.h, model.h), ctx.h)
-                if network:
-                    rho = float(np.mean(process.network.params()))
-                    rho_sum, rho_sq = rho_sum + rho, rho_sq + rho * rho
-            if keep_samples or res.steps == nsteps - 1:
+                _lib.check(lib.nhp_cont_model_moments_accumulate(ctx.h, model.h), ctx.h)
+            if last:
                 _pull_params(process, model, ctx)
+                if network and device_net:
+                    pull_adjacency()
+                    pull_rho()
             x = process.params() if keep_samples else None
         else:
             x = resample_(process, ds, rng, step=res.steps, seed=seed, ctx=ctx)
@@ -334,8 +401,9 @@ def mcmc_(process, data, nsteps=1000, log_freq=100, verbose=False, seed=0, keep_
     if not keep_samples:
         res.samples.append(process.params())
     if moments:
-        res.mean, res.m2, res.n = _fetch_moments(process, model, ctx, network, rho_sum, rho_sq)
+        r3 = pull_rho() if network else np.zeros(3)
+        res.mean, res.m2, res.n = _fetch_moments(process, model, ctx, network, r3[1], r3[2])
         if shard is not None and shard.world > 1:
             mask = _owned_mask(process, shard, network)
-            res.mean, res.m2 = _all_reduce_sum(res.mean * mask), _all_reduce_sum(res.m2 * mask)
+            res.mean, res.m2 = _all_reduce_sum(res.mean * mask, ctx), _all_reduce_sum(res.m2 * mask, ctx)
     return res

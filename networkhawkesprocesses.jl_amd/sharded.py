@@ -69,15 +69,22 @@ def _world():
     return 0, 1
 
 
-def _all_reduce_sum(x):
-    """Sum a float64 numpy vector over the ranks of the default process group (identity without one)."""
+def _all_reduce_sum(x, ctx=None):
+    """Sum a float64 numpy vector over the ranks of the default process group (identity without one).  On GPUs ("nccl"
+    group) the exchange is the library's own RCCL communicator of `ctx` (nhp_allreduce_sum: staged on ctx's device,
+    reduced over xGMI); the "gloo" rehearsal reduces on the CPU."""
     rank, world = _world()
     if world == 1:
         return x
+    comm = _lib.comm_for(ctx)
+    if comm is not None:
+        return comm.allreduce_sum(x)
     import torch
     import torch.distributed as dist
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(dev)
+    if dist.get_backend() == "nccl":          # (unreachable: comm_for serves every nccl group) stage on OUR device
+        t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(torch.device("cuda", (ctx or _lib.default_context()).device))
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64).copy())
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()
 
@@ -103,17 +110,34 @@ def sharded_loglikelihood(process, data, recursive=True, ctx=None, model=None):
     """loglikelihood(process, data; recursive) evaluated by all ranks together: each rank its columns, one scalar
     all-reduce.  `data` is the (events, nodes, duration) tuple or a ShardedDataset; every rank returns the same value.
     Without a process group this is `loglikelihood`."""
-    from .continuous import loglikelihood
+    import ctypes as C
+    from .continuous import loglikelihood, _check_recursive
     sd = data if isinstance(data, ShardedDataset) else ShardedDataset(process, data, ctx)
+    comm = _lib.comm_for(sd.ctx)
+    if comm is not None:                      # partial result all-reduced where the kernel left it (device, RCCL), fetched once
+        model = model or process.device_model(sd.ctx)
+        ll = C.c_double()
+        _lib.check(_lib.lib().nhp_cont_loglik_allreduce(sd.ctx.h, comm.h, sd.local.h, model.h, _check_recursive(process, recursive),
+                                                        C.byref(ll)), sd.ctx.h)
+        return ll.value
     part = loglikelihood(process, sd.local, recursive=recursive, ctx=sd.ctx, model=model)
-    return float(_all_reduce_sum(np.array([part]))[0])
+    return float(_all_reduce_sum(np.array([part]), sd.ctx)[0])
 
 
 def sharded_loglikelihood_gradient(process, data, recursive=True, ctx=None, model=None):
     """(ll, ∇ll) in params! order, each rank its columns (the rest of its gradient is exactly 0), one all-reduce of
     [ll; ∇ll]."""
-    from .continuous import loglikelihood_gradient
+    import ctypes as C
+    from .continuous import loglikelihood_gradient, _check_recursive, gradient_length
     sd = data if isinstance(data, ShardedDataset) else ShardedDataset(process, data, ctx)
+    comm = _lib.comm_for(sd.ctx)
+    if comm is not None:                      # [ll; ∇ll] all-reduced on the device: one download, already summed
+        model = model or process.device_model(sd.ctx)
+        P = gradient_length(process)
+        g, ll = np.empty(P), C.c_double()
+        _lib.check(_lib.lib().nhp_cont_loglik_grad_allreduce(sd.ctx.h, comm.h, sd.local.h, model.h, _check_recursive(process, recursive),
+                                                             C.byref(ll), _lib.dptr(g), P), sd.ctx.h)
+        return ll.value, g
     ll, g = loglikelihood_gradient(process, sd.local, recursive=recursive, ctx=sd.ctx, model=model)
-    tot = _all_reduce_sum(np.concatenate([[ll], g]))
+    tot = _all_reduce_sum(np.concatenate([[ll], g]), sd.ctx)
     return float(tot[0]), tot[1:]

@@ -517,17 +517,22 @@ static double adj_integrated_intensity(const orc_cont_model *m, int32_t node0, c
     return I;
 }
 
-int orc_cont_resample_adjacency(const orc_cont_model *m, const double *times, const int64_t *nodes,
-                                int64_t M, double duration, const double *rho, const double *u, double *A)
+/* Columns [c0, c1) only: resample_column! (src/continuous.jl:466-487) reads and writes column c of the matrix
+ * alone (integrated_intensity :489-498 and sum_log_intensity :500-519 are per child node), so a subset of the
+ * columns gets the values the whole sweep gives it -- what the full-size parity tests use. */
+int orc_cont_resample_adjacency_columns(const orc_cont_model *m, const double *times, const int64_t *nodes,
+                                        int64_t M, double duration, const double *rho, const double *u, double *A,
+                                        int32_t c0, int32_t c1)
 {
     int rc = validate_data(m, times, nodes, M);
     if (rc) return rc;
     int32_t N = m->n_nodes;
+    if (c0 < 0 || c1 > N || c0 > c1) return ORC_EINVAL;
     orc_cont_model w = *m;
     w.A = A;                                             /* work on the caller's matrix in place */
     double *cnt = (double *)malloc(sizeof(double) * (size_t)N);
     orc_node_counts(nodes, M, N, cnt);
-    for (int32_t c = 0; c < N; ++c)
+    for (int32_t c = c0; c < c1; ++c)
         for (int32_t p = 0; p < N; ++p) {
             size_t k = IDX(p, c, N);
             A[k] = 0.0;
@@ -544,6 +549,12 @@ int orc_cont_resample_adjacency(const orc_cont_model *m, const double *times, co
         }
     free(cnt);
     return ORC_OK;
+}
+
+int orc_cont_resample_adjacency(const orc_cont_model *m, const double *times, const int64_t *nodes,
+                                int64_t M, double duration, const double *rho, const double *u, double *A)
+{
+    return orc_cont_resample_adjacency_columns(m, times, nodes, M, duration, rho, u, A, 0, m->n_nodes);
 }
 
 /* ------------------------------------------------------------------ analytic gradient

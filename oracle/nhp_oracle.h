@@ -97,6 +97,10 @@ void orc_log_duration_stats(const double *times, const int64_t *nodes, const int
  * ([3P] Distributions: rand(Bernoulli(q)) = rand() <= q); rho[p + c*N] the link probability. */
 int orc_cont_resample_adjacency(const orc_cont_model *m, const double *times, const int64_t *nodes,
                                 int64_t M, double duration, const double *rho, const double *u, double *A);
+/* the same sweep restricted to columns [c0, c1) (columns are independent, src/continuous.jl:460-487) */
+int orc_cont_resample_adjacency_columns(const orc_cont_model *m, const double *times, const int64_t *nodes,
+                                        int64_t M, double duration, const double *rho, const double *u, double *A,
+                                        int32_t c0, int32_t c1);
 
 /* ---- discrete Gibbs parent counts (src/parents.jl:82-134), counts[c + N*k], k = 0 baseline, 1 + p*B + b */
 int orc_disc_resample_parents(const int64_t *data, const double *conv, int64_t T, int32_t N, int32_t B,

@@ -240,6 +240,16 @@ def resample_adjacency(model, times, nodes, duration, rho, u):
     return A.reshape(model.A.shape, order="F")
 
 
+def resample_adjacency_columns(model, times, nodes, duration, rho, u, c0, c1):
+    """The same sweep for the 0-based columns [c0, c1) only (columns are independent); other columns come back unchanged."""
+    t, n, tp, np_, M = _data(times, nodes)
+    A = _col(model.A).copy()
+    r, uu = _col(np.broadcast_to(rho, model.A.shape)), _col(u)
+    _chk(lib().orc_cont_resample_adjacency_columns(C.byref(model.c), tp, np_, M, C.c_double(duration), _p(r), _p(uu), _p(A),
+                                                   C.c_int32(c0), C.c_int32(c1)))
+    return A.reshape(model.A.shape, order="F")
+
+
 def lgcp_loglik(times, nodes, parentnodes, N, grid_x, lam):
     """ll[c] of the baseline-attributed events of every node under candidate grid intensities lam [N, G]."""
     t, n, tp, np_, M = _data(times, nodes)

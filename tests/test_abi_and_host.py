@@ -35,7 +35,36 @@ def test_every_declared_symbol_is_exported(lib):
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     lib.nhp_abi_version.restype = C.c_int32
-    assert lib.nhp_abi_version() == 1
+    assert lib.nhp_abi_version() == 2
+
+
+def test_struct_layouts_match_the_library(lib, nhp):
+    """nhp_abi_layout(): sizeof / offsetof of every struct that crosses the boundary, as compiled into libnhp.so.  The
+    ctypes Structures of _lib.py are asserted against it at load time (check_layout); the same numbers are written next
+    to the Julia structs of julia/NetworkHawkesHIP.jl, which no machine here can execute -- this pins them too."""
+    from nhp_amd import _lib
+    got = _lib.check_layout(lib)
+    # x86-64 / LP64 layout the Julia shim documents: nhp_cont_model_desc 80 bytes, nhp_gibbs_priors 64, nhp_cont_stats 40
+    assert got == [80, 0, 4, 8, 16, 24, 28, 32, 40, 48, 56, 64, 72,
+                   64, 0, 8, 16, 24, 32, 40, 48, 56,
+                   40, 0, 8, 16, 24, 32,
+                   4096, 128]
+    text = open(os.path.join(PKG, "julia", "NetworkHawkesHIP.jl"), encoding="utf-8").read()
+    assert "ABI_LAYOUT" in text
+    listed = re.search(r"const ABI_LAYOUT = Int32\[(.*?)\]", text, flags=re.S).group(1)
+    assert [int(v) for v in re.findall(r"-?\d+", listed)] == got
+
+
+def test_rccl_entry_points_fail_cleanly_without_a_communicator(lib):
+    """No GPU here: the collectives must refuse a NULL communicator / context with a status, not crash (RCCL itself is only
+    dlopen'ed when a communicator is created)."""
+    lib.nhp_allreduce_sum.restype = C.c_int32
+    x = np.ones(3)
+    assert lib.nhp_allreduce_sum(None, None, x.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(3)) == 1     # NHP_EINVAL
+    lib.nhp_comm_rank.restype = C.c_int32
+    assert lib.nhp_comm_rank(None) == -1
+    out = subprocess.run(["ldd", os.path.join(PKG, "libnhp.so")], capture_output=True, text=True).stdout
+    assert "rccl" not in out                    # opened on first use, not a load-time dependency
 
 
 def test_no_gpu_means_a_loud_error_not_a_fallback(lib, nhp):
