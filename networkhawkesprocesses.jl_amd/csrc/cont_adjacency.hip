@@ -112,7 +112,12 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_build(nhp_cont_args a, const 
         auto fits = [&](int q, int id) {                 // list of q: <= 16 entries, children unseen in group id
             const int eb = start[q], ee = start[q + 1];
             if (ee - eb > 16) return false;
-            for (int e = eb; e < ee; ++e) if (seen[ent_k[base + e]] == id) return false;
+            for (int e = eb; e < ee; ++e) {
+                const int ke = ent_k[base + e];
+                if (seen[ke] == id) return false;
+                for (int e2 = eb; e2 < e; ++e2)           // a child named twice in q's OWN list: general path (found by the
+                    if (ent_k[base + e2] == ke) return false;   // full-size parity test: a grouped member summed its two entries apart)
+            }
             return true;
         };
         auto take = [&](int q, int id) { for (int e = start[q]; e < start[q + 1]; ++e) seen[ent_k[base + e]] = id; };

@@ -171,11 +171,12 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
             nhp_event en[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) en[u] = a.ev[j[u] - G > 0 ? j[u] - G : 0];
+            asm volatile("" ::: "memory");          // keeps the prefetch a prefetch (see k_windowed_batch)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const double dt = t[u] - e[u].t;
                 const double2 q = col[e[u].node];
-                if (IMP == NHP_IMPULSE_EXPONENTIAL) s[u] += q.y * nhp_pdf_exponential(q.x, dt);
+                if (IMP == NHP_IMPULSE_EXPONENTIAL) s[u] += q.y * nhp_pdf_exponential_ll(q.x, dt);
                 else s[u] += colw[e[u].node] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
                 j[u] -= G;
                 e[u] = en[u];
@@ -190,13 +191,17 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
             nhp_event en[U];                       // next iteration's parents, in flight under the math
 #pragma unroll
             for (int u = 0; u < U; ++u) en[u] = a.ev[j[u] - G > 0 ? j[u] - G : 0];
+            // Wide groups (long windows): keep the prefetch a prefetch (see k_windowed_batch).  Narrow groups run one or two
+            // trips per child: there the compiler's folding of the prefetch into the consuming trip SAVES the load a last
+            // trip would waste (K = 8: 41.5 us folded, 52.7 us with the barrier).
+            if (G >= 16) asm volatile("" ::: "memory");
             more = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const double dt = t[u] - e[u].t;
                 const double2 q = col[e[u].node];
                 double term;
-                if (IMP == NHP_IMPULSE_EXPONENTIAL) term = q.y * nhp_pdf_exponential(q.x, dt);
+                if (IMP == NHP_IMPULSE_EXPONENTIAL) term = q.y * nhp_pdf_exponential_ll(q.x, dt);
                 else term = colw[e[u].node] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
                 s[u] += (j[u] >= f[u]) ? term : 0.0;
                 j[u] -= G;
@@ -268,9 +273,10 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
 // in ONE pass over the data: S columns of the tables sit in LDS, every parent record is fetched once and used S
 // times.  Same arithmetic per model as k_windowed (same item layout, same per-child lane order); the logs of a
 // round are taken by all lanes from a small LDS buffer.
+#define NHP_MULTI_MAX 8
 struct nhp_multi {
-    const double *p1[4], *p2[4], *W[4], *A[4], *lambda0[4], *grid[4];
-    double *out[4];
+    const double *p1[NHP_MULTI_MAX], *p2[NHP_MULTI_MAX], *W[NHP_MULTI_MAX], *A[NHP_MULTI_MAX], *lambda0[NHP_MULTI_MAX], *grid[NHP_MULTI_MAX];
+    double *out[NHP_MULTI_MAX];
 };
 
 __device__ __forceinline__ double baseline_at_p(int kind, const double *lambda0, const double *x, int grid_n, int c, double t)
@@ -346,6 +352,7 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed_multi(nhp_cont_args a, 
             nhp_event en[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) en[u] = a.ev[j[u] - G > 0 ? j[u] - G : 0];
+            asm volatile("" ::: "memory");          // keeps the prefetch a prefetch (see k_windowed_batch)
             more = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -453,7 +460,7 @@ static nhp_status enqueue_multi(nhp_ctx *ctx, const nhp_cont_dataset *ds, const 
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)ds->n_items * S));
     nhp_cont_args a = nhp_make_args(ds, m0);
     nhp_multi mm;
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NHP_MULTI_MAX; ++k) {
         const nhp_cont_model *m = ms[k < S ? k : 0];
         mm.p1[k] = m->d_p1; mm.p2[k] = m->d_p2; mm.W[k] = m->d_W; mm.A[k] = m->has_A ? m->d_A : nullptr;
         mm.lambda0[k] = m->d_lambda0; mm.grid[k] = m->d_grid;
@@ -462,6 +469,209 @@ static nhp_status enqueue_multi(nhp_ctx *ctx, const nhp_cont_dataset *ds, const 
     dim3 grid((unsigned)ds->n_items);
     if (expo) launch_multi<NHP_IMPULSE_EXPONENTIAL, S>(G, grid, lds, ctx->stream, a, mm, ctx->d_partials, ctx->d_counter);
     else launch_multi<NHP_IMPULSE_LOGITNORMAL, S>(G, grid, lds, ctx->stream, a, mm, ctx->d_partials, ctx->d_counter);
+    NHP_HIP(ctx, hipGetLastError());
+    return NHP_OK;
+}
+
+// ---- S parameter sets per launch, one lane per (child, parameter set) ---------------------------------------------
+// The real callers of "log-likelihood evaluations per second" are batches: the 2P objective calls of a finite-difference
+// gradient inside mle! (src/continuous.jl:190), restarts, chain populations.  For S models on one dataset the
+// parameter-independent part of an evaluation -- the scattered gathers of the parent windows, the child records --
+// is paid once: a workgroup stages column c of all S tables in LDS (S x 16 KB at N = 1024), and lane (k, m) walks the
+// window of child k for model m, most recent parent first (the reference's own order, src/continuous.jl:290-298), with
+// no cross-lane reduction at all: the S lanes of a child load the same parent record (one request), read their own
+// model's {θ, a·w} from LDS, and keep their own sum, their own log.  What is left per evaluation is its S-independent
+// share of the gathers plus its own exponentials -- the fp64 VALU, not the fabric, becomes the bound.
+// LDS image: model m's column at m·(N+1) double2s: the +1 skews the S models of one child onto different banks.
+template <int IMP, int S, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_windowed_batch(nhp_cont_args a, nhp_multi mm, double *__restrict__ partials,
+                                                           unsigned int *__restrict__ counter)
+{
+    constexpr int U = 4, NW = THREADS / 64, CPR = THREADS / S;      // children per round and slot
+    static_assert(S == 2 || S == 4 || S == 8, "lane = (child, model) with S a power of two <= 8");
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *red = reinterpret_cast<double *>(smem);                 // [2][NW][S] wave sums, then the flag
+    int *flag = reinterpret_cast<int *>(red + 2 * NW * S);
+    double2 *col = reinterpret_cast<double2 *>(smem + 16 * (NW * S + 1));     // [S][N+1]
+    const int N = a.N, NP = N + 1, tid = threadIdx.x;
+    double *colw = reinterpret_cast<double *>(col + (size_t)S * NP);           // [S][N+1], logit-normal only
+    const nhp_item it = a.items[blockIdx.x];
+    const int c = it.node;
+    const int m = tid % S, kslot = tid / S;
+
+    // ---- stage column c of the S models; the node's first item also owns the columns' integral terms
+    double integ = 0.0;                                             // lane's share, model by model below
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+        double part = 0.0;
+        for (int p = tid; p < N; p += THREADS) {
+            const size_t k = (size_t)p + (size_t)c * N;
+            double w = mm.W[q][k];
+            if (mm.A[q]) w = mm.A[q][k] * w;                         // windowed path: the integral is masked too
+            if (IMP == NHP_IMPULSE_EXPONENTIAL) {
+                col[(size_t)q * NP + p] = make_double2(mm.p1[q][k], w);
+            } else {
+                col[(size_t)q * NP + p] = make_double2(mm.p1[q][k], __builtin_sqrt(mm.p2[q][k]));
+                colw[(size_t)q * NP + p] = w;
+            }
+            if (it.first) part += a.cnt[p] * w;
+        }
+        // model q's integral share of this wave -> the lane whose model is q (lane q of the wave; others add 0)
+        part = nhp_wave_sum(part);
+        if ((tid & 63) == q) integ = part;
+    }
+    __syncthreads();
+
+    const double2 *mycol = col + (size_t)m * NP;
+    const double *mycolw = colw + (size_t)m * NP;
+    const double *l0 = mm.lambda0[m], *gx = mm.grid[m];
+    const int nchild = it.kend - it.kbeg;
+    double acc = 0.0;                                               // Σ log λ of model m over this lane's children
+    for (int r0 = 0; r0 < nchild; r0 += CPR * U) {
+        double t[U], s[U];
+        int j[U], f[U];
+        bool valid[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // a wave's 64/S children of slot u are contiguous in the item's window-sorted order; odd rounds hand the
+            // chunks out in reverse wave order (serpentine), so every wave gets long and short windows alike -- the
+            // workgroup (the only one on its CU: the S columns fill the LDS) ends when its slowest wave does
+            const int wq = kslot / (64 / S);
+            const int wsel = ((r0 / (CPR * U)) & 1) ? (NW - 1 - wq) : wq;
+            const int kk = r0 + wsel * (64 / S) * U + u * (64 / S) + (kslot % (64 / S));
+            valid[u] = kk < nchild;
+            const nhp_child ch = a.child_w[it.kbeg + (valid[u] ? kk : r0)];
+            t[u] = ch.t;
+            j[u] = ch.idx - 1;
+            f[u] = valid[u] ? ch.first : 0x7fffffff;
+            s[u] = 0.0;
+        }
+        bool more = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) more |= j[u] >= f[u];
+        nhp_event e[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) e[u] = a.ev[j[u] > 0 ? j[u] : 0];
+        while (more) {
+            nhp_event en[U];                                        // the next parents, in flight under the math
+#pragma unroll
+            for (int u = 0; u < U; ++u) en[u] = a.ev[j[u] - 1 > 0 ? j[u] - 1 : 0];
+            // compiler-level memory barrier: without it InstCombine folds phi(load, load) into a load of phi'd addresses at the
+            // loop head -- i.e. it moves these prefetches to where they are consumed, one full memory latency per iteration
+            asm volatile("" ::: "memory");
+            more = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double dt = t[u] - e[u].t;
+                const double2 q = mycol[e[u].node];
+                double term;
+                if (IMP == NHP_IMPULSE_EXPONENTIAL) term = q.y * nhp_pdf_exponential_ll(q.x, dt);
+                else term = mycolw[e[u].node] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
+                s[u] += (j[u] >= f[u]) ? term : 0.0;
+                j[u] -= 1;
+                more |= j[u] >= f[u];
+                e[u] = en[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double lam = baseline_at_p(a.baseline_kind, l0, gx, a.grid_n, c, t[u]) + s[u];
+            acc += valid[u] ? nhp_log(lam) : 0.0;
+        }
+    }
+    // ---- per-model sums: lanes with equal (lane % S) inside the wave, then the waves in a fixed order
+    for (int off = S; off < 64; off <<= 1) acc += __shfl_xor(acc, off, 64);
+    const int wv = tid >> 6, ln = tid & 63;
+    if (ln < S) { red[wv * S + ln] = acc; red[(NW + wv) * S + ln] = integ; }
+    __syncthreads();
+    if (tid < S) {
+        double blk = 0.0, blk_int = 0.0;
+        for (int w = 0; w < NW; ++w) { blk += red[w * S + tid]; blk_int += red[(NW + w) * S + tid]; }
+        __hip_atomic_store(&partials[(2 * (size_t)blockIdx.x) * S + 2 * tid], blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&partials[(2 * (size_t)blockIdx.x) * S + 2 * tid + 1], blk_int, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();                                                // every storing lane has drained before the ticket
+    if (tid == 0) {
+        const unsigned int nb = gridDim.x, sh = blockIdx.x % NHP_SHARDS;
+        const unsigned int pop = (nb - sh + NHP_SHARDS - 1) / NHP_SHARDS;
+        const unsigned int used = nb < NHP_SHARDS ? nb : NHP_SHARDS;
+        int last = 0;
+        if (__hip_atomic_fetch_add(&counter[32 * (1 + sh)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pop - 1)
+            last = __hip_atomic_fetch_add(&counter[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == used - 1;
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    // the last workgroup adds all partials of model (tid % S) in a fixed order; lane groups of THREADS / S per model
+    {
+        double sl = 0.0, si = 0.0;
+        for (unsigned int i = kslot; i < gridDim.x; i += CPR) {
+            sl += __hip_atomic_load(&partials[(2 * (size_t)i) * S + 2 * m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            si += __hip_atomic_load(&partials[(2 * (size_t)i) * S + 2 * m + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // baseline integral of model m, spread over the CPR lanes of the model
+        double sb = 0.0;
+        for (int cc = a.col_begin + kslot; cc < a.col_end; cc += CPR) {
+            if (a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) {
+                sb += l0[cc] * a.duration;
+            } else {
+                const double *y = l0 + (size_t)cc * a.grid_n;
+                double I = 0.0;
+                for (int i = 0; i + 1 < a.grid_n; ++i) I += 0.5 * (y[i] + y[i + 1]) * (gx[i + 1] - gx[i]);
+                sb += I;
+            }
+        }
+        for (int off = S; off < 64; off <<= 1) {
+            sl += __shfl_xor(sl, off, 64); si += __shfl_xor(si, off, 64); sb += __shfl_xor(sb, off, 64);
+        }
+        __syncthreads();
+        double *r3 = reinterpret_cast<double *>(col);               // the columns are dead: [3][NW][S]
+        if (ln < S) { r3[wv * S + ln] = sl; r3[(NW + wv) * S + ln] = si; r3[(2 * NW + wv) * S + ln] = sb; }
+        __syncthreads();
+        if (tid < S) {
+            double tl = 0.0, ti = 0.0, tb = 0.0;
+            for (int w = 0; w < NW; ++w) { tl += r3[w * S + tid]; ti += r3[(NW + w) * S + tid]; tb += r3[(2 * NW + w) * S + tid]; }
+            *mm.out[tid] = (0.0 - tb) - ti + tl;
+        }
+    }
+    if (tid <= NHP_SHARDS) __hip_atomic_store(&counter[32 * tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int S>
+static size_t batch_lds(const nhp_cont_dataset *ds, bool expo, int threads)
+{
+    const size_t cols = (expo ? 16 : 24) * (size_t)(ds->N + 1) * S, tail = 24 * (size_t)(threads / 64) * S;   // the finalizing
+    return 16 * ((size_t)(threads / 64) * S + 1) + (cols > tail ? cols : tail);                                     // workgroup reuses the columns
+
+}
+
+// S models (2, 4 or 8) of identical kinds on one dataset, results into ctx->d_results[slot0 .. slot0+S)
+template <int S>
+static nhp_status enqueue_batch(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *const *ms, int32_t slot0)
+{
+    constexpr int THREADS = 1024;
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    const nhp_cont_model *m0 = ms[0];
+    const bool expo = m0->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
+    const size_t lds = batch_lds<S>(ds, expo, THREADS);
+    NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)ds->n_items * S));
+    nhp_cont_args a = nhp_make_args(ds, m0);
+    nhp_multi mm;
+    for (int k = 0; k < NHP_MULTI_MAX; ++k) {
+        const nhp_cont_model *m = ms[k < S ? k : 0];
+        mm.p1[k] = m->d_p1; mm.p2[k] = m->d_p2; mm.W[k] = m->d_W; mm.A[k] = m->has_A ? m->d_A : nullptr;
+        mm.lambda0[k] = m->d_lambda0; mm.grid[k] = m->d_grid;
+        mm.out[k] = ctx->d_results + slot0 + (k < S ? k : 0);
+    }
+    dim3 grid((unsigned)ds->n_items);
+    if (expo) {
+        if (lds > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_windowed_batch<NHP_IMPULSE_EXPONENTIAL, S, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_windowed_batch<NHP_IMPULSE_EXPONENTIAL, S, THREADS>), grid, dim3(THREADS), lds, ctx->stream, a, mm, ctx->d_partials, ctx->d_counter);
+    } else {
+        if (lds > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_windowed_batch<NHP_IMPULSE_LOGITNORMAL, S, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_windowed_batch<NHP_IMPULSE_LOGITNORMAL, S, THREADS>), grid, dim3(THREADS), lds, ctx->stream, a, mm, ctx->d_partials, ctx->d_counter);
+    }
     NHP_HIP(ctx, hipGetLastError());
     return NHP_OK;
 }
@@ -597,7 +807,8 @@ extern "C" nhp_status nhp_cont_loglik_batch(nhp_ctx *ctx, const nhp_cont_dataset
     if (!models || !ll || nb < 0) return NHP_EINVAL;
     // windowed evaluations at short windows are bound by gathers that do not depend on the parameters: take the models
     // four (or two) at a time through one pass over the data; everything else goes one launch per model
-    static const int fuse = getenv("NHP_BATCH_FUSE") ? atoi(getenv("NHP_BATCH_FUSE")) : 4;      // largest group: 0/1 off, 2, 4
+    static const int fuse = getenv("NHP_BATCH_FUSE") ? atoi(getenv("NHP_BATCH_FUSE")) : 8;      // largest group: 0/1 off, 2, 4, 8
+    static const bool batch_kernel = getenv("NHP_BATCH_KERNEL") ? atoi(getenv("NHP_BATCH_KERNEL")) != 0 : true;   // 0: the older k_windowed_multi
     static const bool two_lanes = getenv("NHP_BATCH_LANES") ? atoi(getenv("NHP_BATCH_LANES")) >= 2 : true;
     const double kbar = ds && ds->M > 0 ? (double)ds->pairs / (double)ds->M : 0.0;
     // Windowed launches alternate between the context's two lanes (stream + partial sums + tickets each): they are
@@ -619,11 +830,27 @@ extern "C" nhp_status nhp_cont_loglik_batch(nhp_ctx *ctx, const nhp_cont_dataset
             const nhp_cont_model *const *ms = models + done + k;
             const bool windowed = ms[0] && !((flags & NHP_LL_RECURSIVE) && ms[0]->impulse_kind == NHP_IMPULSE_EXPONENTIAL);
             int take = 1;
-            if (fuse >= 2 && windowed && kbar <= 48.0 && ds && ds->N >= 1) {
+            bool lane_kernel = false;                      // k_windowed_batch (one lane per (child, model)) vs k_windowed_multi
+            if (fuse >= 2 && windowed && kbar <= 96.0 && ds && ds->N >= 1) {
                 NHP_TRY(nhp_check_pair(ctx, ds, ms[0]));
-                if (fuse >= 4 && k + 4 <= n && multi_compatible(ds, ms[0], ms[1], 80 * 1024, 4) && multi_compatible(ds, ms[0], ms[2], 80 * 1024, 4) &&
-                    multi_compatible(ds, ms[0], ms[3], 80 * 1024, 4)) take = 4;
-                else if (k + 2 <= n && multi_compatible(ds, ms[0], ms[1], 64 * 1024, 2)) take = 2;
+                const bool expo0 = ms[0]->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
+                auto all_compatible = [&](int S) {
+                    if (k + S > n) return false;
+                    for (int q = 1; q < S; ++q)
+                        if (!multi_compatible(ds, ms[0], ms[q], (size_t)1 << 30, S)) return false;
+                    return true;
+                };
+                if (batch_kernel) {
+                    const size_t cap = 160 * 1024;
+                    if (fuse >= 8 && all_compatible(8) && batch_lds<8>(ds, expo0, 1024) <= cap) take = 8;
+                    else if (fuse >= 4 && all_compatible(4) && batch_lds<4>(ds, expo0, 1024) <= cap) take = 4;
+                    else if (all_compatible(2) && batch_lds<2>(ds, expo0, 1024) <= cap) take = 2;
+                    lane_kernel = take > 1;
+                } else if (kbar <= 48.0) {
+                    if (fuse >= 4 && k + 4 <= n && multi_compatible(ds, ms[0], ms[1], 80 * 1024, 4) && multi_compatible(ds, ms[0], ms[2], 80 * 1024, 4) &&
+                        multi_compatible(ds, ms[0], ms[3], 80 * 1024, 4)) take = 4;
+                    else if (k + 2 <= n && multi_compatible(ds, ms[0], ms[1], 64 * 1024, 2)) take = 2;
+                }
             }
             const bool second = two_lanes && windowed && ctx && ctx->stream2 && (launches & 1);
             if (second) {
@@ -634,8 +861,12 @@ extern "C" nhp_status nhp_cont_loglik_batch(nhp_ctx *ctx, const nhp_cont_dataset
                 }
                 lane.flip();
             }
-            if (take == 4) { for (int q = 1; q < 4; ++q) NHP_TRY(nhp_check_pair(ctx, ds, ms[q])); NHP_TRY(enqueue_multi<4>(ctx, ds, ms, k)); }
-            else if (take == 2) { NHP_TRY(nhp_check_pair(ctx, ds, ms[1])); NHP_TRY(enqueue_multi<2>(ctx, ds, ms, k)); }
+            for (int q = 1; q < take; ++q) NHP_TRY(nhp_check_pair(ctx, ds, ms[q]));
+            if (take == 8) NHP_TRY(enqueue_batch<8>(ctx, ds, ms, k));
+            else if (take == 4 && lane_kernel) NHP_TRY(enqueue_batch<4>(ctx, ds, ms, k));
+            else if (take == 2 && lane_kernel) NHP_TRY(enqueue_batch<2>(ctx, ds, ms, k));
+            else if (take == 4) NHP_TRY(enqueue_multi<4>(ctx, ds, ms, k));
+            else if (take == 2) NHP_TRY(enqueue_multi<2>(ctx, ds, ms, k));
             else NHP_TRY(enqueue(ctx, ds, ms[0], flags, k));
             if (second) lane.flip();
             if (windowed) ++launches;

@@ -26,6 +26,34 @@ __device__ __forceinline__ double nhp_horner(double p, double r, double c)
     return d;
 }
 
+// The whole degree-13 Horner chain of nhp_exp as ONE asm statement.  Same thirteen IEEE fmas in the same order as thirteen
+// nhp_horner() calls (det-math contract untouched), but gfx950's hazard recognizer pads every inline-asm result that the next
+// instruction reads with an `s_nop` (it must assume a dst_sel / cvt-scale forwarding hazard it cannot see into): one statement
+// pays that once instead of thirteen times per exponential.
+__device__ __forceinline__ double nhp_horner13(double r)
+{
+    double p;
+    const double c13 = 1.6059043836821613e-10;
+    asm("v_fma_f64 %0, %1, %2, %3\n\t"
+        "v_fma_f64 %0, %0, %2, %4\n\t"
+        "v_fma_f64 %0, %0, %2, %5\n\t"
+        "v_fma_f64 %0, %0, %2, %6\n\t"
+        "v_fma_f64 %0, %0, %2, %7\n\t"
+        "v_fma_f64 %0, %0, %2, %8\n\t"
+        "v_fma_f64 %0, %0, %2, %9\n\t"
+        "v_fma_f64 %0, %0, %2, %10\n\t"
+        "v_fma_f64 %0, %0, %2, %11\n\t"
+        "v_fma_f64 %0, %0, %2, %12\n\t"
+        "v_fma_f64 %0, %0, %2, %13\n\t"
+        "v_fma_f64 %0, %0, %2, %14\n\t"
+        "v_fma_f64 %0, %0, %2, %14"
+        : "=&v"(p)
+        : "v"(c13), "v"(r), "s"(2.08767569878681e-09), "s"(2.505210838544172e-08), "s"(2.755731922398589e-07),
+          "s"(2.7557319223985893e-06), "s"(2.48015873015873e-05), "s"(1.984126984126984e-04), "s"(1.388888888888889e-03),
+          "s"(8.333333333333333e-03), "s"(4.1666666666666664e-02), "s"(1.6666666666666666e-01), "s"(0.5), "s"(1.0));
+    return p;
+}
+
 __device__ __forceinline__ double nhp_exp(double x)
 {
 #pragma clang fp contract(off)
@@ -37,20 +65,7 @@ __device__ __forceinline__ double nhp_exp(double x)
     double n = __builtin_rint(x * LOG2E);
     double r = __builtin_fma(-n, LN2_HI, x);
     r = __builtin_fma(-n, LN2_LO, r);
-    double p = 1.6059043836821613e-10;
-    p = nhp_horner(p, r, 2.08767569878681e-09);
-    p = nhp_horner(p, r, 2.505210838544172e-08);
-    p = nhp_horner(p, r, 2.755731922398589e-07);
-    p = nhp_horner(p, r, 2.7557319223985893e-06);
-    p = nhp_horner(p, r, 2.48015873015873e-05);
-    p = nhp_horner(p, r, 1.984126984126984e-04);
-    p = nhp_horner(p, r, 1.388888888888889e-03);
-    p = nhp_horner(p, r, 8.333333333333333e-03);
-    p = nhp_horner(p, r, 4.1666666666666664e-02);
-    p = nhp_horner(p, r, 1.6666666666666666e-01);
-    p = nhp_horner(p, r, 0.5);
-    p = nhp_horner(p, r, 1.0);
-    p = nhp_horner(p, r, 1.0);
+    double p = nhp_horner13(r);
     return __builtin_ldexp(p, (int)n);
 }
 
@@ -64,22 +79,24 @@ __device__ __forceinline__ double nhp_exp_neg(double x)
     double n = __builtin_rint(x * LOG2E);
     double r = __builtin_fma(-n, LN2_HI, x);
     r = __builtin_fma(-n, LN2_LO, r);
-    double p = 1.6059043836821613e-10;
-    p = nhp_horner(p, r, 2.08767569878681e-09);
-    p = nhp_horner(p, r, 2.505210838544172e-08);
-    p = nhp_horner(p, r, 2.755731922398589e-07);
-    p = nhp_horner(p, r, 2.7557319223985893e-06);
-    p = nhp_horner(p, r, 2.48015873015873e-05);
-    p = nhp_horner(p, r, 1.984126984126984e-04);
-    p = nhp_horner(p, r, 1.388888888888889e-03);
-    p = nhp_horner(p, r, 8.333333333333333e-03);
-    p = nhp_horner(p, r, 4.1666666666666664e-02);
-    p = nhp_horner(p, r, 1.6666666666666666e-01);
-    p = nhp_horner(p, r, 0.5);
-    p = nhp_horner(p, r, 1.0);
-    p = nhp_horner(p, r, 1.0);
+    double p = nhp_horner13(r);
     double v = __builtin_ldexp(p, (int)n);
     return (x >= -708.0) ? v : 0.0;
+}
+
+// exp(x) for x <= 0 in the log-likelihood kernels: no flush -- v_ldexp_f64 underflows by itself (gradually below -708,
+// to zero below -745), so the compare and the two selects of nhp_exp_neg are saved.  Differs from nhp_exp_neg only on
+// (-745, -708), by less than 1e-307: nothing a log-likelihood registers; the sampler (bit-exact contract) keeps nhp_exp_neg.
+__device__ __forceinline__ double nhp_exp_neg_ll(double x)
+{
+#pragma clang fp contract(off)
+    const double LOG2E = 1.44269504088896338700e+00;
+    const double LN2_HI = 6.93147180369123816490e-01;
+    const double LN2_LO = 1.90821492927058770002e-10;
+    double n = __builtin_rint(x * LOG2E);
+    double r = __builtin_fma(-n, LN2_HI, x);
+    r = __builtin_fma(-n, LN2_LO, r);
+    return __builtin_ldexp(nhp_horner13(r), (int)n);
 }
 
 __device__ __forceinline__ double nhp_log(double x)
@@ -151,6 +168,16 @@ __device__ __forceinline__ double nhp_pdf_exponential(double r, double dt)
 {
 #pragma clang fp contract(off)
     return r * nhp_exp_neg(-(r * dt));
+}
+
+__device__ __forceinline__ double nhp_pdf_exponential_ll(double r, double dt)
+{
+#pragma clang fp contract(off)
+#ifdef NHP_EXP_STUB        // timing experiment only (tools/): the pair term without its exponential
+    return r * (1.0 - 1e-3 * (r * dt));
+#else
+    return r * nhp_exp_neg_ll(-(r * dt));
+#endif
 }
 
 // Logit-normal at x = Δt/Δtmax, NOT divided by Δtmax (src/impulses.jl:174-178).
