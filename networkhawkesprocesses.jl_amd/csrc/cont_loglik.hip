@@ -473,6 +473,17 @@ static nhp_status enqueue_multi(nhp_ctx *ctx, const nhp_cont_dataset *ds, const 
     return NHP_OK;
 }
 
+#ifdef NHP_STAMP      // diagnostic build only (tools/stamps.py): s_memtime at the phase boundaries of wave 0 of every workgroup
+__device__ unsigned long long g_stamps[8 * 4096];
+#define NHP_STAMP_AT(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int nhp_debug_stamps(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#else
+#define NHP_STAMP_AT(i) do { } while (0)
+#endif
+
 // ---- S parameter sets per launch, one lane per (child, parameter set) ---------------------------------------------
 // The real callers of "log-likelihood evaluations per second" are batches: the 2P objective calls of a finite-difference
 // gradient inside mle! (src/continuous.jl:190), restarts, chain populations.  For S models on one dataset the
@@ -487,103 +498,175 @@ template <int IMP, int S, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_windowed_batch(nhp_cont_args a, nhp_multi mm, double *__restrict__ partials,
                                                            unsigned int *__restrict__ counter)
 {
-    constexpr int U = 4, NW = THREADS / 64, CPR = THREADS / S;      // children per round and slot
+    constexpr int NW = THREADS / 64, CW = 64 / S;                   // waves; children a wave holds at a time
+    constexpr int CSTR = S + 1;                                     // records per child row of the window buffer (+1: bank skew)
     static_assert(S == 2 || S == 4 || S == 8, "lane = (child, model) with S a power of two <= 8");
     extern __shared__ __align__(16) unsigned char smem[];
     double *red = reinterpret_cast<double *>(smem);                 // [2][NW][S] wave sums, then the flag
     int *flag = reinterpret_cast<int *>(red + 2 * NW * S);
-    double2 *col = reinterpret_cast<double2 *>(smem + 16 * (NW * S + 1));     // [S][N+1]
+    nhp_event *wbuf = reinterpret_cast<nhp_event *>(smem + 16 * (NW * S + 1));          // [NW][CW][CSTR] staged parent records
+    double2 *col = reinterpret_cast<double2 *>(wbuf + NW * CW * CSTR);                   // [S][N+1]
     const int N = a.N, NP = N + 1, tid = threadIdx.x;
-    double *colw = reinterpret_cast<double *>(col + (size_t)S * NP);           // [S][N+1], logit-normal only
+    double *colw = reinterpret_cast<double *>(col + (size_t)S * NP);                     // [S][N+1], logit-normal only
     const nhp_item it = a.items[blockIdx.x];
     const int c = it.node;
-    const int m = tid % S, kslot = tid / S;
+    const int wv = tid >> 6, ln = tid & 63;
+    const int m = ln % S, kc = ln / S;                              // this lane's model, and child inside the wave's group
 
-    // ---- stage column c of the S models; the node's first item also owns the columns' integral terms
-    double integ = 0.0;                                             // lane's share, model by model below
+    NHP_STAMP_AT(0);
+    // ---- stage column c of the S models; the node's first item also owns the columns' integral terms.  All loads of a
+    // pass over p are issued before any is consumed: the workgroup is alone on its CU (the S columns fill the LDS), so a
+    // chain of S dependent global round trips here is time nothing else hides.
+    double integ = 0.0;                                             // lane q of every wave: the wave's share for model q
+    {
+        double part[S];
 #pragma unroll
-    for (int q = 0; q < S; ++q) {
-        double part = 0.0;
-        for (int p = tid; p < N; p += THREADS) {
+        for (int q = 0; q < S; ++q) part[q] = 0.0;
+        for (int p = tid; p < (NHP_SKIP(a, 2) ? 0 : N); p += THREADS) {
             const size_t k = (size_t)p + (size_t)c * N;
-            double w = mm.W[q][k];
-            if (mm.A[q]) w = mm.A[q][k] * w;                         // windowed path: the integral is masked too
-            if (IMP == NHP_IMPULSE_EXPONENTIAL) {
-                col[(size_t)q * NP + p] = make_double2(mm.p1[q][k], w);
-            } else {
-                col[(size_t)q * NP + p] = make_double2(mm.p1[q][k], __builtin_sqrt(mm.p2[q][k]));
-                colw[(size_t)q * NP + p] = w;
+            double w[S], a1[S], a2[S];
+#pragma unroll
+            for (int q = 0; q < S; ++q) {
+                w[q] = mm.W[q][k];
+                a1[q] = mm.p1[q][k];
+                if (IMP != NHP_IMPULSE_EXPONENTIAL) a2[q] = mm.p2[q][k];
+                if (mm.A[q]) w[q] *= mm.A[q][k];                     // windowed path: the integral is masked too
             }
-            if (it.first) part += a.cnt[p] * w;
+            const double cp = it.first ? a.cnt[p] : 0.0;
+#pragma unroll
+            for (int q = 0; q < S; ++q) {
+                if (IMP == NHP_IMPULSE_EXPONENTIAL) {
+                    col[(size_t)q * NP + p] = make_double2(a1[q], w[q]);
+                } else {
+                    col[(size_t)q * NP + p] = make_double2(a1[q], __builtin_sqrt(a2[q]));
+                    colw[(size_t)q * NP + p] = w[q];
+                }
+                part[q] += cp * w[q];
+            }
         }
-        // model q's integral share of this wave -> the lane whose model is q (lane q of the wave; others add 0)
-        part = nhp_wave_sum(part);
-        if ((tid & 63) == q) integ = part;
+        // slot N of every column: the "no parent" entry (rate 0, weight 0 -> the pair term is exactly 0) that the padding
+        // records of the window buffer point at, so the pair loop has no predicate
+        if (tid < S) {
+            col[(size_t)tid * NP + N] = make_double2(0.0, IMP == NHP_IMPULSE_EXPONENTIAL ? 0.0 : 1.0);
+            if (IMP != NHP_IMPULSE_EXPONENTIAL) colw[(size_t)tid * NP + N] = 0.0;
+        }
+        if (it.first) {                                             // workgroup-uniform
+#pragma unroll
+            for (int q = 0; q < S; ++q) {
+                const double v = nhp_wave_sum(part[q]);
+                if (ln == q) integ = v;
+            }
+        }
     }
     __syncthreads();
+    NHP_STAMP_AT(1);
 
     const double2 *mycol = col + (size_t)m * NP;
     const double *mycolw = colw + (size_t)m * NP;
     const double *l0 = mm.lambda0[m], *gx = mm.grid[m];
     const int nchild = it.kend - it.kbeg;
-    double acc = 0.0;                                               // Σ log λ of model m over this lane's children
-    for (int r0 = 0; r0 < nchild; r0 += CPR * U) {
-        double t[U], s[U];
-        int j[U], f[U];
-        bool valid[U];
+    // Σ log λ over this lane's children as ONE logarithm: log Π λ_k = log(Π mant_k) + ln2 · Σ exp_k with λ_k = mant_k · 2^exp_k
+    // (v_frexp_mant_f64 / v_frexp_exp_i32_f64, 4 instructions per child instead of the ~45 of a software fp64 log); the
+    // running product of mantissas in [0.5, 1) is renormalised after every child group.  A negative λ poisons the product
+    // with a NaN, as its logarithm would.
+    double prod = 1.0;
+    int pexp = 0;
+    const bool homog = a.baseline_kind == NHP_BASELINE_HOMOGENEOUS;
+    const double base_h = homog ? l0[c] : 0.0;
+    nhp_event *myrow = wbuf + ((size_t)wv * CW + kc) * CSTR;        // this child's staged records; as loader: slot m of the row
+
+    // The item's children are sorted by window length; groups of CW consecutive children go to the waves round by round,
+    // odd rounds in reverse wave order (serpentine), so every wave gets long and short windows alike: the workgroup -- the
+    // only one on its CU, the S columns fill the LDS -- ends when its slowest wave does.
+    const int ngroups = (nchild + CW - 1) / CW;
+    const int nrounds = NHP_SKIP(a, 1) ? 0 : (ngroups + NW - 1) / NW;
+    // group of this wave in round r (-1: none), its child record, its first chunk of parents
+    auto group_of = [&](int r) {
+        const int g = r * NW + ((r & 1) ? NW - 1 - wv : wv);
+        return (r < nrounds && g < ngroups) ? g : -1;
+    };
+    auto load_child = [&](int g) {
+        const int ci = g * CW + kc;
+        nhp_child ch = a.child_w[it.kbeg + (g >= 0 ? (ci < nchild ? ci : g * CW) : 0)];
+        if (g < 0 || ci >= nchild) ch.first = ch.idx;               // no window: every staged record is padding
+        return ch;
+    };
+    // As a LOADER this lane fetches parent number c0 + m of its child (most recent first): the S lanes of a child read S
+    // consecutive records -- one contiguous run, one request -- and park them in the child's row of the window buffer,
+    // where all S model-lanes then read them back (same address: a broadcast, no bank conflict).  Parents past the window
+    // are stored as {t, node N}: Δt = 0 on the zero-weight entry.
+    auto fetch = [&](const nhp_child &ch, int c0) {
+        const int r = c0 + m, jj = ch.idx - 1 - r;
+        nhp_event e = a.ev[jj > 0 ? jj : 0];
+        if (r >= ch.idx - ch.first) { e.t = ch.t; e.node = N; }
+        return e;
+    };
+    // Two dependent global round trips lead into a round (child record, then its parents) and a round is only a few
+    // hundred cycles of arithmetic.  Rounds are therefore taken RB at a time: all RB child records are requested, then all
+    // RB first chunks of parents, then the arithmetic of the RB rounds runs with nothing left to wait for (register
+    // arrays with compile-time indices; a rotating software pipeline would wait at every register hand-over).
+    constexpr int RB = 8;
+    for (int rb = 0; rb < nrounds; rb += RB) {
+        nhp_child chs[RB];
+        nhp_event m0s[RB];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            // a wave's 64/S children of slot u are contiguous in the item's window-sorted order; odd rounds hand the
-            // chunks out in reverse wave order (serpentine), so every wave gets long and short windows alike -- the
-            // workgroup (the only one on its CU: the S columns fill the LDS) ends when its slowest wave does
-            const int wq = kslot / (64 / S);
-            const int wsel = ((r0 / (CPR * U)) & 1) ? (NW - 1 - wq) : wq;
-            const int kk = r0 + wsel * (64 / S) * U + u * (64 / S) + (kslot % (64 / S));
-            valid[u] = kk < nchild;
-            const nhp_child ch = a.child_w[it.kbeg + (valid[u] ? kk : r0)];
-            t[u] = ch.t;
-            j[u] = ch.idx - 1;
-            f[u] = valid[u] ? ch.first : 0x7fffffff;
-            s[u] = 0.0;
-        }
-        bool more = false;
+        for (int rr = 0; rr < RB; ++rr) chs[rr] = load_child(group_of(rb + rr));
 #pragma unroll
-        for (int u = 0; u < U; ++u) more |= j[u] >= f[u];
-        nhp_event e[U];
+        for (int rr = 0; rr < RB; ++rr) m0s[rr] = fetch(chs[rr], 0);
 #pragma unroll
-        for (int u = 0; u < U; ++u) e[u] = a.ev[j[u] > 0 ? j[u] : 0];
-        while (more) {
-            nhp_event en[U];                                        // the next parents, in flight under the math
+        for (int rr = 0; rr < RB; ++rr) {
+            const int g = group_of(rb + rr);
+            if (g < 0) continue;                                    // wave-uniform
+            const nhp_child ch0 = chs[rr];
+            const bool valid = g * CW + kc < nchild;
+            const int K = ch0.idx - ch0.first;                      // parents in the window
+            const int kmax = nhp_wave_max_i32(K);                   // longest window of the wave's CW children (wave-uniform)
+            double s = 0.0;
+            nhp_event mine = m0s[rr];
+            for (int c0 = 0; c0 < kmax; c0 += S) {
+                NHP_LDS_SYNC();                                      // the previous chunk's reads precede this overwrite
+                myrow[m] = mine;
+                if (c0 + S < kmax) mine = fetch(ch0, c0 + S);        // next chunk in flight under this chunk's math
+                NHP_LDS_SYNC();
+                const int nrec = kmax - c0 < S ? kmax - c0 : S;      // wave-uniform
+                // records in pairs: the two terms of a pair are independent instruction streams the scheduler interleaves
+                // (one term is a chain of ~20 dependent fp64 operations behind two LDS reads; four waves per SIMD alone do
+                // not cover it).  The odd record of a last pair is padding at worst: zero weight, no predicate.
 #pragma unroll
-            for (int u = 0; u < U; ++u) en[u] = a.ev[j[u] - 1 > 0 ? j[u] - 1 : 0];
-            // compiler-level memory barrier: without it InstCombine folds phi(load, load) into a load of phi'd addresses at the
-            // loop head -- i.e. it moves these prefetches to where they are consumed, one full memory latency per iteration
-            asm volatile("" ::: "memory");
-            more = false;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const double dt = t[u] - e[u].t;
-                const double2 q = mycol[e[u].node];
-                double term;
-                if (IMP == NHP_IMPULSE_EXPONENTIAL) term = q.y * nhp_pdf_exponential_ll(q.x, dt);
-                else term = mycolw[e[u].node] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
-                s[u] += (j[u] >= f[u]) ? term : 0.0;
-                j[u] -= 1;
-                more |= j[u] >= f[u];
-                e[u] = en[u];
+                for (int r = 0; r < S; r += 2) {
+                    if (r < nrec && !NHP_SKIP(a, 8)) {
+                        const nhp_event e0 = myrow[r], e1 = myrow[r + 1];
+                        const double d0 = ch0.t - e0.t, d1 = ch0.t - e1.t;
+                        const double2 q0 = mycol[e0.node], q1 = mycol[e1.node];
+                        double t0, t1;
+                        if (IMP == NHP_IMPULSE_EXPONENTIAL) {
+                            t0 = q0.y * nhp_pdf_exponential_ll(q0.x, d0);
+                            t1 = q1.y * nhp_pdf_exponential_ll(q1.x, d1);
+                        } else {
+                            t0 = mycolw[e0.node] * nhp_pdf_logitnormal(q0.x, q0.y, a.inv_dtmax, d0);
+                            t1 = mycolw[e1.node] * nhp_pdf_logitnormal(q1.x, q1.y, a.inv_dtmax, d1);
+                        }
+                        s += t0;
+                        s += t1;
+                    }
+                }
             }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const double lam = baseline_at_p(a.baseline_kind, l0, gx, a.grid_n, c, t[u]) + s[u];
-            acc += valid[u] ? nhp_log(lam) : 0.0;
+            double lam = (homog ? base_h : baseline_at_p(a.baseline_kind, l0, gx, a.grid_n, c, ch0.t)) + s;
+            lam = valid ? lam : 1.0;
+            const double mt = __builtin_amdgcn_frexp_mant(lam);
+            prod *= lam < 0.0 ? __builtin_nan("") : mt;
+            pexp += __builtin_amdgcn_frexp_exp(lam) + __builtin_amdgcn_frexp_exp(prod);
+            prod = __builtin_amdgcn_frexp_mant(prod);
         }
     }
+    NHP_STAMP_AT(2);
+    double acc = nhp_log(prod) + (double)pexp * 6.93147180559945286e-01;   // (log 0 = -Inf, log NaN = NaN: as the per-child logs)
+    if (prod == 0.0) acc = -__builtin_inf();
     // ---- per-model sums: lanes with equal (lane % S) inside the wave, then the waves in a fixed order
     for (int off = S; off < 64; off <<= 1) acc += __shfl_xor(acc, off, 64);
-    const int wv = tid >> 6, ln = tid & 63;
     if (ln < S) { red[wv * S + ln] = acc; red[(NW + wv) * S + ln] = integ; }
     __syncthreads();
+    NHP_STAMP_AT(3);
     if (tid < S) {
         double blk = 0.0, blk_int = 0.0;
         for (int w = 0; w < NW; ++w) { blk += red[w * S + tid]; blk_int += red[(NW + w) * S + tid]; }
@@ -602,23 +685,27 @@ __global__ __launch_bounds__(THREADS) void k_windowed_batch(nhp_cont_args a, nhp
         *flag = last;
     }
     __syncthreads();
+    NHP_STAMP_AT(4);
     if (!*flag) return;
-    // the last workgroup adds all partials of model (tid % S) in a fixed order; lane groups of THREADS / S per model
+    // the last workgroup adds all partials of model (tid % S) in a fixed order; THREADS / S lanes per model
     {
+        constexpr int CPR = THREADS / S;
+        const int kslot = tid / S, mt = tid % S;
+        const double *l0t = mm.lambda0[mt], *gxt = mm.grid[mt];
         double sl = 0.0, si = 0.0;
         for (unsigned int i = kslot; i < gridDim.x; i += CPR) {
-            sl += __hip_atomic_load(&partials[(2 * (size_t)i) * S + 2 * m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            si += __hip_atomic_load(&partials[(2 * (size_t)i) * S + 2 * m + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sl += __hip_atomic_load(&partials[(2 * (size_t)i) * S + 2 * mt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            si += __hip_atomic_load(&partials[(2 * (size_t)i) * S + 2 * mt + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // baseline integral of model m, spread over the CPR lanes of the model
+        // baseline integral of model mt, spread over the CPR lanes of the model
         double sb = 0.0;
         for (int cc = a.col_begin + kslot; cc < a.col_end; cc += CPR) {
             if (a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) {
-                sb += l0[cc] * a.duration;
+                sb += l0t[cc] * a.duration;
             } else {
-                const double *y = l0 + (size_t)cc * a.grid_n;
+                const double *y = l0t + (size_t)cc * a.grid_n;
                 double I = 0.0;
-                for (int i = 0; i + 1 < a.grid_n; ++i) I += 0.5 * (y[i] + y[i + 1]) * (gx[i + 1] - gx[i]);
+                for (int i = 0; i + 1 < a.grid_n; ++i) I += 0.5 * (y[i] + y[i + 1]) * (gxt[i + 1] - gxt[i]);
                 sb += I;
             }
         }
@@ -626,7 +713,7 @@ __global__ __launch_bounds__(THREADS) void k_windowed_batch(nhp_cont_args a, nhp
             sl += __shfl_xor(sl, off, 64); si += __shfl_xor(si, off, 64); sb += __shfl_xor(sb, off, 64);
         }
         __syncthreads();
-        double *r3 = reinterpret_cast<double *>(col);               // the columns are dead: [3][NW][S]
+        double *r3 = reinterpret_cast<double *>(wbuf);              // window buffer + columns are dead: [3][NW][S]
         if (ln < S) { r3[wv * S + ln] = sl; r3[(NW + wv) * S + ln] = si; r3[(2 * NW + wv) * S + ln] = sb; }
         __syncthreads();
         if (tid < S) {
@@ -638,11 +725,15 @@ __global__ __launch_bounds__(THREADS) void k_windowed_batch(nhp_cont_args a, nhp
     if (tid <= NHP_SHARDS) __hip_atomic_store(&counter[32 * tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// workgroup size of k_windowed_batch: 8 sets fill the LDS of a CU with one workgroup of 16 waves; 4 (or 2) sets leave room
+// for two workgroups of 8 waves, whose latency phases (launch, staging, record fetches, reduction tail) overlap
+#define NHP_BATCH_THREADS(S) ((S) >= 8 ? 1024 : 512)
 template <int S>
 static size_t batch_lds(const nhp_cont_dataset *ds, bool expo, int threads)
 {
-    const size_t cols = (expo ? 16 : 24) * (size_t)(ds->N + 1) * S, tail = 24 * (size_t)(threads / 64) * S;   // the finalizing
-    return 16 * ((size_t)(threads / 64) * S + 1) + (cols > tail ? cols : tail);                                     // workgroup reuses the columns
+    // wave sums + flag | window buffer [waves][64/S children][S+1 records] | S columns (the finalizing workgroup reuses the
+    // window buffer for its 3 x waves x S sums: 24·waves·S <= 16·waves·(64/S)·(S+1) bytes for every S)
+    return 16 * ((size_t)(threads / 64) * S + 1) + 16 * (size_t)(threads / 64) * (64 / S) * (S + 1) + (expo ? 16 : 24) * (size_t)(ds->N + 1) * S;
 
 }
 
@@ -650,7 +741,7 @@ static size_t batch_lds(const nhp_cont_dataset *ds, bool expo, int threads)
 template <int S>
 static nhp_status enqueue_batch(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *const *ms, int32_t slot0)
 {
-    constexpr int THREADS = 1024;
+    constexpr int THREADS = NHP_BATCH_THREADS(S);
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     const nhp_cont_model *m0 = ms[0];
     const bool expo = m0->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
@@ -842,9 +933,9 @@ extern "C" nhp_status nhp_cont_loglik_batch(nhp_ctx *ctx, const nhp_cont_dataset
                 };
                 if (batch_kernel) {
                     const size_t cap = 160 * 1024;
-                    if (fuse >= 8 && all_compatible(8) && batch_lds<8>(ds, expo0, 1024) <= cap) take = 8;
-                    else if (fuse >= 4 && all_compatible(4) && batch_lds<4>(ds, expo0, 1024) <= cap) take = 4;
-                    else if (all_compatible(2) && batch_lds<2>(ds, expo0, 1024) <= cap) take = 2;
+                    if (fuse >= 8 && all_compatible(8) && batch_lds<8>(ds, expo0, NHP_BATCH_THREADS(8)) <= cap) take = 8;
+                    else if (fuse >= 4 && all_compatible(4) && batch_lds<4>(ds, expo0, NHP_BATCH_THREADS(4)) <= cap) take = 4;
+                    else if (all_compatible(2) && batch_lds<2>(ds, expo0, NHP_BATCH_THREADS(2)) <= cap) take = 2;
                     lane_kernel = take > 1;
                 } else if (kbar <= 48.0) {
                     if (fuse >= 4 && k + 4 <= n && multi_compatible(ds, ms[0], ms[1], 80 * 1024, 4) && multi_compatible(ds, ms[0], ms[2], 80 * 1024, 4) &&

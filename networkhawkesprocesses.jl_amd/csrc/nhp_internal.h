@@ -301,6 +301,20 @@ __device__ __forceinline__ double nhp_wave_sum(double v)
     return r;
 }
 
+// Maximum over the 64 lanes of a wave, in the VALU/SALU only (DPP inside rows of 16, scalar reads across rows): no LDS round trips.
+__device__ __forceinline__ int nhp_wave_max_i32(int v)
+{
+    int o;
+    o = __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); v = o > v ? o : v;      // quad_perm [1,0,3,2]
+    o = __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true); v = o > v ? o : v;      // quad_perm [2,3,0,1]
+    o = __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true); v = o > v ? o : v;     // row_half_mirror
+    o = __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true); v = o > v ? o : v;     // row_mirror
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const int ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+
 __device__ __forceinline__ double nhp_wave_sum_shfl(double v)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -255,3 +255,58 @@ def test_batch_lanes_follow_parameter_updates(nhp, orc):
     assert np.max(np.abs(out - want[0]) / abs(want[0])) < TOL
     # and a plain evaluation right after a batch uses the main stream again
     assert rel(nhp.loglikelihood(cases[3]["proc"], data, recursive=False), want[3]) < TOL
+
+
+@pytest.mark.parametrize("kind,network,lgcp", [("exponential", False, False), ("logitnormal", True, False), ("exponential", True, True)])
+@pytest.mark.parametrize("N,M,T", [(9, 2500, 120.0), (70, 9000, 40.0)])
+def test_batches_of_eight_share_one_pass(nhp, orc, kind, network, lgcp, N, M, T, monkeypatch):
+    """nhp_cont_loglik_batch with 19 compatible models: 8 + 8 + 2 + 1 through k_windowed_batch (one lane per (child, model), the
+    S columns in LDS, windows staged once per child) -- every value equals the oracle's windowed log-likelihood of its own
+    model, also with ragged windows (dense second case: windows of ~50 parents, several record chunks per child), and the
+    older 4-model kernel (NHP_BATCH_KERNEL=0) gives the same."""
+    import ctypes as C
+    from nhp_amd import _lib
+    ctx = nhp.default_context()
+    cases = [random_case(N, M, T, kind, 1.0, network=network, lgcp=lgcp, seed=s, nhp=nhp, orc=orc) for s in range(200, 219)]
+    data = cases[0]["data"]
+    ds = nhp.device_dataset(cases[0]["proc"], data, ctx)
+    models = [c["proc"].device_model(ctx) for c in cases]
+    n = len(cases)
+    arr = (C.c_void_p * n)(*[m.h for m in models])
+    out = np.empty(n)
+    _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, ds.h, arr, n, 0, _lib.dptr(out)), ctx.h)
+    want = np.array([orc.loglik_windowed(c["om"], data[0], data[1], data[2]) for c in cases])
+    assert np.max(np.abs(out - want) / np.abs(want)) < TOL
+    single = np.array([nhp.loglikelihood(c["proc"], data, recursive=False) for c in cases])
+    assert np.max(np.abs(out - single) / np.abs(single)) < 1e-13
+
+
+def test_batch_handles_empty_windows_and_degenerate_intensities(nhp, orc):
+    """Edge cases of the (child, model) kernel: children without any parent (Δtmax tiny), a node without events, fewer
+    children than one wave group, and a model whose λ is 0 somewhere (log-likelihood -Inf, as the per-child logs give)."""
+    import ctypes as C
+    from nhp_amd import _lib
+    ctx = nhp.default_context()
+    rng = np.random.default_rng(5)
+    N, M, T = 5, 40, 30.0
+    times = np.sort(rng.uniform(0, T, M))
+    nodes = rng.integers(1, N, M).astype(np.int64)           # node N never fires
+    procs, oms = [], []
+    for k in range(8):
+        lam0, W, th = rng.uniform(0.2, 1.0, N), rng.uniform(0, 0.3, (N, N)), rng.uniform(1, 4, (N, N))
+        if k == 3:
+            lam0[:] = 0.0
+            W[:] = 0.0                                       # λ = 0 at every event
+        procs.append(nhp.ContinuousStandardHawkesProcess(nhp.HomogeneousProcess(lam0), nhp.ExponentialImpulseResponse(th, 1.0, 1.0, 1e-3),
+                                                         nhp.DenseWeightModel(W)))
+        oms.append(orc.ContModel(lam0, W, theta=th, dt_max=1e-3))
+    ds = nhp.device_dataset(procs[0], (times, nodes, T), ctx)
+    models = [p.device_model(ctx) for p in procs]
+    arr = (C.c_void_p * 8)(*[m.h for m in models])
+    out = np.empty(8)
+    _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, ds.h, arr, 8, 0, _lib.dptr(out)), ctx.h)
+    for k in range(8):
+        if k == 3:
+            assert out[k] == -np.inf
+        else:
+            assert rel(out[k], orc.loglik_windowed(oms[k], times, nodes, T)) < TOL
