@@ -24,6 +24,9 @@ sys.path.insert(0, ROOT)
 
 EXP_TERM_CEILING = 1.45e12     # exponential pair terms/s on register operands, measured (profiles/README.md)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_VALU_PEAK_TFLOPS = 78.6   # AMD spec, fp64 vector; nhp_probe_rate measures 66 TFLOP/s of bare fma
+FLOP_PER_EXP_TERM = 44.0       # one pair term w·θ·e^{-θΔt}: 19 fp64 instructions of exp (15 of them fma) + 5 around it = 24
+                               # instructions, 20 fma x 2 + 4 = 44 flop (csrc/nhp_math.h)
 
 WORKLOADS = {
     "windowed_k8": dict(kind="exponential", kbar=8.0, recursive=False),
@@ -49,14 +52,16 @@ def algorithmic_bytes(N, M, kind):
 
 
 def measured_traffic(workload):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/traffic.json: FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE); None when
-    the workload has not been profiled."""
+    """(bytes per launch, commit) of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json,
+    written by tools/traffic.sh: FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE; `commit` = the source state
+    the passes ran on).  PMC counters cannot be collected inside this process, so the number is a record, and the line says
+    which commit it was taken at; (None, None) when the workload has not been profiled."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f)[workload]["traffic_bytes_per_launch"]
+            rec = json.load(f)[workload]
+        return rec["traffic_bytes_per_launch"], rec.get("commit")
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
 def run_workload(nhp, ctx, name, N, M, steps, warmup, sync):
@@ -178,6 +183,124 @@ def cpu_baseline_all_cores(r, budget_s=6.0):
     return dict(value=1.0 / (ts * M / m), unit="log-likelihood evals/sec", cores=threads, kind="port",
                 sample=f"oracle C restatement of the threaded branch, {threads} OpenMP threads, first {m} of {M} events, "
                        f"median of {len(runs)} runs ({ts:.3f} s each), scaled linearly to M")
+
+
+def default_dispatch_leg(nhp, ctx, args, sync):
+    """The reference's DEFAULT call: loglikelihood(process, data) has recursive=true, and for exponential impulses that is the
+    O(M·N) recursion which ignores Δtmax (src/continuous.jl:212-214,241-276).  Two ways to that same value: `recursive`
+    = the library's default (the full-history sum through a truncated window whose tail is below 2^-60 of every λ_i, DESIGN
+    3.2) and `recursive_full` = the 2·M·N-exponential recursion itself (NHP_LL_FULL_RECURSION).  Each with its own CPU
+    baseline (the oracle's literal recursion on a prefix, scaled linearly in M) and an fp64-VALU roofline: this path is
+    arithmetic-bound, its algorithmic bytes are the headline's."""
+    out = {}
+    for name in ("recursive", "recursive_full"):
+        steps = max(3, args.steps // 20)
+        o = run_workload(nhp, ctx, name, args.nodes, args.events, steps, 2, sync)
+        mk = o["dev_ms"] / steps
+        entry = {"workload": name, "value": steps / o["wall"], "unit": "log-likelihood evals/sec", "steps": steps, "kernel_ms": mk,
+                 "loglik": o["ll"], "hbm_frac_on_algorithmic_bytes": algorithmic_bytes(o["N"], o["M"], o["kind"]) / (mk * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if name == "recursive_full":
+            terms = 2.0 * o["M"] * o["N"]                    # the reference's count: 2N exponentials per event
+            tf = terms * FLOP_PER_EXP_TERM / (mk * 1e-3) / 1e12
+            entry["roofline"] = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": tf / FP64_VALU_PEAK_TFLOPS, "exp_terms_per_s": terms / (mk * 1e-3),
+                                 "frac_of_measured_exp_term_ceiling": terms / (mk * 1e-3) / EXP_TERM_CEILING, "traffic": None}
+        if not args.no_cpu:
+            entry["cpu_baseline"] = cpu_baseline(o, budget_s=5.0)
+            entry["speedup_vs_cpu_core"] = entry["value"] / entry["cpu_baseline"]["value"]
+        out[name] = entry
+    return out
+
+
+def _eight_models(nhp, ctx, r):
+    procs = []
+    for q in range(8):
+        pq = nhp.synthetic.s_metric_process(r["N"], r["M"], r["data"][2], "exponential", 1.0)
+        pq.weights.W = pq.weights.W * (1.0 + 0.01 * q)
+        pq.impulses.θ = pq.impulses.θ * (1.0 + 0.005 * q)
+        procs.append(pq)
+    ds = nhp.device_dataset(procs[0], r["data"], ctx)
+    return procs, ds, [pq.device_model(ctx) for pq in procs]
+
+
+def batch_leg(nhp, ctx, r, args, sync):
+    """nhp_cont_loglik_batch: S DISTINCT parameter sets against the headline dataset per call -- what the metric's real
+    callers issue (the 2P objective calls of a finite-difference gradient inside mle!, src/continuous.jl:190; restarts;
+    chain populations).  Eight sets share one pass over the data (k_windowed_batch).  Roofline on the batch's OWN
+    algorithmic bytes: the data once, every parameter set once: 16·M + S·8·P."""
+    import ctypes as C
+    import numpy as np
+    from nhp_amd import _lib
+    procs, ds, models = _eight_models(nhp, ctx, r)
+    P = r["N"] + 2 * r["N"] * r["N"]
+    res = {}
+    for nb in (8, 32, 64):
+        arr = (C.c_void_p * nb)(*[models[q % 8].h for q in range(nb)])
+        outb = np.empty(nb)
+        reps = max(3, args.steps // (nb // 2))
+        _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, ds.h, arr, nb, 0, _lib.dptr(outb)), ctx.h)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, ds.h, arr, nb, 0, _lib.dptr(outb)), ctx.h)
+        sync()
+        tb = (time.perf_counter() - t0) / reps
+        B = (nb // 8) * (16 * r["M"] + 8 * 8 * P)             # per call: nb/8 passes of 8 sets
+        res[f"sets_{nb}"] = {"value": nb / tb, "unit": "log-likelihood evals/sec", "us_per_evaluation": 1e6 * tb / nb,
+                             "calls": reps, "loglik_first_last": [float(outb[0]), float(outb[-1])],
+                             "roofline": {"bound": "hbm", "achieved": B / tb / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": B / tb / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": B, "traffic": None},
+                             "exp_terms_per_s": nb * r["pairs"] / tb,
+                             "frac_of_measured_exp_term_ceiling": nb * r["pairs"] / tb / EXP_TERM_CEILING}
+    res["note"] = ("wall time per call incl. one result fetch; 8 sets per pass (k_windowed_batch: one lane per (child, set), "
+                   "windows gathered once per child for all 8)")
+    return res
+
+
+def changing_parameters_leg(nhp, ctx, r, args, sync):
+    """SURVEY 8d "report both": the evaluation rate when the parameters CHANGE between evaluations.
+    (a) device-updated: 16 different parameter sets resident in HBM, evaluation k takes set k mod 16 (no result re-use,
+        268 MB of parameters cycling through the 256 MB Infinity Cache);
+    (b) re-uploaded: params!(process, x) through nhp_cont_model_set_params (8·P = 16.8 MB over PCIe) before every
+        evaluation -- the PCIe-inclusive rate, never `value`."""
+    import numpy as np
+    from nhp_amd import _lib
+    lib = _lib.lib()
+    procs = []
+    for q in range(16):
+        pq = nhp.synthetic.s_metric_process(r["N"], r["M"], r["data"][2], "exponential", 1.0)
+        pq.weights.W = pq.weights.W * (1.0 + 0.01 * q)
+        procs.append(pq)
+    ds = nhp.device_dataset(procs[0], r["data"], ctx)
+    models = [pq.device_model(ctx) for pq in procs]
+    steps = args.steps
+    for k in range(16):
+        _lib.check(lib.nhp_cont_loglik_enqueue(ctx.h, ds.h, models[k].h, 0, k), ctx.h)
+    ctx.synchronize()
+    sync()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for k in range(steps):
+        _lib.check(lib.nhp_cont_loglik_enqueue(ctx.h, ds.h, models[k % 16].h, 0, k % 16), ctx.h)
+    dev_ms = ctx.timer_stop()
+    sync()
+    wall = time.perf_counter() - t0
+    lls = ctx.fetch(0, 16)
+    x = procs[0].params()
+    n_up = max(5, steps // 10)
+    xs = [x * (1.0 + 1e-3 * k) for k in range(4)]
+    ll = np.empty(1)
+    models[0].set_params(xs[0])
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for k in range(n_up):
+        models[0].set_params(xs[k % 4])
+        _lib.check(lib.nhp_cont_loglik(ctx.h, ds.h, models[0].h, 0, _lib.dptr(ll)), ctx.h)
+    t_up = (time.perf_counter() - t0) / n_up
+    return {"rotating_16_resident_parameter_sets": {"value": steps / wall, "unit": "log-likelihood evals/sec", "kernel_ms": dev_ms / steps,
+                                                    "distinct_logliks": int(len(set(np.round(lls, 6))))},
+            "params_uploaded_before_every_evaluation": {"value": 1.0 / t_up, "unit": "log-likelihood evals/sec", "ms_per_evaluation": 1e3 * t_up,
+                                                        "bytes_uploaded_per_evaluation": int(8 * len(x)), "loglik": float(ll[0])}}
 
 
 def config_workloads(nhp, ctx, which):
@@ -371,7 +494,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("NHP_BENCH_WORKLOAD", "windowed_k8"), choices=sorted(WORKLOADS))
     ap.add_argument("--nodes", type=int, default=1024)
     ap.add_argument("--events", type=int, default=1_000_000)
-    ap.add_argument("--extra", default=os.environ.get("NHP_BENCH_EXTRA", "windowed_k64,windowed_k512,simulated_k32,recursive,recursive_full"),
+    ap.add_argument("--extra", default=os.environ.get("NHP_BENCH_EXTRA", "windowed_k64,windowed_k512,simulated_k32,logitnormal_k8"),
                     help="comma list of secondary workloads reported under 'other_workloads' (N=1 only)")
     ap.add_argument("--configs", default=os.environ.get("NHP_BENCH_CONFIGS", "c2,c3,c4"),
                     help="comma list of BASELINE configs measured as secondary workloads (N=1 only); '' to skip")
@@ -383,6 +506,8 @@ def main():
                     help="also time two independent evaluation streams sharing the GPU (N=1).  Off by default: its launches "
                          "of the headline kernel would enter the rocprofv3 per-symbol average of the default command")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-default-dispatch", action="store_true", help="skip the recursive=true legs (the reference's default call)")
+    ap.add_argument("--no-batch", action="store_true", help="skip the batch / changing-parameter legs")
     args = ap.parse_args()
 
     import torch                       # first: libnhp.so must bind to torch's HIP runtime copy
@@ -449,7 +574,7 @@ def main():
                        "pairs_per_eval": r["pairs"], "independent_streams": world},
             "roofline": {"bound": "hbm", "achieved": B / (ms_kernel * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": B / (ms_kernel * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(args.workload),
+                         "traffic": measured_traffic(args.workload)[0], "traffic_measured_at_commit": measured_traffic(args.workload)[1],
                          "algorithmic_bytes": B, "kernel_ms": ms_kernel,
                          "pair_rate_per_s": r["pairs"] / (ms_kernel * 1e-3)},
             "loglik": [float(v) for v in lls.cpu()],
@@ -476,6 +601,17 @@ def main():
                     out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline_all_cores"]["value"]
                 except Exception as exc:      # secondary number
                     out["cpu_baseline_all_cores"] = {"error": repr(exc)}
+        if world == 1 and not args.no_default_dispatch:
+            out["default_dispatch"] = default_dispatch_leg(nhp, ctx, args, sync)
+        if world == 1 and not args.no_batch:
+            try:
+                out["batch"] = batch_leg(nhp, ctx, r, args, sync)
+            except Exception as exc:        # secondary number: never take the headline down with it
+                out["batch"] = {"error": repr(exc)}
+            try:
+                out["parameters_changing_every_evaluation"] = changing_parameters_leg(nhp, ctx, r, args, sync)
+            except Exception as exc:
+                out["parameters_changing_every_evaluation"] = {"error": repr(exc)}
         if world == 1 and args.extra:
             others = []
             for name in [s for s in args.extra.split(",") if s and s != args.workload]:
@@ -492,43 +628,6 @@ def main():
                     entry["exp_terms_per_s"] = terms / (mk * 1e-3)
                     entry["fp64_valu_frac"] = terms / (mk * 1e-3) / EXP_TERM_CEILING
                 others.append(entry)
-            try:     # 8 parameter sets on the headline dataset through nhp_cont_loglik_batch (fused launches)
-                import ctypes as C
-                import numpy as np
-                from nhp_amd import _lib
-                procs = []
-                for q in range(8):
-                    pq = nhp.synthetic.s_metric_process(r["N"], r["M"], r["data"][2], "exponential", 1.0)
-                    pq.weights.W = pq.weights.W * (1.0 + 0.01 * q)
-                    procs.append(pq)
-                dsb = nhp.device_dataset(procs[0], r["data"], ctx)
-                models = [pq.device_model(ctx) for pq in procs]
-                arr = (C.c_void_p * 8)(*[m.h for m in models])
-                outb = np.empty(8)
-                reps = max(3, args.steps // 10)
-                _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, dsb.h, arr, 8, 0, _lib.dptr(outb)), ctx.h)
-                sync()
-                t0 = time.perf_counter()
-                for _ in range(reps):
-                    _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, dsb.h, arr, 8, 0, _lib.dptr(outb)), ctx.h)
-                sync()
-                tb = (time.perf_counter() - t0) / reps
-                others.append({"workload": "windowed_k8, 8 parameter sets per nhp_cont_loglik_batch call", "value": 8 / tb,
-                               "us_per_evaluation": 1e6 * tb / 8, "loglik": float(outb[0])})
-                # 64 sets per call: fused launches on the context's two lanes reach their steady state
-                arr64 = (C.c_void_p * 64)(*[models[q % 8].h for q in range(64)])
-                out64 = np.empty(64)
-                _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, dsb.h, arr64, 64, 0, _lib.dptr(out64)), ctx.h)
-                sync()
-                t0 = time.perf_counter()
-                for _ in range(reps):
-                    _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, dsb.h, arr64, 64, 0, _lib.dptr(out64)), ctx.h)
-                sync()
-                tb = (time.perf_counter() - t0) / reps
-                others.append({"workload": "windowed_k8, 64 parameter sets per nhp_cont_loglik_batch call", "value": 64 / tb,
-                               "us_per_evaluation": 1e6 * tb / 64, "loglik": float(out64[0])})
-            except Exception as exc:        # secondary number: never take the headline down with it
-                others.append({"workload": "windowed_k8 batch", "error": repr(exc)})
             out["other_workloads"] = others
         if world == 1 and args.configs:
             out["configs"] = config_workloads(nhp, ctx, args.configs.split(","))

@@ -99,7 +99,6 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
     double *red = reinterpret_cast<double *>(smem);                 // [waves <= 16] + flag at [16]
     double2 *col = reinterpret_cast<double2 *>(smem + 192);         // [N]
     double *colw = reinterpret_cast<double *>(col + a.N);           // [N], logit-normal only
-    double *lam_buf = colw + (IMP == NHP_IMPULSE_EXPONENTIAL ? 0 : a.N);   // [children of the item]
 
     const nhp_item it = a.items[blockIdx.x];
     const int c = it.node, N = a.N, tid = threadIdx.x;
@@ -134,14 +133,17 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
     // round's window-sorted order
     constexpr int GW = 64 / G;
     const int slot0 = (gid / GW) * (GW * U) + (gid % GW);
+    // Σ log λ as one logarithm per lane: log Π λ_k = log(Π mant_k) + ln2·Σ exp_k (see k_windowed_batch); only a group's
+    // first lane holds a λ, so the old scheme parked the λ_k in LDS and took the ~45-instruction logs in a second pass
+    double prod = 1.0;
+    int pexp = 0;
     for (int r0 = 0; r0 < (NHP_SKIP(a, 1) ? 0 : nchild); r0 += GROUPS * U) {
         double t[U], s[U];
-        int j[U], f[U], idx[U], kks[U];
+        int j[U], f[U], idx[U];
         bool valid[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int kk = r0 + slot0 + u * GW;
-            kks[u] = kk;
             valid[u] = kk < nchild;
             const nhp_child ch = a.child_w[it.kbeg + (valid[u] ? kk : r0)];
             t[u] = ch.t; idx[u] = ch.idx;
@@ -214,15 +216,16 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
             s[u] = group_sum<G>(s[u]);
             if (gl == 0 && valid[u]) {
                 const double lam = baseline_at(a, c, t[u]) + s[u];
-                lam_buf[kks[u]] = lam;
                 if (lambda_out) lambda_out[idx[u]] = lam;
+                prod *= lam < 0.0 ? __builtin_nan("") : __builtin_amdgcn_frexp_mant(lam);
+                pexp += __builtin_amdgcn_frexp_exp(lam);
             }
         }
+        pexp += __builtin_amdgcn_frexp_exp(prod);
+        prod = __builtin_amdgcn_frexp_mant(prod);
     }
-    __syncthreads();
-    // ---- deferred logs: every lane busy, one child each
-    double acc = 0.0;
-    for (int k = tid; k < (NHP_SKIP(a, 4) ? 0 : nchild); k += NHP_WBLOCK) acc += nhp_log(lam_buf[k]);
+    double acc = nhp_log(prod) + (double)pexp * 6.93147180559945286e-01;
+    if (prod == 0.0) acc = -__builtin_inf();
     static_assert(2 * (NHP_WBLOCK / 64) <= 16, "red[] holds 16 doubles ahead of the flag");
     double blk = acc, blk_int = integ;
     nhp_block_sum2_n<NHP_WBLOCK / 64>(blk, blk_int, red);
@@ -813,7 +816,7 @@ static nhp_status run_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const n
 {
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t per = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? 16 : 24;
-    const size_t lds = 192 + per * (size_t)ds->N + 8 * (size_t)(ds->max_item > 0 ? ds->max_item : 1);
+    const size_t lds = 192 + per * (size_t)ds->N;
     if (lds > 160 * 1024) { nhp_set_error(ctx, "n_nodes = %d exceeds the 160 KiB LDS column budget", ds->N); return NHP_ENOTIMPL; }
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)ds->n_items));
     nhp_cont_args a = nhp_make_args(ds, m);

@@ -1,0 +1,37 @@
+#!/bin/bash
+# HBM-side traffic of the dominant kernels from rocprofv3 PMC passes (separate passes, --kernel-trace only), written to
+# gpurun_out/traffic.json in the format bench.py reads from profiles/traffic.json.  Run on the GPU box:
+#   NHP_HEAD=$(git rev-parse --short HEAD) gpurun -- "NHP_HEAD=$NHP_HEAD bash tools/traffic.sh"
+# then copy gpurun_out/traffic.json (and the raw counter CSVs under gpurun_out/pmc_traffic/) into profiles/.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+run() {   # run <tag> <counters...> -- <cmd...>
+  tag=$1; shift; ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
+  rocprofv3 --kernel-trace --pmc "${ctr[@]}" --output-format csv -d $R/gpurun_out/pmc_traffic/$tag -- "$@" > /dev/null 2>&1
+}
+run k8_fetch FETCH_SIZE -- python3 $R/tools/kbench.py windowed_k8 10
+run k8_write WRITE_SIZE -- python3 $R/tools/kbench.py windowed_k8 10
+run k8_tcc TCC_HIT_sum TCC_MISS_sum -- python3 $R/tools/kbench.py windowed_k8 10
+NB=8 run b8_fetch FETCH_SIZE -- python3 $R/tools/batch.py
+NB=8 run b8_write WRITE_SIZE -- python3 $R/tools/batch.py
+NB=8 run b8_tcc TCC_HIT_sum TCC_MISS_sum -- python3 $R/tools/batch.py
+python3 - <<PY
+import csv, glob, json, collections, os
+R = "$R"
+def mean(tag, kern, name):
+    v = [float(r["Counter_Value"]) for f in glob.glob(f"{R}/gpurun_out/pmc_traffic/{tag}/*/*counter_collection.csv")
+         for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"] and r["Counter_Name"] == name]
+    return sum(v) / len(v) if v else None
+out = {}
+for key, pre, kern, label in (("windowed_k8", "k8", "k_windowed<", "k_windowed<0,8,4>"), ("batch_8_sets", "b8", "k_windowed_batch", "k_windowed_batch<0,8,1024>")):
+    f, w = mean(pre + "_fetch", kern, "FETCH_SIZE"), mean(pre + "_write", kern, "WRITE_SIZE")
+    h, m = mean(pre + "_tcc", kern, "TCC_HIT_sum"), mean(pre + "_tcc", kern, "TCC_MISS_sum")
+    if f is None: continue
+    out[key] = {"kernel": label, "commit": os.environ.get("NHP_HEAD", "unknown"),
+                "source": f"gpurun_out/pmc_traffic/{pre}_{{fetch,write,tcc}} (separate rocprofv3 --pmc passes; tools/traffic.sh)",
+                "FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB_raw": w,
+                "correction": "MI355X_MICROARCH.md HBM: FETCH_SIZE counts 128-B requests at 64 B on gfx950 -> doubled; WRITE_SIZE exact; unit KB",
+                "traffic_bytes_per_launch": int(2 * f * 1024 + (w or 0) * 1024), "tcc_hit_rate": h / (h + m) if h is not None else None}
+json.dump(out, open(f"{R}/gpurun_out/traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
