@@ -155,6 +155,19 @@ def cpu_baseline(r, budget_s=12.0):
                        f"({ts:.3f} s each), scaled linearly to M; row sums of W hoisted (stronger baseline)")
 
 
+def _cpu_share():
+    """Cores this process may actually use: the affinity mask, cut to the cgroup's CPU quota when there is one (a GPU box hands a
+    one-GPU job a share of the host -- 128 OpenMP threads on a 16-core share ran 30x slower than 16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, int(os.environ.get("NHP_BENCH_THREADS", "64")))
+
+
 def cpu_baseline_all_cores(r, budget_s=6.0):
     """the reference's `Threads.@threads` branch (src/continuous.jl:224-232) restated with OpenMP, on
     every core the box gives this process; windowed formulation only (the reference's recursion is serial)."""
@@ -164,7 +177,7 @@ def cpu_baseline_all_cores(r, budget_s=6.0):
     kw = dict(theta=proc.impulses.θ) if r["kind"] == "exponential" else dict(mu=proc.impulses.μ, tau=proc.impulses.τ)
     om = orc.ContModel(proc.baseline.λ, proc.weights.W, dt_max=1.0, **kw)
     M = len(times)
-    threads = max(1, min(orc.max_threads(), len(os.sched_getaffinity(0))))
+    threads = max(1, min(orc.max_threads(), _cpu_share()))
 
     def run(m):
         t0 = time.perf_counter()
@@ -206,7 +219,7 @@ def default_dispatch_leg(nhp, ctx, args, sync):
                                  "frac": tf / FP64_VALU_PEAK_TFLOPS, "exp_terms_per_s": terms / (mk * 1e-3),
                                  "frac_of_measured_exp_term_ceiling": terms / (mk * 1e-3) / EXP_TERM_CEILING, "traffic": None}
         if not args.no_cpu:
-            entry["cpu_baseline"] = cpu_baseline(o, budget_s=5.0)
+            entry["cpu_baseline"] = cpu_baseline(o, budget_s=2.5)
             entry["speedup_vs_cpu_core"] = entry["value"] / entry["cpu_baseline"]["value"]
         out[name] = entry
     return out

@@ -249,6 +249,12 @@ void nhp_uniform_stream(uint64_t seed, uint64_t step, int64_t n, double *u);
  * 4 exp for x<=0, 5 exponential pdf(θ=x, Δt=y), 6 logit-normal pdf(τ=x, Δt=y; μ=.25, Δtmax=2));
  * lets tests hold the kernels' fixed operation sequences to a bitwise contract */
 nhp_status nhp_probe_math(nhp_ctx *ctx, int32_t op, const double *x, const double *y, int64_t n, double *out);
+/* diagnostics: n device-side random variates with the generators and Philox keying of the Gibbs kernels (nhp_rng.h):
+ * kind 0 Gamma(shape a[i], scale b[i]) keyed (seed, step, i); 1 standard normal keyed (seed, step, i); 2 Beta(a[i], b[i]) as
+ * X/(X+Y) from Gammas keyed (seed, step, 2i) and (seed, step, 2i+1).  Lets tests hold the draws to their distributions
+ * (Kolmogorov-Smirnov) and to known answers of the Philox -> uniform -> variate chain. */
+nhp_status nhp_probe_draws(nhp_ctx *ctx, int32_t kind, uint64_t seed, uint64_t step, int64_t n, const double *a, const double *b,
+                           double *out);
 /* throughput calibration on register operands: mode 0 = exponential pair terms per second (the
  * fp64-VALU ceiling of the windowed kernels), mode 1 = fp64 fma per second */
 nhp_status nhp_probe_rate(nhp_ctx *ctx, int32_t mode, int32_t iters, int32_t blocks, double *ops_per_s);

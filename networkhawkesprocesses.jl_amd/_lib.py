@@ -113,6 +113,7 @@ def _declare(lib):
     f("nhp_disc_resample_adjacency", i32, _vp, _vp, _dp, _dp, _dp, _dp, dbl, _dp, dbl, _dp, u64, u64, _dp)
     f("nhp_cont_resample_adjacency", i32, _vp, _vp, _vp, _dp, dbl, _dp, u64, u64, _dp, _dp)
     f("nhp_probe_math", i32, _vp, i32, _dp, _dp, i64, _dp)
+    f("nhp_probe_draws", i32, _vp, i32, u64, u64, i64, _dp, _dp, _dp)
     f("nhp_probe_rate", i32, _vp, i32, i32, i32, _dp)
     f("nhp_probe_gather", i32, _vp, i32, i32, i64, i32, _dp)
     for name, args in (

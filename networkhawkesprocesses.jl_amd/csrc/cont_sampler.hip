@@ -684,3 +684,37 @@ extern "C" nhp_status nhp_cont_model_get_adjacency(nhp_ctx *ctx, const nhp_cont_
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     return nhp_download(ctx, A, m->d_A, 8 * NN);
 }
+
+
+// ---- diagnostics: the device-side random variates themselves (tests hold them to their distributions and to known answers)
+// kind 0: Gamma(shape a[i], scale b[i]); kind 1: standard normal; kind 2: Beta(a[i], b[i]) as X/(X+Y) -- each with the
+// generators and the Philox keying (seed, step, element i | 2i, 2i+1) the Gibbs kernels use.
+__global__ __launch_bounds__(256) void k_probe_draws(int kind, uint64_t seed, uint64_t step, int64_t n, const double *__restrict__ pa,
+                                                     const double *__restrict__ pb, double *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (kind == 0) out[i] = dev_gamma(pa[i], pb[i], seed, step, (uint64_t)i);
+    else if (kind == 1) out[i] = dev_normal(seed, step, (uint64_t)i, 0);
+    else {
+        const double x = dev_gamma(pa[i], 1.0, seed, step, (uint64_t)(2 * i)), y = dev_gamma(pb[i], 1.0, seed, step, (uint64_t)(2 * i + 1));
+        out[i] = x / (x + y);
+    }
+}
+
+extern "C" nhp_status nhp_probe_draws(nhp_ctx *ctx, int32_t kind, uint64_t seed, uint64_t step, int64_t n, const double *a,
+                                      const double *b, double *out)
+{
+    if (!ctx || !out || n < 0 || kind < 0 || kind > 2 || (kind != 1 && (!a || !b))) return NHP_EINVAL;
+    if (n == 0) return NHP_OK;
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    NHP_TRY(nhp_ctx_reserve_scratch(ctx, 3 * sizeof(double) * (size_t)n));
+    double *da = (double *)ctx->d_scratch, *db = da + n, *dout = db + n;
+    if (kind != 1) {
+        NHP_HIP(ctx, hipMemcpyAsync(da, a, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        NHP_HIP(ctx, hipMemcpyAsync(db, b, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    hipLaunchKernelGGL(k_probe_draws, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, kind, seed, step, n, da, db, dout);
+    NHP_HIP(ctx, hipGetLastError());
+    return nhp_download(ctx, out, dout, sizeof(double) * (size_t)n);
+}

@@ -37,6 +37,25 @@ def test_convolve_bit_exact(nhp, orc, N, T, B, L):
     assert np.array_equal(conv, orc.disc_convolve(data, phi))      # same summation order, no contraction
 
 
+@pytest.mark.parametrize("N,T,B,L,rate", [(4, 1001, 3, 64, 0.05), (3, 777, 2, 70, 0.3), (6, 1500, 11, 9, 2.0), (2, 513, 1, 2, 0.0)])
+def test_convolve_sparse_and_dense_paths_bit_exact(nhp, orc, N, T, B, L, rate, monkeypatch):
+    """The convolution walks only the NONZERO counts of a bin's lag window (bitmap, L <= 64), odd T takes 8-byte stores, L > 64
+    takes the dense kernel, B > 8 takes two basis passes, an all-zero matrix gives all zeros: each bit for bit the oracle's
+    direct-form sum; and the dense kernel forced on a sparse case agrees with the sparse one."""
+    proc, data, *_ = make(nhp, N, T, max(B, 2), L, seed=3 * N + L, rate=rate)
+    if B != proc.impulses.θ.shape[2]:
+        th = np.ones((N, N, B)) / B
+        th[:, :, -1] = 1.0 - th[:, :, :-1].sum(axis=2)
+        proc.impulses.θ = th
+    phi = proc.impulses.basis()
+    want = orc.disc_convolve(data, phi)
+    _, conv = nhp.convolve(proc, data, fetch=True)
+    assert np.array_equal(conv, want)
+    monkeypatch.setenv("NHP_CONV_DENSE", "1")
+    _, conv2 = nhp.convolve(proc, data, fetch=True)
+    assert np.array_equal(conv2, want)
+
+
 @pytest.mark.parametrize("N,T,B,L,network", [(3, 50, 2, 4, False), (5, 300, 3, 7, True), (16, 1000, 8, 32, False),
                                              (130, 257, 2, 3, True), (64, 2000, 4, 8, False)])
 def test_intensity_and_loglik(nhp, orc, N, T, B, L, network):
