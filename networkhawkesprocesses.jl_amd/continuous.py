@@ -144,7 +144,9 @@ def device_dataset(process, data, ctx=None):
     events, nodes, duration = data
     key = (id(events), id(nodes), len(events), float(duration), float(process.impulses.Δtmax), process.ndims(), id(ctx))
     hit = _ds_cache.get(key)
-    if hit is not None and hit[1]() is events:
+    # the arrays may have been refilled in place since the upload (a preallocated buffer reused for the next dataset):
+    # a cheap content fingerprint decides, not the identity alone
+    if hit is not None and hit[1]() is events and hit[2] == _fingerprint(events, nodes):
         return hit[0]
     ds = DeviceDataset(ctx, data, process.ndims(), process.impulses.Δtmax)
     try:
@@ -153,8 +155,22 @@ def device_dataset(process, data, ctx=None):
         return ds          # plain lists cannot be weak-referenced: no caching
     if len(_ds_cache) > 16:
         _ds_cache.clear()
-    _ds_cache[key] = (ds, ref)
+    _ds_cache[key] = (ds, ref, _fingerprint(events, nodes))
     return ds
+
+
+def _fingerprint(events, nodes):
+    """First, last and sum of the events, sum of the nodes, and a strided sample of both: O(M) adds (≈1 ms at M = 10⁶)
+    against an upload + pre-pass of tens of ms; not a hash, but any refill of the buffers changes it."""
+    e, n = np.asarray(events), np.asarray(nodes)
+    if len(e) == 0:
+        return (0,)
+    return (float(e[0]), float(e[-1]), float(e.sum()), int(n.sum()), float(e[::97].sum()), int(n[::89].sum()))
+
+
+def invalidate_device_datasets():
+    """Forget every cached device copy (call after mutating data arrays in place if in doubt)."""
+    _ds_cache.clear()
 
 
 class ContinuousStandardHawkesProcess(ContinuousHawkesProcess):

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 
+#include <atomic>
 #include "nhp_internal.h"
 
 template <typename T>
@@ -74,6 +75,8 @@ extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double
     NHP_HIP(ctx, hipSetDevice(ctx->device));
 
     nhp_cont_dataset *ds = new nhp_cont_dataset();
+    static std::atomic<uint64_t> next_uid{1};
+    ds->uid = next_uid.fetch_add(1);
     ds->ctx = ctx; ds->M = M; ds->N = N; ds->duration = duration; ds->dt_max = dt_max;
     ds->col_begin = col_begin; ds->col_end = col_end;
     ds->t_last = M > 0 ? events[M - 1] : 0.0;

@@ -82,6 +82,17 @@ __device__ __forceinline__ double baseline_integral_col(const nhp_cont_args &a, 
     return I;
 }
 
+#ifdef NHP_STAMP      // diagnostic build only (tools/stamps.py): s_memtime at the phase boundaries of wave 0 of every workgroup
+__device__ unsigned long long g_stamps[8 * 4096];
+#define NHP_STAMP_AT(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int nhp_debug_stamps(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#else
+#define NHP_STAMP_AT(i) do { } while (0)
+#endif
+
 // U children per group are in flight at once: their child records, then their parents'
 // packed (t, node) records, are fetched by independent loads before any is consumed, so the
 // dependent global-load chains of different children overlap.  Inactive slots are predicated
@@ -102,6 +113,7 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
 
     const nhp_item it = a.items[blockIdx.x];
     const int c = it.node, N = a.N, tid = threadIdx.x;
+    NHP_STAMP_AT(0);
 
     // ---- stage column c; the node's first item also owns the column's integral term
     double integ = 0.0;
@@ -124,6 +136,7 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
     // leaves it to k_finalize), so the last workgroup's tail has nothing to load but the partial sums
     if (out && it.first && !NHP_SKIP(a, 2)) integ += baseline_integral_col(a, c);
     __syncthreads();
+    NHP_STAMP_AT(1);
 
     // ---- children: G lanes per child, U children per group in flight
     constexpr int GROUPS = NHP_WBLOCK / G;
@@ -224,6 +237,7 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
         pexp += __builtin_amdgcn_frexp_exp(prod);
         prod = __builtin_amdgcn_frexp_mant(prod);
     }
+    NHP_STAMP_AT(2);
     double acc = nhp_log(prod) + (double)pexp * 6.93147180559945286e-01;
     if (prod == 0.0) acc = -__builtin_inf();
     static_assert(2 * (NHP_WBLOCK / 64) <= 16, "red[] holds 16 doubles ahead of the flag");
@@ -257,6 +271,8 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
         *flag = last;
     }
     __syncthreads();
+    NHP_STAMP_AT(3);
+    NHP_STAMP_AT(4);
     if (!*flag) return;
     double sl = 0.0, si = 0.0;
     for (unsigned int i = tid; i < gridDim.x; i += NHP_WBLOCK) {
@@ -476,17 +492,6 @@ static nhp_status enqueue_multi(nhp_ctx *ctx, const nhp_cont_dataset *ds, const 
     return NHP_OK;
 }
 
-#ifdef NHP_STAMP      // diagnostic build only (tools/stamps.py): s_memtime at the phase boundaries of wave 0 of every workgroup
-__device__ unsigned long long g_stamps[8 * 4096];
-#define NHP_STAMP_AT(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-extern "C" int nhp_debug_stamps(unsigned long long *out, int n)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)n);
-}
-#else
-#define NHP_STAMP_AT(i) do { } while (0)
-#endif
-
 // ---- S parameter sets per launch, one lane per (child, parameter set) ---------------------------------------------
 // The real callers of "log-likelihood evaluations per second" are batches: the 2P objective calls of a finite-difference
 // gradient inside mle! (src/continuous.jl:190), restarts, chain populations.  For S models on one dataset the
@@ -608,28 +613,36 @@ __global__ __launch_bounds__(THREADS) void k_windowed_batch(nhp_cont_args a, nhp
     // hundred cycles of arithmetic.  Rounds are therefore taken RB at a time: all RB child records are requested, then all
     // RB first chunks of parents, then the arithmetic of the RB rounds runs with nothing left to wait for (register
     // arrays with compile-time indices; a rotating software pipeline would wait at every register hand-over).
-    constexpr int RB = 8;
+    constexpr int RB = 4;
     for (int rb = 0; rb < nrounds; rb += RB) {
         nhp_child chs[RB];
-        nhp_event m0s[RB];
+        nhp_event m0s[RB], m1s[RB];
+        int kmaxs[RB];
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) chs[rr] = load_child(group_of(rb + rr));
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) m0s[rr] = fetch(chs[rr], 0);
+        // the second chunk of a round too, where the wave's longest window needs one (wave-uniform; the item is sorted by
+        // window length, so it is whole waves that do or do not)
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            kmaxs[rr] = nhp_wave_max_i32(chs[rr].idx - chs[rr].first);
+            if (kmaxs[rr] > S) m1s[rr] = fetch(chs[rr], S);
+        }
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) {
             const int g = group_of(rb + rr);
             if (g < 0) continue;                                    // wave-uniform
             const nhp_child ch0 = chs[rr];
             const bool valid = g * CW + kc < nchild;
-            const int K = ch0.idx - ch0.first;                      // parents in the window
-            const int kmax = nhp_wave_max_i32(K);                   // longest window of the wave's CW children (wave-uniform)
+            const int kmax = kmaxs[rr];                             // longest window of the wave's CW children
             double s = 0.0;
             nhp_event mine = m0s[rr];
             for (int c0 = 0; c0 < kmax; c0 += S) {
                 NHP_LDS_SYNC();                                      // the previous chunk's reads precede this overwrite
                 myrow[m] = mine;
-                if (c0 + S < kmax) mine = fetch(ch0, c0 + S);        // next chunk in flight under this chunk's math
+                if (c0 == 0) mine = m1s[rr];                         // (already requested above)
+                else if (c0 + S < kmax) mine = fetch(ch0, c0 + S);   // third and later chunks: in flight under this chunk's math
                 NHP_LDS_SYNC();
                 const int nrec = kmax - c0 < S ? kmax - c0 : S;      // wave-uniform
                 // records in pairs: the two terms of a pair are independent instruction streams the scheduler interleaves

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(BLOCK) void k_recursive(nhp_cont_args a, double *__
     auto fold_regs = [&](double *acc, const nhp_event *e, int j0, int je, double tk) {
         double v[FU];
 #pragma unroll
-        for (int u = 0; u < FU; ++u) v[u] = nhp_exp_neg(-(th[e[u].node] * (tk - e[u].t)));
+        for (int u = 0; u < FU; ++u) v[u] = nhp_exp_neg_ll(-(th[e[u].node] * (tk - e[u].t)));
 #pragma unroll
         for (int u = 0; u < FU; ++u)
             if (j0 + u * BLOCK < je && e[u].t > 0.0) atomicAdd(&acc[e[u].node], v[u]);
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(BLOCK) void k_recursive(nhp_cont_args a, double *__
 #pragma unroll
         for (int q = 0; q < REC_PQ; ++q) {
             const int p = tid + q * BLOCK;
-            double s = S[q] * nhp_exp_neg(-(thr[q] * gap));
+            double s = S[q] * nhp_exp_neg_ll(-(thr[q] * gap));
             s += accB[p];
             accB[p] = 0.0;
             S[q] = s;
@@ -252,7 +252,9 @@ __global__ __launch_bounds__(256) void k_rec_windows(const nhp_child *__restrict
 // cut for this model (cached per parameter version); 0 = no usable bound
 static nhp_status rec_cut_for(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *cut)
 {
-    if (m->rec_version == m->version && m->rec_M == ds->M) { *cut = m->rec_cut; return NHP_OK; }
+    // the bound uses the dataset's slab statistics as well as the parameters: key it on both (a dataset id, not its size --
+    // two datasets of equal length have different crowding)
+    if (m->rec_version == m->version && m->rec_ds == ds->uid) { *cut = m->rec_cut; return NHP_OK; }
     const int blocks = 64;
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 3 * (size_t)blocks));
     nhp_cont_args a = nhp_make_args(ds, m);
@@ -283,7 +285,7 @@ static nhp_status rec_cut_for(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
     }
     m->rec_cut = c;
     m->rec_version = m->version;
-    m->rec_M = ds->M;
+    m->rec_ds = ds->uid;
     *cut = c;
     return NHP_OK;
 }

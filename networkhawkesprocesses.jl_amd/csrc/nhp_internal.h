@@ -73,6 +73,7 @@ struct __attribute__((aligned(16))) nhp_event {
 
 struct nhp_cont_dataset {
     nhp_ctx *ctx = nullptr;
+    uint64_t uid = 0;                   // process-unique id (caches keyed on "this dataset", never on its address or size)
     int64_t M = 0;
     int32_t N = 0;
     double duration = 0.0, dt_max = 0.0, t_last = 0.0;
@@ -130,7 +131,7 @@ struct nhp_cont_model {
     // quantities derived from the parameters (the recursive path's truncation window) are recomputed only when stale
     uint64_t version = 1;
     mutable uint64_t rec_version = 0;
-    mutable int64_t rec_M = -1;         // the event count the cached bound was derived for
+    mutable uint64_t rec_ds = 0;        // uid of the dataset whose slab statistics the cached bound was derived from
     mutable double rec_cut = 0.0;       // look-back beyond which the full-history sum is below 2^-60 of every λ_i (0: no bound)
     // running sums of the chain's samples (nhp_cont_model_moments_*): Σx and Σx² over [λ0; θ | μ; τ; W; vec(A)], so a
     // chain's posterior summaries never cross PCIe step by step

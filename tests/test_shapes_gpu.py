@@ -79,3 +79,24 @@ def test_loglik_sampler_and_gradient_on_awkward_shapes(nhp, orc, N, M, T, kind, 
         wantA = orc.resample_adjacency(om, t, n, dur, 0.5, uA)
         nhp.resample_adjacency_matrix_(proc, data, u=uA)
         assert np.array_equal(proc.adjacency_matrix, wantA)
+
+
+def test_device_dataset_cache_sees_in_place_refills(nhp, orc):
+    """device_dataset caches the upload per (arrays, Δtmax); refilling the SAME buffers with another dataset of the same
+    length must not evaluate the stale device copy (the cache key carries a content fingerprint), and two datasets of equal
+    length keep separate truncation windows for the recursive formulation (keyed on the dataset, not on its size)."""
+    rng = np.random.default_rng(0)
+    N, M, T = 4, 3000, 100.0
+    times = np.sort(rng.uniform(0, T, M))
+    nodes = rng.integers(1, N + 1, M).astype(np.int64)
+    proc = nhp.ContinuousStandardHawkesProcess(nhp.HomogeneousProcess(rng.uniform(0.5, 1.5, N)),
+                                               nhp.ExponentialImpulseResponse(rng.uniform(20, 40, (N, N)), 1.0, 1.0, 0.5),
+                                               nhp.DenseWeightModel(rng.uniform(0, 0.2, (N, N))))
+    om = orc.ContModel(proc.baseline.λ, proc.weights.W, theta=proc.impulses.θ, dt_max=0.5)
+    data = (times, nodes, T)
+    for rec in (False, True):
+        assert abs(nhp.loglikelihood(proc, data, recursive=rec) - orc.loglik(om, times, nodes, T, recursive=rec)) < 1e-9
+    times[:] = np.sort(rng.uniform(0, T, M) ** 1.7 / T ** 0.7)     # refill in place: another (burstier) dataset
+    nodes[:] = rng.integers(1, N + 1, M)
+    for rec in (False, True):
+        assert abs(nhp.loglikelihood(proc, data, recursive=rec) - orc.loglik(om, times, nodes, T, recursive=rec)) < 1e-9
