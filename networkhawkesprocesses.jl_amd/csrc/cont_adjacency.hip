@@ -109,18 +109,23 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_build(nhp_cont_args a, const 
         for (int k = 0; k < nchild; ++k) seen[k] = 0;
         int gid = 0, p = 0;
         unsigned char *grp = col_group + (size_t)c * N;
-        auto fits = [&](int q, int id) {                 // list of q: <= 16 entries, children unseen in group id
+        // list of q: <= 16 entries, every child unseen in group id -- in the group so far AND earlier in q's own list (a child
+        // named twice by q goes to the general path: the full-size parity test caught a grouped member summing its two
+        // entries apart).  Marks as it goes and takes the marks back on failure, so it is linear in the list.
+        auto fits = [&](int q, int id) {
             const int eb = start[q], ee = start[q + 1];
             if (ee - eb > 16) return false;
             for (int e = eb; e < ee; ++e) {
-                const int ke = ent_k[base + e];
-                if (seen[ke] == id) return false;
-                for (int e2 = eb; e2 < e; ++e2)           // a child named twice in q's OWN list: general path (found by the
-                    if (ent_k[base + e2] == ke) return false;   // full-size parity test: a grouped member summed its two entries apart)
+                int &sk = seen[ent_k[base + e]];
+                if (sk == id) {
+                    for (int e2 = eb; e2 < e; ++e2) seen[ent_k[base + e2]] = 0;
+                    return false;
+                }
+                sk = id;
             }
             return true;
         };
-        auto take = [&](int q, int id) { for (int e = start[q]; e < start[q + 1]; ++e) seen[ent_k[base + e]] = id; };
+        auto take = [&](int, int) {};                    // (fits() has marked the list)
         while (p < N) {
             ++gid;
             bool ok = start[p + 1] - start[p] <= 16;
