@@ -457,56 +457,56 @@ def sharded_leg(nhp, ctx, N, M, world, names):
 
 
 def chains_leg(nhp, ctx, rank, steps, sync):
-    """N>1 only (BASELINE config 5): every rank runs its own mcmc! chain of the config-3 model -- parents, statistics,
-    conjugate draws and the adjacency sweep on the device, chain seed = rank -- with no exchange between chains
-    (src/inference.jl:49-70 has no cross-chain term).  Returns this rank's wall time for `steps` steps of its own chain
-    and for `steps` steps of ONE chain swept by all ranks together."""
+    """N>1 only (BASELINE config 5): every rank runs its own mcmc! chain of the config-3 model inside the library's chain
+    driver (nhp_cont_mcmc_run: parents, statistics, conjugate draws, adjacency sweep, ρ ~ Beta and the posterior moments all
+    on the device, chain seed = rank) with no exchange between chains (src/inference.jl:49-70 has no cross-chain term); then
+    the ONE exchange of the configuration, the chains' posterior sums all-gathered device to device over RCCL
+    (nhp_gather_moments).  Returns this rank's wall time for `steps` steps of its own chain, for the gather, and for
+    `steps` steps of ONE chain swept by all ranks together (each rank its columns, link counts all-reduced per step)."""
     import ctypes as C
+    import numpy as np
     from nhp_amd import _lib, inference, chains
+    lib = _lib.lib()
     N, M = 1024, 1_000_000
     times, nodes, T = nhp.synthetic.s_metric_data(N, M, kbar=8.0)
     proc = nhp.synthetic.s_metric_process(N, M, T, "logitnormal", 1.0, network=True)
     ds = nhp.device_dataset(proc, (times, nodes, T), ctx)
     model, pri = proc.device_model(ctx), inference._priors(proc)
     seed = chains.chain_seed(1, rank)
+    _lib.check(lib.nhp_cont_model_set_rho(ctx.h, model.h, proc.network.ρ), ctx.h)
+    _lib.check(lib.nhp_cont_model_moments_reset(ctx.h, model.h), ctx.h)
 
-    def step(k):
-        _lib.check(_lib.lib().nhp_cont_gibbs_step(ctx.h, ds.h, model.h, C.byref(pri), seed, k), ctx.h)
-        inference.resample_adjacency_matrix_(proc, ds, seed=seed, step=k, model=model, fetch=False, ctx=ctx)
-        _lib.check(_lib.lib().nhp_cont_model_moments_accumulate(ctx.h, model.h), ctx.h)     # the chain's sample store
-    for k in range(3):
-        step(k)
-    ctx.synchronize()
+    def run(k0, n):
+        _lib.check(lib.nhp_cont_mcmc_run(ctx.h, None, ds.h, model.h, C.byref(pri), proc.network.α, proc.network.β, seed, k0, n, 0), ctx.h)
+    run(0, 3)
     sync()
     t0 = time.perf_counter()
-    for k in range(3, 3 + steps):
-        step(k)
-    ctx.synchronize()
+    run(3, steps)
     sync()
     wall = time.perf_counter() - t0
-    # the same chain swept by ALL ranks, each its columns (sharded.py / mcmc_ on a ShardedDataset): per step one scalar
-    # all-reduce (the link count for the network's ρ update)
-    from nhp_amd.sharded import ShardedDataset, _all_reduce_sum
-    import numpy as np
+    comm = _lib.comm_for(ctx)                       # RCCL communicator of this rank ("nccl" groups); None in the gloo rehearsal
+    t_gather = 0.0
+    if comm is not None:
+        L = inference.moments_length(proc)
+        s, q = np.empty((comm.world, L)), np.empty((comm.world, L))
+        counts, rho = np.empty(comm.world, dtype=np.int64), np.empty((comm.world, 3))
+        sync()
+        t0 = time.perf_counter()
+        _lib.check(lib.nhp_gather_moments(ctx.h, comm.h, model.h, _lib.dptr(s), _lib.dptr(q), L, _lib.iptr(counts), _lib.dptr(rho)), ctx.h)
+        sync()
+        t_gather = time.perf_counter() - t0
+        assert np.all(counts == steps + 3)
+    # the same chain swept by ALL ranks, each its columns (mcmc_ on a ShardedDataset -> nhp_cont_mcmc_run with the
+    # communicator; through the host when the ranks cannot form an RCCL clique)
+    from nhp_amd.sharded import ShardedDataset
     sproc = nhp.synthetic.s_metric_process(N, M, T, "logitnormal", 1.0, network=True)
     sd = ShardedDataset(sproc, (times, nodes, T), ctx)
-    smodel = sproc.device_model(ctx)
-
-    def sstep(k):
-        _lib.check(_lib.lib().nhp_cont_gibbs_step(ctx.h, sd.local.h, smodel.h, C.byref(pri), 1, k), ctx.h)
-        links = inference.resample_adjacency_matrix_(sproc, sd.local, seed=1, step=k, model=smodel, fetch=False, ctx=ctx)
-        _all_reduce_sum(np.array([links]))
-        _lib.check(_lib.lib().nhp_cont_model_moments_accumulate(ctx.h, smodel.h), ctx.h)
-    for k in range(3):
-        sstep(k)
-    ctx.synchronize()
+    nhp.mcmc_(sproc, sd, nsteps=3, seed=1, keep_samples=False, moments=True)
     sync()
     t0 = time.perf_counter()
-    for k in range(3, 3 + steps):
-        sstep(k)
-    ctx.synchronize()
+    nhp.mcmc_(sproc, sd, nsteps=steps, seed=1, keep_samples=False, moments=True)
     sync()
-    return wall, time.perf_counter() - t0
+    return wall, time.perf_counter() - t0, t_gather
 
 
 def main():
@@ -576,7 +576,7 @@ def main():
     if world > 1 and args.chain_steps > 0:
         tw = torch.tensor(list(chains_leg(nhp, ctx, rank, args.chain_steps, sync)), dtype=torch.float64, device=tdev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        chain_wall, one_chain_wall = float(tw[0].item()), float(tw[1].item())
+        chain_wall, one_chain_wall, gather_wall = float(tw[0].item()), float(tw[1].item()), float(tw[2].item())
     sharded = None
     if world > 1 and args.sharded:
         sharded = sharded_leg(nhp, ctx, args.nodes, args.events, world, [x for x in args.sharded.split(",") if x])
@@ -607,6 +607,7 @@ def main():
                 "workload": "c3 model (N=1024, M=1e6, logit-normal network), one mcmc! chain per rank, device-side sweep",
                 "chains": world, "steps_per_chain": args.chain_steps,
                 "mcmc_steps_per_sec": world * args.chain_steps / chain_wall, "ms_per_step": 1e3 * chain_wall / args.chain_steps,
+                "rccl_gather_of_the_chains_posterior_moments_ms": 1e3 * gather_wall,
                 "one_chain_over_all_ranks_ms_per_step": 1e3 * one_chain_wall / args.chain_steps}
         if sharded is not None:
             out["one_evaluation_over_all_ranks"] = sharded
