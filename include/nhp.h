@@ -246,7 +246,8 @@ nhp_status nhp_cont_model_moments_fetch(nhp_ctx *ctx, const nhp_cont_model *mode
 void nhp_uniform_stream(uint64_t seed, uint64_t step, int64_t n, double *u);
 
 /* diagnostics: evaluate a device math primitive elementwise (op 0 exp, 1 log, 2 sqrt, 3 x/y,
- * 4 exp for x<=0, 5 exponential pdf(θ=x, Δt=y), 6 logit-normal pdf(τ=x, Δt=y; μ=.25, Δtmax=2));
+ * 4 exp for x<=0, 5 exponential pdf(θ=x, Δt=y), 6 logit-normal pdf(τ=x, Δt=y; μ=.25, Δtmax=2), 7 the log-likelihood
+ * kernels' table-driven exp for x<=0 (nhp_exp_neg_tab: within 2 ulp, not part of the bitwise contract), 8 θ·e^{-θΔt} through it);
  * lets tests hold the kernels' fixed operation sequences to a bitwise contract */
 nhp_status nhp_probe_math(nhp_ctx *ctx, int32_t op, const double *x, const double *y, int64_t n, double *out);
 /* diagnostics: n device-side random variates with the generators and Philox keying of the Gibbs kernels (nhp_rng.h):

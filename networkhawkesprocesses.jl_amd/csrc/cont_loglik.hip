@@ -110,6 +110,8 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
     double *red = reinterpret_cast<double *>(smem);                 // [waves <= 16] + flag at [16]
     double2 *col = reinterpret_cast<double2 *>(smem + 192);         // [N]
     double *colw = reinterpret_cast<double *>(col + a.N);           // [N], logit-normal only
+    double *etab = colw + (IMP == NHP_IMPULSE_EXPONENTIAL ? 0 : a.N);   // [64] 2^(j/64) for nhp_exp_neg_tab
+    nhp_exp_tab_init(etab);
 
     const nhp_item it = a.items[blockIdx.x];
     const int c = it.node, N = a.N, tid = threadIdx.x;
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
             for (int u = 0; u < U; ++u) {
                 const double dt = t[u] - e[u].t;
                 const double2 q = col[e[u].node];
-                if (IMP == NHP_IMPULSE_EXPONENTIAL) s[u] += q.y * nhp_pdf_exponential_ll(q.x, dt);
+                if (IMP == NHP_IMPULSE_EXPONENTIAL) s[u] += q.y * nhp_pdf_exponential_tab(q.x, dt, etab);
                 else s[u] += colw[e[u].node] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
                 j[u] -= G;
                 e[u] = en[u];
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
                 const double dt = t[u] - e[u].t;
                 const double2 q = col[e[u].node];
                 double term;
-                if (IMP == NHP_IMPULSE_EXPONENTIAL) term = q.y * nhp_pdf_exponential_ll(q.x, dt);
+                if (IMP == NHP_IMPULSE_EXPONENTIAL) term = q.y * nhp_pdf_exponential_tab(q.x, dt, etab);
                 else term = colw[e[u].node] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
                 s[u] += (j[u] >= f[u]) ? term : 0.0;
                 j[u] -= G;
@@ -512,7 +514,9 @@ __global__ __launch_bounds__(THREADS) void k_windowed_batch(nhp_cont_args a, nhp
     extern __shared__ __align__(16) unsigned char smem[];
     double *red = reinterpret_cast<double *>(smem);                 // [2][NW][S] wave sums, then the flag
     int *flag = reinterpret_cast<int *>(red + 2 * NW * S);
-    nhp_event *wbuf = reinterpret_cast<nhp_event *>(smem + 16 * (NW * S + 1));          // [NW][CW][CSTR] staged parent records
+    double *etab = reinterpret_cast<double *>(smem + 16 * (NW * S + 1));                 // [64] 2^(j/64) for nhp_exp_neg_tab
+    nhp_exp_tab_init(etab);
+    nhp_event *wbuf = reinterpret_cast<nhp_event *>(smem + 16 * (NW * S + 1) + 512);    // [NW][CW][CSTR] staged parent records
     double2 *col = reinterpret_cast<double2 *>(wbuf + NW * CW * CSTR);                   // [S][N+1]
     const int N = a.N, NP = N + 1, tid = threadIdx.x;
     double *colw = reinterpret_cast<double *>(col + (size_t)S * NP);                     // [S][N+1], logit-normal only
@@ -656,8 +660,8 @@ __global__ __launch_bounds__(THREADS) void k_windowed_batch(nhp_cont_args a, nhp
                         const double2 q0 = mycol[e0.node], q1 = mycol[e1.node];
                         double t0, t1;
                         if (IMP == NHP_IMPULSE_EXPONENTIAL) {
-                            t0 = q0.y * nhp_pdf_exponential_ll(q0.x, d0);
-                            t1 = q1.y * nhp_pdf_exponential_ll(q1.x, d1);
+                            t0 = q0.y * nhp_pdf_exponential_tab(q0.x, d0, etab);
+                            t1 = q1.y * nhp_pdf_exponential_tab(q1.x, d1, etab);
                         } else {
                             t0 = mycolw[e0.node] * nhp_pdf_logitnormal(q0.x, q0.y, a.inv_dtmax, d0);
                             t1 = mycolw[e1.node] * nhp_pdf_logitnormal(q1.x, q1.y, a.inv_dtmax, d1);
@@ -749,7 +753,7 @@ static size_t batch_lds(const nhp_cont_dataset *ds, bool expo, int threads)
 {
     // wave sums + flag | window buffer [waves][64/S children][S+1 records] | S columns (the finalizing workgroup reuses the
     // window buffer for its 3 x waves x S sums: 24·waves·S <= 16·waves·(64/S)·(S+1) bytes for every S)
-    return 16 * ((size_t)(threads / 64) * S + 1) + 16 * (size_t)(threads / 64) * (64 / S) * (S + 1) + (expo ? 16 : 24) * (size_t)(ds->N + 1) * S;
+    return 16 * ((size_t)(threads / 64) * S + 1) + 512 + 16 * (size_t)(threads / 64) * (64 / S) * (S + 1) + (expo ? 16 : 24) * (size_t)(ds->N + 1) * S;
 
 }
 
@@ -829,7 +833,7 @@ static nhp_status run_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const n
 {
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t per = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? 16 : 24;
-    const size_t lds = 192 + per * (size_t)ds->N;
+    const size_t lds = 192 + per * (size_t)ds->N + 512;            // + the 64-entry exp table
     if (lds > 160 * 1024) { nhp_set_error(ctx, "n_nodes = %d exceeds the 160 KiB LDS column budget", ds->N); return NHP_ENOTIMPL; }
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)ds->n_items));
     nhp_cont_args a = nhp_make_args(ds, m);

@@ -99,6 +99,66 @@ __device__ __forceinline__ double nhp_exp_neg_ll(double x)
     return __builtin_ldexp(nhp_horner13(r), (int)n);
 }
 
+// ---- table-driven exp for the log-likelihood kernels ------------------------------------------------------------------
+// exp(x) = 2^n · 2^(j/64) · e^r with k = rint(x·64/ln2) = 64 n + j and |r| <= ln2/128: a 64-entry table of 2^(j/64) (correctly
+// rounded, kept in LDS: 512 bytes) and a degree-5 polynomial for e^r - 1 (truncation r^6/720 < 4e-17) replace the degree-13
+// polynomial of nhp_exp: 12 fp64 instructions + 3 integer + one 8-byte LDS read instead of 19 fp64.  Within 2 ulp of exp
+// (checked against 200-bit arithmetic for the whole range); NOT bit-identical to nhp_exp, so only the log-likelihood
+// kernels use it -- the parent sampler keeps the det-math sequence it shares with the CPU checker.
+static __device__ const double nhp_exp2_64[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0,
+};
+
+// every thread of the workgroup calls this before a __syncthreads(); `tab` = 64 doubles of LDS
+__device__ __forceinline__ void nhp_exp_tab_init(double *tab)
+{
+    if (threadIdx.x < 64) tab[threadIdx.x] = nhp_exp2_64[threadIdx.x];
+}
+
+__device__ __forceinline__ double nhp_exp_neg_tab(double x, const double *tab)
+{
+#pragma clang fp contract(off)
+    const double K64 = 92.33248261689366;                 // 64 / ln 2
+    const double L64_HI = 0x1.62e42ff000000p-7;           // ln 2 / 64, 32 significant bits: k·L64_HI is exact for |k| < 2^21
+    const double L64_LO = -0x1.718432a1b0e26p-41;
+    const double kf = __builtin_rint(x * K64);
+    double r = __builtin_fma(-kf, L64_HI, x);
+    r = __builtin_fma(-kf, L64_LO, r);
+    const int k = (int)kf;
+    const double t = tab[k & 63];
+    double p;
+    const double c5 = 8.3333333333333332e-03;
+    asm("v_fma_f64 %0, %1, %2, %3\n\t"                    // ((((r/120 + 1/24) r + 1/6) r + 1/2) r + 1) r = e^r - 1
+        "v_fma_f64 %0, %0, %2, %4\n\t"
+        "v_fma_f64 %0, %0, %2, 0.5\n\t"
+        "v_fma_f64 %0, %0, %2, 1.0\n\t"
+        "v_mul_f64 %0, %0, %2"
+        : "=&v"(p)
+        : "v"(c5), "v"(r), "s"(4.1666666666666664e-02), "s"(1.6666666666666666e-01));
+    return __builtin_ldexp(__builtin_fma(t, p, t), k >> 6);
+}
+
+__device__ __forceinline__ double nhp_pdf_exponential_tab(double r, double dt, const double *tab)
+{
+#pragma clang fp contract(off)
+    return r * nhp_exp_neg_tab(-(r * dt), tab);
+}
+
 __device__ __forceinline__ double nhp_log(double x)
 {
 #pragma clang fp contract(off)

@@ -8,9 +8,14 @@ __global__ void k_probe(int op, const double *__restrict__ x, const double *__re
 {
 #pragma clang fp contract(off)
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double etab[64];
+    nhp_exp_tab_init(etab);
+    __syncthreads();
     if (i >= n) return;
     double a = x[i], b = y ? y[i] : 0.0, r;
     switch (op) {
+    case 7: r = nhp_exp_neg_tab(a, etab); break;                       // the log-likelihood kernels' table-driven exp, x <= 0
+    case 8: r = nhp_pdf_exponential_tab(a, b, etab); break;            // (θ, Δt) through it
     case 0: r = nhp_exp(a); break;
     case 1: r = nhp_log(a); break;
     case 2: r = __builtin_sqrt(a); break;

@@ -45,6 +45,25 @@ def test_det_math_is_bitwise_identical(nhp, orc):
     assert np.array_equal(probe(nhp, 6, tau, dt).view(np.uint64), want.view(np.uint64))
 
 
+def test_table_driven_exp_of_the_loglik_kernels_is_within_two_ulp(nhp):
+    """nhp_exp_neg_tab (64-entry 2^(j/64) table in LDS + degree-5 polynomial; csrc/nhp_math.h) is what the log-likelihood
+    kernels evaluate e^{-θΔt} with: not bit-identical to the det-math exp the sampler shares with the oracle, but within
+    2 ulp of the correctly rounded value over the whole range, underflowing gradually like exp itself."""
+    import mpmath as mp
+    rng = np.random.default_rng(7)
+    x = np.concatenate([-rng.uniform(0.0, 745.0, 150_000), -np.exp(rng.uniform(-40, 3, 100_000)), [0.0, -1e-300, -708.0, -744.0, -745.2, -800.0, -1e6]])
+    got = probe(nhp, 7, x)
+    want = np.exp(x)                                    # (glibc: < 1 ulp)
+    big = want > 1e-300
+    assert np.max(np.abs(got[big] - want[big]) / want[big]) < 3.0 * 2.0 ** -53
+    assert np.all(np.abs(got[~big] - want[~big]) <= 4e-308 * 1e-15 + 3.0 * 2.0 ** -53 * want[~big] + 5e-324 * 4)
+    assert got[-1] == 0.0 and got[-2] == 0.0 and got[len(x) - 7] == 1.0
+    mp.mp.prec = 120                                    # a few points against 120-bit arithmetic
+    for v in (-0.3, -5.25, -37.0, -123.456, -700.5):
+        g = float(probe(nhp, 7, np.array([v]))[0])
+        assert abs((mp.mpf(g) - mp.exp(mp.mpf(v))) / mp.exp(mp.mpf(v))) < 2.3 * mp.mpf(2) ** -53
+
+
 def test_uniform_stream_matches_oracle(nhp, orc):
     for seed, step in ((0, 0), (1, 7), (2 ** 63 + 5, 2 ** 40 + 3)):
         assert np.array_equal(nhp.uniform_stream(seed, step, 1000), orc.uniform_stream(seed, step, 1000))
