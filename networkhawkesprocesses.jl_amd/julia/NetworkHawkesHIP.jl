@@ -180,7 +180,7 @@ function resample_parents(p::NHP.ContinuousHawkesProcess, data; seed::UInt64=UIn
     cnt0, Mn, Mnm, Xnm, Vnm = zeros(N), zeros(N), zeros(N, N), zeros(N, N), zeros(N, N)
     st = Ref(Stats(pointer(cnt0), pointer(Mn), pointer(Mnm), pointer(Xnm), pointer(Vnm)))
     with_model(ctx, p) do m
-        GC.@preserve cnt0 Mn Mnm Xnm Vnm check(ccall((:nhp_cont_resample_parents, libnhp), Int32,
+        GC.@preserve st cnt0 Mn Mnm Xnm Vnm check(ccall((:nhp_cont_resample_parents, libnhp), Int32,
                     (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, UInt64, UInt64, Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}),
                     ctx.h, ds.h, m, C_NULL, seed, step, parents, parentnodes, stats ? Base.unsafe_convert(Ptr{Cvoid}, st) : C_NULL), ctx.h)
     end

@@ -109,6 +109,31 @@ def test_config3_adjacency_columns_at_full_size(nhp, orc, config3):
         assert 0 < want[:, col].sum() < N
 
 
+def test_config5_chains_at_full_size_on_one_gpu(nhp, config3):
+    """BASELINE config 5 is 8 chains of config 3, one per GPU, gathered once.  What one GPU can rehearse at the REAL size: two
+    chains of the N=1024, M=1e6 logit-normal network model run by chains.run_chains (the library's chain driver, posterior
+    moments on the device) -- each chain's gathered summary equals what the same chain gives when it is run by hand, the two
+    chains differ, and the sweep leaves a valid state (A binary, ρ in (0, 1), positive rates)."""
+    from nhp_amd import chains
+    c = config3
+
+    def make(k):
+        return nhp.synthetic.s_metric_process(c["N"], c["M"], c["T"], "logitnormal", 1.0, network=True)
+    out = chains.run_chains(make, c["data"], n_chains=2, nsteps=6, base_seed=3, burn=2)
+    assert sorted(out) == [0, 1] and out[0]["n"][0] == out[1]["n"][0] == 4
+    P = 1 + c["N"] + 4 * c["N"] ** 2                             # [ρ; λ0; W; μ; τ; vec(A)]  src/continuous.jl:325-333
+    assert out[0]["mean"].shape == (P,) and not np.array_equal(out[0]["mean"], out[1]["mean"])
+    proc = make(0)
+    res = nhp.mcmc_(proc, c["data"], nsteps=6, seed=chains.chain_seed(3, 0), keep_samples=False, moments=True, burn=2)
+    assert np.array_equal(res.mean, out[0]["mean"]) and np.array_equal(res.m2, out[0]["m2"])
+    A = proc.adjacency_matrix
+    assert set(np.unique(A)) <= {0.0, 1.0} and 0.0 < proc.network.ρ < 1.0
+    assert abs(A.mean() - proc.network.ρ) < 0.01                  # ρ | A ~ Beta(1 + ΣA, 1 + N² - ΣA), N² = 10⁶ entries
+    assert np.all(proc.baseline.λ > 0) and np.all(proc.weights.W > 0) and np.all(proc.impulses.τ > 0)
+    mean_A = out[0]["mean"][-c["N"] ** 2:]
+    assert 0.0 <= mean_A.min() and mean_A.max() <= 1.0
+
+
 def test_config3_loglikelihood_slices_at_full_size(nhp, orc, config3):
     # the logit-normal network kernel at full size: per-event intensities of random slices vs the oracle, and the
     # log-likelihood rebuilt from them (masked integral term, src/continuous.jl:368-371)
