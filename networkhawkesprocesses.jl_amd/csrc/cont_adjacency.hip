@@ -152,7 +152,11 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_eval(nhp_cont_args a, const d
                                                         const int64_t *__restrict__ pair_off,
                                                         const int32_t *__restrict__ ent_k, const int32_t *__restrict__ ent_p,
                                                         const double *__restrict__ ent_dt, double *__restrict__ ent_x,
-                                                        int max_children, double *__restrict__ lam_g)
+                                                        int max_children, double *__restrict__ lam_g,
+                                                        const double *__restrict__ rho_mat, double rho_host,
+                                                        const double *__restrict__ rho_dev, const double *__restrict__ u,
+                                                        uint64_t seed, uint64_t step, double *__restrict__ uni_out,
+                                                        double *__restrict__ bias_out)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = a.N, c = a.col_begin + blockIdx.x, tid = threadIdx.x;
@@ -170,6 +174,14 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_eval(nhp_cont_args a, const d
             colw[p] = a.W[k];
         }
         acol[p] = A[k];
+        // The per-entry constants of the sweep -- logit of the Bernoulli draw, prior log-odds - W·cnt -- are data of this
+        // sweep, not of the chain: computed here, 256 lanes wide (the one-wave chain used to spend ~400 dependent
+        // instructions per 64 parents on them).  The Bernoulli rule u <= exp(ll1 - logsumexp(ll0, ll1)) = 1/(1 + e^{-d}) is
+        // logit(u) <= d (src/continuous.jl:472-487 with [3P] rand(Bernoulli(q)) = rand() <= q).
+        const double rho = rho_mat ? rho_mat[k] : (rho_dev ? *rho_dev : rho_host);
+        const double uu = u ? u[k] : nhp_philox_uniform(seed ^ 0xBE5466CF34E90C6Cull, step, k);
+        uni_out[k] = nhp_log(uu / (1.0 - uu));
+        bias_out[k] = -(a.W[k] * a.cnt[p]) + nhp_log(rho) - nhp_log(1.0 - rho);
     }
     for (int k = tid; k < nchild; k += NHP_BLOCK) lam[k] = adj_baseline(a, c, a.child[kb + k].t);
     __syncthreads();
@@ -244,18 +256,22 @@ __device__ __forceinline__ double adj_readlane(double v, int l)     // l is wave
 // visible before any lane reads them back).  The per-entry constants -- logit of the uniform draw,
 // prior log-odds - W·cnt, current A -- are computed 64 parents at a time, one per lane, and handed to
 // the chain with v_readlane; the entry lists of parent p+1 are fetched while p is processed.
+#ifdef NHP_STAMP
+__device__ unsigned long long g_adj_stamps[4 * 1024];
+extern "C" int nhp_debug_adj_stamps(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_adj_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 __global__ __launch_bounds__(64) void k_adj_sweep(nhp_cont_args a, double *__restrict__ A,
                                                   const int64_t *__restrict__ pair_off,
                                                   const int32_t *__restrict__ ent_k, const double *__restrict__ ent_x,
                                                   const int32_t *__restrict__ col_start, const unsigned char *__restrict__ col_group,
                                                   const double *__restrict__ lam_g,
-                                                  const double *__restrict__ rho_mat, double rho_host,
-                                                  const double *__restrict__ rho_dev,
-                                                  const double *__restrict__ u, uint64_t seed, uint64_t step,
+                                                  const double *__restrict__ uni_g, const double *__restrict__ bias_g,
                                                   int max_children, double *__restrict__ col_links)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const double rho_scalar = rho_dev ? *rho_dev : rho_host;          // device-resident ρ of the network model, if any
     const int N = a.N, c = a.col_begin + blockIdx.x, lane = threadIdx.x;
     double *lam = reinterpret_cast<double *>(smem);                        // [max_children] current λ_k
     double *dx = lam + max_children;                                       // [max_children] Σ x_kp of the current p
@@ -272,18 +288,23 @@ __global__ __launch_bounds__(64) void k_adj_sweep(nhp_cont_args a, double *__res
     double links = 0.0;
     double c_uni = 0.0, c_bias = 0.0, c_a = 0.0;                            // this lane's parent of the current 64-chunk
     // per-entry constants of 64 parents at a time, one per lane: logit of the draw, prior log-odds - W·cnt, A
-    auto refresh = [&](const int p64) {
+    // logit(u), prior log-odds - W·cnt (both from k_adj_eval) and the current A of lane's parent: loaded one 64-parent chunk
+    // AHEAD (n_*), handed over at the chunk start -- the loads are ~20 steps old by then, so the hand-over does not wait
+    double n_uni = 0.0, n_bias = 0.0, n_a = 0.0;
+    auto chunk_load = [&](const int p64) {
         const int pp = p64 + lane;
         if (pp < N) {
             const size_t kq = (size_t)pp + (size_t)c * N;
-            const double rho = rho_mat ? rho_mat[kq] : rho_scalar;
-            // the Bernoulli rule u <= exp(ll1 - logsumexp(ll0, ll1)) = 1/(1 + e^{-d}) is logit(u) <= d:
-            // the logit is taken here, off the chain, which then carries no exp and no division
-            const double uu = u ? u[kq] : nhp_philox_uniform(seed ^ 0xBE5466CF34E90C6Cull, step, kq);
-            c_uni = nhp_log(uu / (1.0 - uu));
-            c_bias = -(a.W[kq] * a.cnt[pp]) + nhp_log(rho) - nhp_log(1.0 - rho);
-            c_a = A[kq];
+            n_uni = uni_g[kq];
+            n_bias = bias_g[kq];
+            n_a = A[kq];                                                 // (entries of a later chunk: not yet rewritten)
         }
+    };
+    chunk_load(0);
+    auto refresh = [&](const int p64) {
+        c_uni = n_uni; c_bias = n_bias; c_a = n_a;
+        chunk_load(p64 + 64);
+        asm volatile("" ::: "memory");
     };
 
     // ---- a group of g <= 4 independent parents p .. p+g-1 (same 64-chunk): 16 lanes per parent, one entry per
@@ -316,62 +337,131 @@ __global__ __launch_bounds__(64) void k_adj_sweep(nhp_cont_args a, double *__res
     };
 
     // ---- one parent alone (a long list, or a child named more than once): lane l owns entries eb + l, eb + l + 64, ...
-    auto visit_general = [&](const int p) {
+    // Its first 64 entries arrive like a group's, requested one step ahead (ck, cx): nearly every such list is shorter,
+    // so the step has no global load on its chain (it had two round trips: ~3 us per step, 1/4 of the sweep).
+    auto visit_general = [&](const int p, const int ck, const double cx) {
         const int eb = start[p], ee = start[p + 1];
         const size_t kpc = (size_t)p + (size_t)c * N;
         const double aold = adj_readlane(c_a, p & 63);
         const double uni_p = adj_readlane(c_uni, p & 63), bias_p = adj_readlane(c_bias, p & 63);
-        for (int e = eb + lane; e < ee; e += 64) atomicAdd(&dx[ent_k[base + e]], ent_x[base + e]);
+        if (ck >= 0) atomicAdd(&dx[ck], cx);
+        for (int e = eb + 64 + lane; e < ee; e += 64) atomicAdd(&dx[ent_k[base + e]], ent_x[base + e]);
         NHP_LDS_SYNC();
         double delta = 0.0;
-        for (int e = eb + lane; e < ee; e += 64) {
-            const int k = ent_k[base + e];
+        auto own = [&](const int k) {
             if (atomicExch(&marker[k], p + 1) != p + 1) {           // first entry of child k for this p owns it
                 const double d = dx[k];
                 const double l0 = lam[k] - aold * d;
                 delta += nhp_log(l0 + d) - nhp_log(l0);
             }
-        }
+        };
+        if (ck >= 0) own(ck);
+        for (int e = eb + 64 + lane; e < ee; e += 64) own(ent_k[base + e]);
         delta = nhp_wave_sum(delta);
         const double anew = uni_p <= bias_p + delta ? 1.0 : 0.0;    // ll1 - ll0 = bias + delta
         if (lane == 0) A[kpc] = anew;
         links += anew;
-        for (int e = eb + lane; e < ee; e += 64) {
-            const int k = ent_k[base + e];
+        auto settle = [&](const int k) {
             // the first taker carries the child's total
             const double dd = __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long *>(&dx[k]), 0ull));
             if (dd != 0.0 && anew != aold) lam[k] += (anew - aold) * dd;
-        }
+        };
+        if (ck >= 0) settle(ck);
+        for (int e = eb + 64 + lane; e < ee; e += 64) settle(ent_k[base + e]);
         NHP_LDS_SYNC();
     };
 
-    // entry of lane l in the group headed by p: slot l/16 -> parent p + slot, entry start + l%16
-    auto fetch = [&](const int p, const int code, int *k_out, double *x_out) {
-        *k_out = -1; *x_out = 0.0;
-        if (p < N && code != 255) {
-            const int slot = lane >> 4;
-            if (slot < code) {
-                const int e = start[p + slot] + (lane & 15);
-                if (e < start[p + slot + 1]) { *k_out = ent_k[base + e]; *x_out = ent_x[base + e]; }
+    // entries of the step headed by p, one per lane: a group (slot l/16 -> parent p + slot, entry start + l%16) or the
+    // first 64 entries of a lone parent.  locate() reads the list bounds (LDS) and is issued BEFORE the current step's work,
+    // request() sends the global loads after it: neither LDS latency nor the global round trip sits on the chain.
+    auto locate = [&](const int p, const int code) {
+        int e = -1;
+        if (p < N) {
+            if (code == 255) {
+                e = start[p] + lane;
+                if (e >= start[p + 1]) e = -1;
+            } else {
+                const int slot = lane >> 4;
+                if (slot < code) {
+                    e = start[p + slot] + (lane & 15);
+                    if (e >= start[p + slot + 1]) e = -1;
+                }
             }
         }
+        return e;
     };
-    int p = 0, code = N > 0 ? grp[0] : 255;
-    int ck, nk;
-    double cx, nx;
-    fetch(0, code, &ck, &cx);
-    while (p < (NHP_SKIP(a, 64) ? 0 : N)) {
-        if ((p & 63) == 0 || p == 0) refresh(p & ~63);
-        const int step_len = code == 255 ? 1 : code;
-        const int pn = p + step_len;
-        const int ncode = pn < N ? grp[pn] : 255;
-        fetch(pn, ncode, &nk, &nx);                                  // the next step's entries, in flight under this one
-        if (code == 255) visit_general(p);
-        else visit_group(p, code, ck, cx);
-        // a group never straddles a 64-parent chunk, so the refresh test above sees every chunk start
-        p = pn; code = ncode; ck = nk; cx = nx;
+    auto request = [&](const int e, int *k_out, double *x_out) {
+        *k_out = -1; *x_out = 0.0;
+        if (e >= 0) { *k_out = ent_k[base + e]; *x_out = ent_x[base + e]; }
+    };
+    auto fetch = [&](const int p, const int code, int *k_out, double *x_out) { request(locate(p, code), k_out, x_out); };
+#ifdef NHP_STAMP
+    unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+    int n_steps = 0, n_general = 0;
+    unsigned long long t_general = 0;
+#endif
+    // The chain walks the steps in order; what a step needs from global memory -- its entries {child slot, x} -- is data only,
+    // and which entries those are follows from the grouping codes (LDS).  One global round trip is ~1500 cycles, a step's own
+    // work ~850: the entries are therefore requested THREE steps ahead, into three register sets used round-robin (the loop
+    // is unrolled by three so no set is ever copied: a register hand-over would wait for the load it carries).
+    auto step_len = [&](const int q, const int cq) { return cq == 255 ? 1 : cq; };
+    auto code_at = [&](const int q) { return q < N ? (int)grp[q] : 255; };
+    int p0 = 0, c0 = code_at(0);
+    int p1 = p0 + step_len(p0, c0), c1 = code_at(p1);
+    int p2 = p1 + step_len(p1, c1), c2 = code_at(p2);
+    int kA, kB, kC;
+    double xA, xB, xC;
+    fetch(p0, c0, &kA, &xA);
+    fetch(p1, c1, &kB, &xB);
+    fetch(p2, c2, &kC, &xC);
+    const int NL = NHP_SKIP(a, 64) ? 0 : N;
+#ifdef NHP_STAMP
+#define ADJ_COUNT(code_) do { ++n_steps; if ((code_) == 255) ++n_general; } while (0)
+#else
+#define ADJ_COUNT(code_) do { } while (0)
+#endif
+#ifdef NHP_STAMP
+    unsigned long long sec[5] = {0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+#define ADJ_SEC(i) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); sec[i] += tn_ - tl; tl = tn_; } while (0)
+#else
+#define ADJ_SEC(i) do { } while (0)
+#endif
+#define ADJ_STEP(KS, XS)                                                                                      \
+    {                                                                                                         \
+        ADJ_SEC(4);                                                                                           \
+        if ((p0 & 63) == 0) refresh(p0);                 /* a group never straddles a 64-parent chunk */     \
+        ADJ_COUNT(c0);                                                                                        \
+        ADJ_SEC(0);                                                                                           \
+        const int p3 = p2 + step_len(p2, c2), c3 = code_at(p3);                                               \
+        const int e3 = locate(p3, c3);                   /* list bounds of step s + 3: LDS reads under this step */ \
+        ADJ_SEC(1);                                                                                           \
+        if (c0 == 255) visit_general(p0, KS, XS);                                                             \
+        else visit_group(p0, c0, KS, XS);                                                                     \
+        ADJ_SEC(2);                                                                                           \
+        request(e3, &KS, &XS);                           /* step s + 3 into the set step s has just freed */ \
+        ADJ_SEC(3);                                                                                           \
+        asm volatile("" ::: "memory");                   /* keep the prefetch where it is issued */          \
+        p0 = p1; c0 = c1; p1 = p2; c1 = c2; p2 = p3; c2 = c3;                                                 \
     }
+    while (p0 < NL) {
+        ADJ_STEP(kA, xA)
+        if (p0 >= NL) break;
+        ADJ_STEP(kB, xB)
+        if (p0 >= NL) break;
+        ADJ_STEP(kC, xC)
+    }
+#undef ADJ_STEP
     if (lane == 0 && col_links) col_links[c] = links;
+#ifdef NHP_STAMP
+    if (lane == 0 && blockIdx.x < 1024) {
+        g_adj_stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_begin;
+        g_adj_stamps[4 * blockIdx.x + 1] = n_steps;
+        g_adj_stamps[4 * blockIdx.x + 2] = n_general;
+        g_adj_stamps[4 * blockIdx.x + 3] = t_general;
+        if (blockIdx.x == 7) printf("col 7: %d steps; cycles per step: refresh %.0f, locate %.0f, visit %.0f, request %.0f, shift+loop %.0f\n", n_steps,
+                                    (double)sec[0] / n_steps, (double)sec[1] / n_steps, (double)sec[2] / n_steps, (double)sec[3] / n_steps, (double)sec[4] / n_steps);
+    }
+#endif
 }
 
 // One sweep of A, enqueued on the ctx stream; the per-column link counts are left at *d_links_out [N] in the scratch.
@@ -419,6 +509,7 @@ nhp_status nhp_adj_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_mo
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t r = off; off += (bytes + 255) & ~(size_t)255; return r; };
     const size_t o_x = carve(8 * P), o_u = carve(8 * NN), o_rho = carve(8 * NN), o_links = carve(8 * N), o_lam = carve(8 * M1);
+    const size_t o_uni = carve(8 * NN), o_bias = carve(8 * NN);
     NHP_TRY(nhp_ctx_reserve_scratch(ctx, off));
     char *base = (char *)ctx->d_scratch;
     if (u) NHP_HIP(ctx, hipMemcpyAsync(base + o_u, u, 8 * NN, hipMemcpyHostToDevice, st));
@@ -430,19 +521,20 @@ nhp_status nhp_adj_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_mo
     const int64_t *d_off = ds->d_adj_off;
     const int32_t *d_k = ds->d_adj_k, *d_start = ds->d_adj_start;
     double *d_x = (double *)(base + o_x), *d_lam = (double *)(base + o_lam);
+    double *d_uni = (double *)(base + o_uni), *d_bias = (double *)(base + o_bias);
     if (expo) {
         if (lds_eval > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_eval<NHP_IMPULSE_EXPONENTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval));
         hipLaunchKernelGGL((k_adj_eval<NHP_IMPULSE_EXPONENTIAL>), dim3(ncol), dim3(NHP_BLOCK), lds_eval, st, a, m->d_A,
-                           d_off, d_k, ds->d_adj_p, ds->d_adj_dt, d_x, max_children, d_lam);
+                           d_off, d_k, ds->d_adj_p, ds->d_adj_dt, d_x, max_children, d_lam, d_rho, rho, d_rho_scalar, d_u, seed, step, d_uni, d_bias);
     } else {
         if (lds_eval > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_eval<NHP_IMPULSE_LOGITNORMAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval));
         hipLaunchKernelGGL((k_adj_eval<NHP_IMPULSE_LOGITNORMAL>), dim3(ncol), dim3(NHP_BLOCK), lds_eval, st, a, m->d_A,
-                           d_off, d_k, ds->d_adj_p, ds->d_adj_dt, d_x, max_children, d_lam);
+                           d_off, d_k, ds->d_adj_p, ds->d_adj_dt, d_x, max_children, d_lam, d_rho, rho, d_rho_scalar, d_u, seed, step, d_uni, d_bias);
     }
     NHP_HIP(ctx, hipGetLastError());
     if (lds_sweep > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sweep));
     hipLaunchKernelGGL(k_adj_sweep, dim3(ncol), dim3(64), lds_sweep, st, a, m->d_A, d_off, d_k, d_x, d_start, ds->d_adj_group, d_lam,
-                       d_rho, rho, d_rho_scalar, d_u, seed, step, max_children, d_links);
+                       d_uni, d_bias, max_children, d_links);
     NHP_HIP(ctx, hipGetLastError());
     *d_links_out = d_links;
     return NHP_OK;
