@@ -21,6 +21,8 @@
 #include "nhp_internal.h"
 #include "nhp_math.h"
 
+#define NHP_ADJ_RUN_SHIFT 24      // parent word of a cached entry: node | (repeats folded into the entry) << 24
+
 __device__ __forceinline__ double adj_baseline(const nhp_cont_args &a, int c, double t)
 {
 #pragma clang fp contract(off)
@@ -96,6 +98,43 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_build(nhp_cont_args a, const 
         }
     }
     for (int p = tid; p <= N; p += NHP_BLOCK) col_start[(size_t)c * (N + 1) + p] = start[p];
+    // ---- a child named more than once by one parent node (two events of p inside the child's window): the entries of a short
+    // list are put in (child, time) order and the repeats folded into the first of their run -- it carries the run length in the
+    // high bits of its parent word, k_adj_eval sums the run's x into it in that order, the repeats become dead entries
+    // (child -1).  Every short list then names each child once and is eligible for the grouped step; only lists longer than
+    // 16 entries take the general path (they were ~10 % of the steps of the 1024-node case and a quarter of its time).
+    __syncthreads();
+    __threadfence_block();
+    for (int p = tid; p < N; p += NHP_BLOCK) {
+        const int eb = start[p], n = start[p + 1] - eb;
+        if (n < 2 || n > 16) continue;
+        int kk[16];
+        double dd[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { kk[i] = i < n ? ent_k[base + eb + i] : 0x7fffffff; dd[i] = i < n ? ent_dt[base + eb + i] : 0.0; }
+        // odd-even transposition sort on (k ascending, Δt descending = parent time ascending): fixed network, registers only
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int i = r & 1; i + 1 < 16; i += 2) {
+                const bool swap = kk[i] > kk[i + 1] || (kk[i] == kk[i + 1] && dd[i] < dd[i + 1]);
+                const int k0 = kk[i], k1 = kk[i + 1];
+                const double d0 = dd[i], d1 = dd[i + 1];
+                kk[i] = swap ? k1 : k0; kk[i + 1] = swap ? k0 : k1;
+                dd[i] = swap ? d1 : d0; dd[i + 1] = swap ? d0 : d1;
+            }
+        }
+        int run = 0;                                      // repeats that follow entry i (walking backwards)
+#pragma unroll
+        for (int i = 15; i >= 0; --i) {
+            if (i >= n) continue;
+            run = (i + 1 < n && i + 1 < 16 && kk[i + 1 < 16 ? i + 1 : 15] == kk[i]) ? run + 1 : 0;
+            const bool rep = i > 0 && kk[i > 0 ? i - 1 : 0] == kk[i];
+            ent_k[base + eb + i] = rep ? -1 : kk[i];
+            ent_dt[base + eb + i] = dd[i];
+            ent_p[base + eb + i] = p | ((rep ? 0 : run) << NHP_ADJ_RUN_SHIFT);
+        }
+    }
     // Grouping (data only).  Entries (p, c) and (p', c) of a column interact only through children that have
     // parents on both nodes, so consecutive parents whose lists share no child can be decided together with
     // the same result as one after the other.  col_group[p + c·N]: 1..4 = p heads a group of that many
@@ -116,9 +155,11 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_build(nhp_cont_args a, const 
             const int eb = start[q], ee = start[q + 1];
             if (ee - eb > 16) return false;
             for (int e = eb; e < ee; ++e) {
-                int &sk = seen[ent_k[base + e]];
+                const int ke = ent_k[base + e];
+                if (ke < 0) continue;                    // (a folded repeat)
+                int &sk = seen[ke];
                 if (sk == id) {
-                    for (int e2 = eb; e2 < e; ++e2) seen[ent_k[base + e2]] = 0;
+                    for (int e2 = eb; e2 < e; ++e2) if (ent_k[base + e2] >= 0) seen[ent_k[base + e2]] = 0;
                     return false;
                 }
                 sk = id;
@@ -128,14 +169,10 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_build(nhp_cont_args a, const 
         auto take = [&](int, int) {};                    // (fits() has marked the list)
         while (p < N) {
             ++gid;
-            bool ok = start[p + 1] - start[p] <= 16;
-            if (ok) {                                    // a child twice in p's own list?  mark as we go
-                for (int e = start[p]; e < start[p + 1]; ++e) {
-                    int &sk = seen[ent_k[base + e]];
-                    if (sk == gid) { ok = false; break; }
-                    sk = gid;
-                }
-            }
+            const bool ok = start[p + 1] - start[p] <= 16;
+            if (ok)                                      // (repeats are folded: a short list names a child once)
+                for (int e = start[p]; e < start[p + 1]; ++e)
+                    if (ent_k[base + e] >= 0) seen[ent_k[base + e]] = gid;
             if (!ok) { grp[p] = 255; ++p; continue; }
             int g = 1;
             while (g < 4 && p + g < N && ((p + g) & 63) != 0 && fits(p + g, gid)) { take(p + g, gid); grp[p + g] = 0; ++g; }
@@ -197,8 +234,10 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_eval(nhp_cont_args a, const d
             const int64_t e = eb + u * NHP_BLOCK < e1 ? eb + u * NHP_BLOCK : eb;       // clamped: value unused
             p[u] = ent_p[e]; dt[u] = ent_dt[e]; k[u] = ent_k[e];
         }
+        int run[EU];
 #pragma unroll
         for (int u = 0; u < EU; ++u) {
+            run[u] = p[u] >> NHP_ADJ_RUN_SHIFT; p[u] &= (1 << NHP_ADJ_RUN_SHIFT) - 1;
             const double2 q = col[p[u]];
             if (IMP == NHP_IMPULSE_EXPONENTIAL) x[u] = q.y * nhp_pdf_exponential(q.x, dt[u]);
             else x[u] = colw[p[u]] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt[u]);
@@ -206,9 +245,19 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_eval(nhp_cont_args a, const d
 #pragma unroll
         for (int u = 0; u < EU; ++u) {
             if (eb + u * NHP_BLOCK < e1) {
-                ent_x[eb + u * NHP_BLOCK] = x[u];
+                const int64_t e = eb + u * NHP_BLOCK;
+                // the first entry of a run of repeats carries the run's total, summed in list order (k_adj_build); the
+                // repeats themselves (child -1) are dead
+                for (int r = 1; r <= run[u]; ++r) {
+                    const double2 q = col[p[u]];
+                    const double dr = ent_dt[e + r];
+                    if (IMP == NHP_IMPULSE_EXPONENTIAL) x[u] += q.y * nhp_pdf_exponential(q.x, dr);
+                    else x[u] += colw[p[u]] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dr);
+                }
+                if (k[u] < 0) x[u] = 0.0;
+                ent_x[e] = x[u];
                 const double av = acol[p[u]];
-                if (av != 0.0) atomicAdd(&lam[k[u]], av * x[u]);
+                if (av != 0.0 && k[u] >= 0) atomicAdd(&lam[k[u]], av * x[u]);
             }
         }
     }
@@ -269,7 +318,7 @@ __global__ __launch_bounds__(64) void k_adj_sweep(nhp_cont_args a, double *__res
                                                   const int32_t *__restrict__ col_start, const unsigned char *__restrict__ col_group,
                                                   const double *__restrict__ lam_g,
                                                   const double *__restrict__ uni_g, const double *__restrict__ bias_g,
-                                                  int max_children, double *__restrict__ col_links)
+                                                  int max_children, double *__restrict__ col_links, double *__restrict__ sink)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = a.N, c = a.col_begin + blockIdx.x, lane = threadIdx.x;
@@ -281,39 +330,31 @@ __global__ __launch_bounds__(64) void k_adj_sweep(nhp_cont_args a, double *__res
     const int kb = a.boff[c], nchild = a.boff[c + 1] - kb;
     for (int k = lane; k < nchild; k += 64) { lam[k] = lam_g[kb + k]; dx[k] = 0.0; marker[k] = 0; }
     for (int p = lane; p <= N + 1; p += 64) start[p] = col_start[(size_t)c * (N + 1) + (p <= N ? p : N)];
-    for (int p = lane; p <= N; p += 64) grp[p] = p < N ? col_group[(size_t)c * N + p] : 255;
+    for (int p = lane; p <= N; p += 64) grp[p] = p < N ? col_group[(size_t)c * N + p] : 0;      // (0: the empty step past the end)
     NHP_LDS_SYNC();
 
     const int64_t base = pair_off[c];
-    double links = 0.0;
-    double c_uni = 0.0, c_bias = 0.0, c_a = 0.0;                            // this lane's parent of the current 64-chunk
-    // per-entry constants of 64 parents at a time, one per lane: logit of the draw, prior log-odds - W·cnt, A
-    // logit(u), prior log-odds - W·cnt (both from k_adj_eval) and the current A of lane's parent: loaded one 64-parent chunk
-    // AHEAD (n_*), handed over at the chunk start -- the loads are ~20 steps old by then, so the hand-over does not wait
-    double n_uni = 0.0, n_bias = 0.0, n_a = 0.0;
-    auto chunk_load = [&](const int p64) {
-        const int pp = p64 + lane;
-        if (pp < N) {
-            const size_t kq = (size_t)pp + (size_t)c * N;
-            n_uni = uni_g[kq];
-            n_bias = bias_g[kq];
-            n_a = A[kq];                                                 // (entries of a later chunk: not yet rewritten)
-        }
-    };
-    chunk_load(0);
-    auto refresh = [&](const int p64) {
-        c_uni = n_uni; c_bias = n_bias; c_a = n_a;
-        chunk_load(p64 + 64);
-        asm volatile("" ::: "memory");
-    };
-
+    int links = 0;
+    // Every global access of the walk is issued by ALL lanes, every step, at a clamped address: a load or store under a
+    // condition compiles to a skipped block, the number of requests in flight is then unknown to the compiler and its waits
+    // become s_waitcnt vmcnt(0) -- a full round trip per step, whatever was prefetched (measured: 1460 -> ... cycles/step).
+    const size_t cN = (size_t)c * N;
+    const int slot = lane >> 4, sub = lane & 15;
+    const int64_t total = pair_off[N];
+    const int32_t *ek = ent_k + (base < total ? base : 0);             // (an empty last column reads entry 0, and drops it)
+    const double *ex = ent_x + (base < total ? base : 0);
+    const double *ug = uni_g + cN, *bg = bias_g + cN;
+    double *Ac = A + cN;
     // ---- a group of g <= 4 independent parents p .. p+g-1 (same 64-chunk): 16 lanes per parent, one entry per
     // lane, all children distinct -- one LDS read on the chain, no atomics, no ownership marks.  The fp32
     // screening of the general path applies per parent; if any of them is inside its band all are redone in fp64.
-    auto visit_group = [&](const int p, const int g, const int ck, const double cx) {
-        const int slot = lane >> 4, pp = p + (slot < g ? slot : 0);
-        const double aold = __shfl(c_a, pp & 63), uni_p = __shfl(c_uni, pp & 63), bias_p = __shfl(c_bias, pp & 63);
+    auto visit_group = [&](const int p, const int g, const int ck, const double cx, const double uni_p, const double bias_p, const double aold) {
+        const int pp = p + (slot < g ? slot : 0);
+#if defined(ADJ_ABL) && (ADJ_ABL & 2)
+        const double lv = 1.0;
+#else
         const double lv = ck >= 0 ? lam[ck] : 1.0;
+#endif
         const double l0 = ck >= 0 ? lv - aold * cx : 1.0;
         // hardware reciprocal and log2 (≈1 ulp each): the 1e-3 band below is far wider than their error
         float t32 = ck >= 0 ? 0.6931471806f * __builtin_amdgcn_logf(1.0f + (float)cx * __builtin_amdgcn_rcpf((float)l0)) : 0.0f;
@@ -326,24 +367,21 @@ __global__ __launch_bounds__(64) void k_adj_sweep(nhp_cont_args a, double *__res
             delta = nhp_dpp_add(delta, 0); delta = nhp_dpp_add(delta, 1); delta = nhp_dpp_add(delta, 2); delta = nhp_dpp_add(delta, 3);
             an = uni_p <= bias_p + delta ? 1.0 : 0.0;
         }
-        if (slot < g) {
-            if ((lane & 15) == 0) A[(size_t)pp + (size_t)c * N] = an;
-            if (an != aold && ck >= 0) lam[ck] = lv + (an - aold) * cx;
-        }
+#if !defined(ADJ_ABL) || !(ADJ_ABL & 4)
+        *(slot < g ? &Ac[(unsigned)pp] : &sink[c]) = an;             // (16 lanes, one address, one value)
+#endif
+        if (slot < g && an != aold && ck >= 0) lam[ck] = lv + (an - aold) * cx;
         // links: one count per parent of the group
         const unsigned long long heads = __ballot((lane & 15) == 0 && slot < g && an == 1.0);
-        links += (double)__popcll(heads);
+        links += __popcll(heads);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the next step reads these λ in program order
     };
 
     // ---- one parent alone (a long list, or a child named more than once): lane l owns entries eb + l, eb + l + 64, ...
     // Its first 64 entries arrive like a group's, requested one step ahead (ck, cx): nearly every such list is shorter,
     // so the step has no global load on its chain (it had two round trips: ~3 us per step, 1/4 of the sweep).
-    auto visit_general = [&](const int p, const int ck, const double cx) {
+    auto visit_general = [&](const int p, const int ck, const double cx, const double uni_p, const double bias_p, const double aold) {
         const int eb = start[p], ee = start[p + 1];
-        const size_t kpc = (size_t)p + (size_t)c * N;
-        const double aold = adj_readlane(c_a, p & 63);
-        const double uni_p = adj_readlane(c_uni, p & 63), bias_p = adj_readlane(c_bias, p & 63);
         if (ck >= 0) atomicAdd(&dx[ck], cx);
         for (int e = eb + 64 + lane; e < ee; e += 64) atomicAdd(&dx[ent_k[base + e]], ent_x[base + e]);
         NHP_LDS_SYNC();
@@ -359,8 +397,8 @@ __global__ __launch_bounds__(64) void k_adj_sweep(nhp_cont_args a, double *__res
         for (int e = eb + 64 + lane; e < ee; e += 64) own(ent_k[base + e]);
         delta = nhp_wave_sum(delta);
         const double anew = uni_p <= bias_p + delta ? 1.0 : 0.0;    // ll1 - ll0 = bias + delta
-        if (lane == 0) A[kpc] = anew;
-        links += anew;
+        Ac[(unsigned)p] = anew;
+        links += anew == 1.0 ? 1 : 0;
         auto settle = [&](const int k) {
             // the first taker carries the child's total
             const double dd = __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long *>(&dx[k]), 0ull));
@@ -372,94 +410,109 @@ __global__ __launch_bounds__(64) void k_adj_sweep(nhp_cont_args a, double *__res
     };
 
     // entries of the step headed by p, one per lane: a group (slot l/16 -> parent p + slot, entry start + l%16) or the
-    // first 64 entries of a lone parent.  locate() reads the list bounds (LDS) and is issued BEFORE the current step's work,
-    // request() sends the global loads after it: neither LDS latency nor the global round trip sits on the chain.
-    auto locate = [&](const int p, const int code) {
-        int e = -1;
-        if (p < N) {
-            if (code == 255) {
-                e = start[p] + lane;
-                if (e >= start[p + 1]) e = -1;
-            } else {
-                const int slot = lane >> 4;
-                if (slot < code) {
-                    e = start[p + slot] + (lane & 15);
-                    if (e >= start[p + slot + 1]) e = -1;
-                }
-            }
-        }
-        return e;
+    // first 64 entries of a lone parent.  bounds() issues the LDS reads of the list bounds BEFORE the current step's work --
+    // unconditionally, whatever the step's code, so that they do not wait for the code read issued with them -- and request()
+    // turns them into entry indices and sends the global loads AFTER it: neither the LDS latency nor the global round trip
+    // sits on the chain.  The constants of the step's parents -- logit of the draw, prior log-odds - W·cnt (k_adj_eval) and
+    // the current A (a later parent's: not yet rewritten) -- come the same way, 16 lanes sharing an address.
+    struct step_regs { int e, k; double x, uni, bias, a; };           // (k, x are read only where e >= 0: selected at the point of
+                                                                       // use -- a select next to the load would wait for it)
+    auto bounds = [&](const int p, int *s0, int *s1) {
+        const int q = p + slot;
+        *s0 = start[q < N ? q : N];                                    // start[N] == start[N + 1]: nothing past the last parent
+        *s1 = start[q < N ? q + 1 : N + 1];
     };
-    auto request = [&](const int e, int *k_out, double *x_out) {
-        *k_out = -1; *x_out = 0.0;
-        if (e >= 0) { *k_out = ent_k[base + e]; *x_out = ent_x[base + e]; }
+    auto request = [&](const int p, const int code, const int s0, const int s1, step_regs &r, const bool in_loop = true) {
+        const bool lone = code == 255;
+        const int b0 = lone ? __builtin_amdgcn_readfirstlane(s0) + lane : s0 + sub;
+        const int b1 = lone ? __builtin_amdgcn_readfirstlane(s1) : s1;
+        const bool live = lone || slot < code;
+        const int e = live && b0 < b1 ? b0 : -1;
+        int pp = p + (!lone && slot < code ? slot : 0);
+        pp = pp < N ? pp : N - 1;
+        const unsigned at = e >= 0 ? (unsigned)e : 0u;
+#if defined(ADJ_ABL) && (ADJ_ABL & 1)                                      /* timing experiments (tools/dbg/adjabl.sh), compile-time: */
+        if (in_loop) { r.e = e; return; }                               /* a run-time switch would make the requests conditional  */
+#endif
+        r.e = e;
+        r.k = ek[at];
+        r.x = ex[at];
+        r.uni = ug[(unsigned)pp];
+        r.bias = bg[(unsigned)pp];
+        r.a = Ac[(unsigned)pp];
     };
-    auto fetch = [&](const int p, const int code, int *k_out, double *x_out) { request(locate(p, code), k_out, x_out); };
 #ifdef NHP_STAMP
     unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-    int n_steps = 0, n_general = 0;
-    unsigned long long t_general = 0;
 #endif
     // The chain walks the steps in order; what a step needs from global memory -- its entries {child slot, x} -- is data only,
     // and which entries those are follows from the grouping codes (LDS).  One global round trip is ~1500 cycles, a step's own
     // work ~850: the entries are therefore requested THREE steps ahead, into three register sets used round-robin (the loop
     // is unrolled by three so no set is ever copied: a register hand-over would wait for the load it carries).
-    auto step_len = [&](const int q, const int cq) { return cq == 255 ? 1 : cq; };
-    auto code_at = [&](const int q) { return q < N ? (int)grp[q] : 255; };
-    int p0 = 0, c0 = code_at(0);
-    int p1 = p0 + step_len(p0, c0), c1 = code_at(p1);
-    int p2 = p1 + step_len(p1, c1), c2 = code_at(p2);
-    int kA, kB, kC;
-    double xA, xB, xC;
-    fetch(p0, c0, &kA, &xA);
-    fetch(p1, c1, &kB, &xB);
-    fetch(p2, c2, &kC, &xC);
+    // Past the last parent the steps are empty groups (code 0: no live slot), so that the loop always runs whole rounds of
+    // three: an exit between two steps would join the paths "requested just now" and "requested three steps ago", and the
+    // compiler would again have to wait for everything.
+    auto step_len = [&](const int q, const int cq) { return cq == 255 || cq == 0 ? 1 : cq; };
+    auto code_at = [&](const int q) { return (int)grp[q < N ? q : N]; };
+    // (the code read is wave-uniform, and the compiler would move it to a scalar register -- waiting for it -- where it is
+    //  issued: it is kept a vector value until the step's work is done)
+    auto settle_code = [&](int cv) { asm volatile("" : "+v"(cv)); return __builtin_amdgcn_readfirstlane(cv); };
+#ifndef ADJ_DEPTH
+#define ADJ_DEPTH 3
+#endif
+    constexpr int D = ADJ_DEPTH;
+    int P[D], Cq[D];                                                   // heads and codes of the steps in flight (a ring; indices
+    step_regs R[D];                                                    //  are compile-time after unrolling: all of it in registers)
+    P[0] = 0; Cq[0] = code_at(0);
+#pragma unroll
+    for (int j = 1; j < D; ++j) { P[j] = P[j - 1] + step_len(P[j - 1], Cq[j - 1]); Cq[j] = code_at(P[j]); }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        int s0, s1;
+        bounds(P[j], &s0, &s1);
+        request(P[j], Cq[j], s0, s1, R[j], false);
+    }
     const int NL = NHP_SKIP(a, 64) ? 0 : N;
 #ifdef NHP_STAMP
-#define ADJ_COUNT(code_) do { ++n_steps; if ((code_) == 255) ++n_general; } while (0)
-#else
-#define ADJ_COUNT(code_) do { } while (0)
+    int n_steps = 0, n_general = 0;
+    unsigned long long t_general = 0, t_group = 0;
 #endif
+    while (P[0] < NL) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            constexpr int dummy = 0; (void)dummy;
+            const int last = (j + D - 1) % D;                           // the newest step in flight
+            const int pn = P[last] + step_len(P[last], Cq[last]), cnv = code_at(pn);
+            int s0n, s1n;
+            bounds(pn, &s0n, &s1n);                                     // code and list bounds of step s + D: LDS reads under this step
+            const int ck = R[j].e >= 0 ? R[j].k : -1;
+            const double cx = R[j].e >= 0 ? R[j].x : 0.0;
 #ifdef NHP_STAMP
-    unsigned long long sec[5] = {0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
-#define ADJ_SEC(i) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); sec[i] += tn_ - tl; tl = tn_; } while (0)
-#else
-#define ADJ_SEC(i) do { } while (0)
+            const unsigned long long tv0 = __builtin_amdgcn_s_memtime();
 #endif
-#define ADJ_STEP(KS, XS)                                                                                      \
-    {                                                                                                         \
-        ADJ_SEC(4);                                                                                           \
-        if ((p0 & 63) == 0) refresh(p0);                 /* a group never straddles a 64-parent chunk */     \
-        ADJ_COUNT(c0);                                                                                        \
-        ADJ_SEC(0);                                                                                           \
-        const int p3 = p2 + step_len(p2, c2), c3 = code_at(p3);                                               \
-        const int e3 = locate(p3, c3);                   /* list bounds of step s + 3: LDS reads under this step */ \
-        ADJ_SEC(1);                                                                                           \
-        if (c0 == 255) visit_general(p0, KS, XS);                                                             \
-        else visit_group(p0, c0, KS, XS);                                                                     \
-        ADJ_SEC(2);                                                                                           \
-        request(e3, &KS, &XS);                           /* step s + 3 into the set step s has just freed */ \
-        ADJ_SEC(3);                                                                                           \
-        asm volatile("" ::: "memory");                   /* keep the prefetch where it is issued */          \
-        p0 = p1; c0 = c1; p1 = p2; c1 = c2; p2 = p3; c2 = c3;                                                 \
+            if (Cq[j] == 255) visit_general(P[j], ck, cx, R[j].uni, R[j].bias, R[j].a);
+            else visit_group(P[j], Cq[j], ck, cx, R[j].uni, R[j].bias, R[j].a);
+#ifdef NHP_STAMP
+            if (Cq[j] == 255) { ++n_general; t_general += __builtin_amdgcn_s_memtime() - tv0; }
+            else if (Cq[j] != 0) t_group += __builtin_amdgcn_s_memtime() - tv0;
+#endif
+            const int cn = settle_code(cnv);
+            request(pn, cn, s0n, s1n, R[j]);                            // step s + D into the set step s has just freed
+            asm volatile("" ::: "memory");                              // keep the prefetch where it is issued
+            P[j] = pn; Cq[j] = cn;
+#ifdef NHP_STAMP
+            ++n_steps;
+#endif
+        }
     }
-    while (p0 < NL) {
-        ADJ_STEP(kA, xA)
-        if (p0 >= NL) break;
-        ADJ_STEP(kB, xB)
-        if (p0 >= NL) break;
-        ADJ_STEP(kC, xC)
-    }
-#undef ADJ_STEP
-    if (lane == 0 && col_links) col_links[c] = links;
+    if (lane == 0 && col_links) col_links[c] = (double)links;
 #ifdef NHP_STAMP
     if (lane == 0 && blockIdx.x < 1024) {
         g_adj_stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_begin;
         g_adj_stamps[4 * blockIdx.x + 1] = n_steps;
         g_adj_stamps[4 * blockIdx.x + 2] = n_general;
         g_adj_stamps[4 * blockIdx.x + 3] = t_general;
-        if (blockIdx.x == 7) printf("col 7: %d steps; cycles per step: refresh %.0f, locate %.0f, visit %.0f, request %.0f, shift+loop %.0f\n", n_steps,
-                                    (double)sec[0] / n_steps, (double)sec[1] / n_steps, (double)sec[2] / n_steps, (double)sec[3] / n_steps, (double)sec[4] / n_steps);
+        if (blockIdx.x == 7) printf("col 7: %d steps, %d lone: visit cycles per step: lone %.0f, group %.0f\n", n_steps, n_general,
+                                    (double)t_general / n_general, (double)t_group / (n_steps - n_general));
     }
 #endif
 }
@@ -509,7 +562,7 @@ nhp_status nhp_adj_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_mo
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t r = off; off += (bytes + 255) & ~(size_t)255; return r; };
     const size_t o_x = carve(8 * P), o_u = carve(8 * NN), o_rho = carve(8 * NN), o_links = carve(8 * N), o_lam = carve(8 * M1);
-    const size_t o_uni = carve(8 * NN), o_bias = carve(8 * NN);
+    const size_t o_uni = carve(8 * NN), o_bias = carve(8 * NN), o_sink = carve(8 * N);
     NHP_TRY(nhp_ctx_reserve_scratch(ctx, off));
     char *base = (char *)ctx->d_scratch;
     if (u) NHP_HIP(ctx, hipMemcpyAsync(base + o_u, u, 8 * NN, hipMemcpyHostToDevice, st));
@@ -534,7 +587,7 @@ nhp_status nhp_adj_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_mo
     NHP_HIP(ctx, hipGetLastError());
     if (lds_sweep > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sweep));
     hipLaunchKernelGGL(k_adj_sweep, dim3(ncol), dim3(64), lds_sweep, st, a, m->d_A, d_off, d_k, d_x, d_start, ds->d_adj_group, d_lam,
-                       d_uni, d_bias, max_children, d_links);
+                       d_uni, d_bias, max_children, d_links, (double *)(base + o_sink));
     NHP_HIP(ctx, hipGetLastError());
     *d_links_out = d_links;
     return NHP_OK;
