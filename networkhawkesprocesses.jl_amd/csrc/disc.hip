@@ -50,7 +50,9 @@ struct gemm_args {
 // C[m,n] = Σ_k Aop[m,k]·B[k + n·ldb];  A_MCONTIG: Aop[m,k] = A[m + k·lda], else A[k + m·lda].
 // TBM = rows of the output tile: 128, or 160 for the m-contiguous GEMM-1 when that fills the last round of workgroups
 // better (gemm1_tile_m): 5 instead of 4 MFMA row-fragments per wave, everything else alike.
-template <bool A_MCONTIG, int EPI, int TBM = BM>
+// WHOLE: every tile of every workgroup is inside the matrices and the reduction chunk is whole BK-tiles (the host checks):
+// the main loop is then branch-free and scheduled instruction by instruction (tile_whole).
+template <bool A_MCONTIG, int EPI, int TBM = BM, bool WHOLE = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 waves/SIMD: <= 256 VGPR+AGPR
 {
     static_assert(TBM % 32 == 0 && (A_MCONTIG || TBM == BM), "the k-contiguous A staging covers 128 rows");
@@ -60,9 +62,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
     constexpr int EA = A_MCONTIG ? MS * (BK / 16) : EPT;            // staged A elements per thread
     constexpr int A_LD = TBM + 16;                                 // m-contiguous image: row stride ≡ 128 B (mod 256)
     extern __shared__ __align__(16) double gsm[];
-    double *As = gsm;                                              // [A_MCONTIG ? BK * A_LD : BM * KC_LD]
-    double *Bs = As + (A_MCONTIG ? BK * A_LD : BM * KC_LD);        // [BN * KC_LD]
-    double *red = Bs + BN * KC_LD;                                 // [NHP_WAVES]
+    // two stages of {A image, B image}: tile k+1 is written while tile k is read, ONE barrier per tile.  The epilogue's small
+    // reduction arrays reuse stage 0 after the last tile's barrier.
+    constexpr int SA = A_MCONTIG ? BK * A_LD : BM * KC_LD, SB = BN * KC_LD, STAGE = SA + SB;
+    double *red = gsm;                                             // [NHP_WAVES]
     double(*wcol)[64] = reinterpret_cast<double(*)[64]>(red + NHP_WAVES);   // [NHP_WAVES][64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -105,24 +108,35 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
     for (int e = 0; e < (A_MCONTIG ? MS : 8); ++e) a_ok |= ((A_MCONTIG ? m0 + a_m + 16 * e : m0 + a_m) < g.M ? 1u : 0u) << e;   // bit e: m-slot e
     const bool b_ok = n0 + b_n < g.N;
 
+    // Interior tiles (every row, column and k of the tile inside the matrix -- all of them at the benchmark shape) load
+    // unconditionally: a predicated load compiles to an exec-mask branch of its own, ~20 of them per tile on the path of a
+    // wave whose every non-MFMA cycle is taken from the matrix pipe.
+    const bool interior = m0 + TBM <= g.M && n0 + BN <= g.N;
     auto load_tiles = [&](int k0) {
         const bool full = k0 + BK <= kend;   // only the last tile of a ragged K needs per-element checks
+        if (interior && full) {
 #pragma unroll
-        for (int e = 0; e < EA; ++e) {
-            // m-contig: element e = (m-slot e % MS, k-row a_k + 16 (e / MS)); k-contig: k offset a_k + e
-            const bool ka = full || (A_MCONTIG ? k0 + a_k + 16 * (e / MS) : k0 + a_k + e) < kend;
-            const bool ma = A_MCONTIG ? ((a_ok >> (e % MS)) & 1u) : (a_ok & 1u);
-            ra[e] = ma && ka ? (A_MCONTIG ? pa[16 * (e % MS) + (size_t)(16 * (e / MS)) * g.lda] : pa[e]) : 0.0;
-        }
+            for (int e = 0; e < EA; ++e) ra[e] = A_MCONTIG ? pa[16 * (e % MS) + (size_t)(16 * (e / MS)) * g.lda] : pa[e];
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const bool kb = full || k0 + b_k + e < kend;
-            rb[e] = b_ok && kb ? pb[e] : 0.0;
+            for (int e = 0; e < EPT; ++e) rb[e] = pb[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < EA; ++e) {
+                // m-contig: element e = (m-slot e % MS, k-row a_k + 16 (e / MS)); k-contig: k offset a_k + e
+                const bool ka = full || (A_MCONTIG ? k0 + a_k + 16 * (e / MS) : k0 + a_k + e) < kend;
+                const bool ma = A_MCONTIG ? ((a_ok >> (e % MS)) & 1u) : (a_ok & 1u);
+                ra[e] = ma && ka ? (A_MCONTIG ? pa[16 * (e % MS) + (size_t)(16 * (e / MS)) * g.lda] : pa[e]) : 0.0;
+            }
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const bool kb = full || k0 + b_k + e < kend;
+                rb[e] = b_ok && kb ? pb[e] : 0.0;
+            }
         }
         pa += a_step;
         pb += BK;
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](double *As, double *Bs) {
 #pragma unroll
         for (int e = 0; e < EA; ++e) {
             if (A_MCONTIG) As[(a_k + 16 * (e / MS)) * A_LD + a_m + 16 * (e % MS)] = ra[e];
@@ -131,37 +145,181 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
 #pragma unroll
         for (int e = 0; e < EPT; ++e) Bs[b_n * KC_LD + b_k + e] = rb[e];
     };
+    struct frag { double a[MI], b[4]; };
+    auto read_slab = [&](const double *As, const double *Bs, const int ks, frag &f) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = wm * (TBM / 2) + i * 16 + r16;
+            f.a[i] = A_MCONTIG ? As[(ks * 4 + kk) * A_LD + m] : As[m * KC_LD + ks * 4 + kk];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = wn * 64 + i * 16 + r16;
+            f.b[i] = Bs[n * KC_LD + ks * 4 + kk];
+        }
+    };
+    auto mfma_slab = [&](const frag &f) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+    };
+    // One tile: the MFMAs of stage `cur`; under them, tile k+1 goes from registers to the other stage and tile k+2 is
+    // requested from memory, and every slab's fragments are read while the slab before it multiplies.  sched_barrier pins
+    // that order: the non-MFMA work sits between MFMA groups of the same wave (the matrix pipe takes 64 cycles per
+    // instruction and runs on while the wave issues other work) instead of in a block of its own between two barriers,
+    // where only the other workgroup's wave could cover it.
+    static_assert(BK == 16, "the tile schedule below is written for four k-slabs");
+    auto tile = [&](const int k0, const int cur) {
+        const double *Ac = gsm + cur * STAGE, *Bc = Ac + SA;
+        double *An = gsm + (cur ^ 1) * STAGE, *Bn = An + SA;
+        frag f0, f1;
+#if defined(GEMM_PRIO) && GEMM_PRIO == 1
+        __builtin_amdgcn_s_setprio(2);
+#endif
+        read_slab(Ac, Bc, 0, f0);
+        read_slab(Ac, Bc, 1, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_slab(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + BK < kend) store_tiles(An, Bn);
+        __builtin_amdgcn_sched_barrier(0);
+        read_slab(Ac, Bc, 2, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_slab(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 2 * BK < kend) load_tiles(k0 + 2 * BK);
+        __builtin_amdgcn_sched_barrier(0);
+        read_slab(Ac, Bc, 3, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_slab(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_slab(f1);
+#if defined(GEMM_PRIO) && GEMM_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        __syncthreads();                       // stage cur^1 written by all, stage cur read by all
+    };
+
+#if defined(GEMM_PRIO) && GEMM_PRIO == 2
+    if ((lin >> 3) & 1) __builtin_amdgcn_s_setprio(2);
+#elif defined(GEMM_PRIO) && GEMM_PRIO == 3
+    if ((lin >> 9) & 1) __builtin_amdgcn_s_setprio(2);
+#endif
+    // The same tile for a workgroup whose every tile is whole (all of them at the benchmark shapes): no branch inside, so
+    // the tile is ONE scheduling region and the order below is imposed instruction by instruction -- an LDS write, a global
+    // load or a fragment read after each MFMA.  One wave then keeps the matrix pipe busy through its own LDS/global traffic
+    // (each of those issues in a few cycles under a 64-cycle MFMA); clustered, they cost the pipe ~3000 idle cycles per
+    // 5120-cycle tile whenever the other workgroup's wave on the SIMD was not there to cover them.
+    auto tile_whole = [&](const int k0, const int cur) {
+        const double *Ac = gsm + cur * STAGE, *Bc = Ac + SA;
+        double *An = gsm + (cur ^ 1) * STAGE, *Bn = An + SA;
+        constexpr int NM = MI * 4;                                 // MFMAs of a k-slab
+        constexpr int NW = (EA + 1) / 2 + EPT / 2;                 // LDS writes of a tile, two elements each
+        constexpr int NL = EA + EPT;                               // global loads of a tile, one element each
+        constexpr int NR = MI + 4;                                 // fragment reads of a k-slab
+        static_assert(NW + NL <= 2 * NM && NR <= NM, "the schedule below places one memory operation after each MFMA");
+        const bool more = k0 + 2 * BK < kend;                      // tile k0 + 2 BK: past the end, the last tile is loaded again
+        const long back_a = more ? 0 : -(long)a_step, back_b = more ? 0 : -(long)BK;
+        auto wr = [&](const int n) {                               // n-th LDS write: tile k0 + BK from the staging registers
+            if (n < (EA + 1) / 2) {
+#pragma unroll
+                for (int e = 2 * n; e < 2 * n + 2 && e < EA; ++e) {
+                    if (A_MCONTIG) An[(a_k + 16 * (e / MS)) * A_LD + a_m + 16 * (e % MS)] = ra[e];
+                    else An[a_m * KC_LD + a_k + e] = ra[e];
+                }
+            } else {
+                const int e = 2 * (n - (EA + 1) / 2);
+                Bn[b_n * KC_LD + b_k + e] = rb[e];
+                Bn[b_n * KC_LD + b_k + e + 1] = rb[e + 1];
+            }
+        };
+        auto ld = [&](const int n) {                               // n-th global load: tile k0 + 2 BK into the staging registers
+            if (n < EA) ra[n] = A_MCONTIG ? pa[back_a + 16 * (n % MS) + (long)(16 * (n / MS)) * (long)g.lda] : pa[back_a + n];
+            else rb[n - EA] = pb[back_b + (n - EA)];
+        };
+        auto rd = [&](const int ks, const int n, frag &f) {        // n-th fragment read of k-slab ks
+            if (n < MI) {
+                const int m = wm * (TBM / 2) + n * 16 + r16;
+                f.a[n] = A_MCONTIG ? Ac[(ks * 4 + kk) * A_LD + m] : Ac[m * KC_LD + ks * 4 + kk];
+            } else {
+                const int nn = wn * 64 + (n - MI) * 16 + r16;
+                f.b[n - MI] = Bc[nn * KC_LD + ks * 4 + kk];
+            }
+        };
+        frag f0, f1;
+        read_slab(Ac, Bc, 0, f0);                                  // (the one exposed LDS latency of the tile)
+        read_slab(Ac, Bc, 1, f1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NM; ++n) {                             // slab 0: the writes, then loads
+            acc[n / 4][n % 4] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0.a[n / 4], f0.b[n % 4], acc[n / 4][n % 4], 0, 0, 0);
+            if (n < NW) wr(n);
+            else if (n - NW < NL) ld(n - NW);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int n = 0; n < NM; ++n) {                             // slab 1: the rest of the loads, then slab 2's fragments
+            constexpr int done = NM - NW;
+            acc[n / 4][n % 4] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1.a[n / 4], f1.b[n % 4], acc[n / 4][n % 4], 0, 0, 0);
+            if (done + n < NL) ld(done + n);
+            else if (done + n - NL < NR) rd(2, done + n - NL, f0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        pa = more ? pa + a_step : pa;
+        pb = more ? pb + BK : pb;
+#pragma unroll
+        for (int n = 0; n < NM; ++n) {                             // slab 2: slab 3's fragments
+            acc[n / 4][n % 4] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0.a[n / 4], f0.b[n % 4], acc[n / 4][n % 4], 0, 0, 0);
+            if (n < NR) rd(3, n, f1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma_slab(f1);
+        __syncthreads();                       // stage cur^1 written by all, stage cur read by all
+    };
 
     load_tiles(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();                       // previous tile fully consumed
-        store_tiles();
-        __syncthreads();
-        if (k0 + BK < kend) load_tiles(k0 + BK);   // prefetch under the MFMAs
-#pragma unroll
-        for (int ks = 0; ks < BK / 4; ++ks) {
-            double a[MI], b[4];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int m = wm * (TBM / 2) + i * 16 + r16;
-                a[i] = A_MCONTIG ? As[(ks * 4 + kk) * A_LD + m] : As[m * KC_LD + ks * 4 + kk];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = wn * 64 + i * 16 + r16;
-                b[i] = Bs[n * KC_LD + ks * 4 + kk];
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    store_tiles(gsm, gsm + SA);
+    __syncthreads();
+    if (kbeg + BK < kend) load_tiles(kbeg + BK);
+    if (WHOLE) {
+        for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
+            tile_whole(k0, 0);
+            if (k0 + BK < kend) tile_whole(k0 + BK, 1);
+        }
+    } else {
+        for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
+            tile(k0, 0);
+            if (k0 + BK < kend) tile(k0 + BK, 1);
         }
     }
 
     // ---- epilogue.  acc[i][j][r] is C[row, col], row = wm*(TBM/2) + i*16 + kk + 4r, col = wn*64 + j*16 + r16
     double t_sum = 0.0, t_sum2 = 0.0;
     double colp[4] = {0.0, 0.0, 0.0, 0.0};
+    // Σ s·log λ needs a logarithm only where the bin holds events -- one bin in twenty at the benchmark's rate, yet a wave
+    // pays for all 64 lanes whenever one of them does.  Each wave therefore queues its (λ, s) pairs in LDS (ballot +
+    // prefix count: the order depends on the data only) and takes the logarithm 64 at a time: ~5 evaluations per wave and
+    // tile instead of 80 (3 % of the kernel).  The queue lives in the stages, free after the last tile's barrier.
+    double *qlam = gsm + 512 + wave * 256, *qs = qlam + 128;       // [128] each, per wave
+    int qn = 0;                                                     // wave-uniform fill
+    auto log_queue_push = [&](const bool nz, const double lam, const double sv) {
+        const unsigned long long m = __ballot(nz);
+        if (m == 0ull) return;
+        const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (nz) { qlam[pos] = lam; qs[pos] = sv; }
+        qn += __popcll(m);
+        if (qn >= 64) {
+            NHP_LDS_SYNC();
+            t_sum += qs[lane] * nhp_log(qlam[lane]);
+            const bool mv = lane < qn - 64;
+            const double ml = mv ? qlam[64 + lane] : 0.0, ms = mv ? qs[64 + lane] : 0.0;
+            NHP_LDS_SYNC();
+            if (mv) { qlam[lane] = ml; qs[lane] = ms; }
+            qn -= 64;
+        }
+    };
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = n0 + wn * 64 + j * 16 + r16;
@@ -171,6 +329,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm * (TBM / 2) + i * 16 + kk + 4 * r;
+                double sv = 0.0, lamv = 1.0;                       // (EPI_LOGLIK / EPI_GRAD: this element's count and intensity)
                 if (row < g.M && col < g.N) {
                     const size_t o = (size_t)row + (size_t)col * g.M;
                     const double v = acc[i][j][r];
@@ -180,8 +339,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
                     } else if (EPI == EPI_LOGLIK) {
                         // log pdf(Poisson(λ), s) = xlogy(s, λ) - λ - loggamma(s+1); the data-only
                         // Σ loggamma(s+1) is hoisted to the host
-                        const double lam = base + v, s = g.dataT[o];
-                        t_sum += (s == 0.0 ? 0.0 : s * nhp_log(lam));
+                        const double lam = base + v;
+                        sv = g.dataT[o]; lamv = lam;
                         t_sum2 += lam;
                     } else if (EPI == EPI_VB_Z) {
                         const double rr = g.dataT[o] / (base + v);
@@ -191,15 +350,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
                         const double lam = base + v, s = g.dataT[o], rr = s / lam;
                         g.out[o] = rr;
                         colp[j] += rr;
-                        t_sum += (s == 0.0 ? 0.0 : s * nhp_log(lam));
+                        sv = s; lamv = lam;
                         t_sum2 += lam;
                     } else {
                         g.out[(size_t)blockIdx.z * (size_t)g.M * g.N + o] = v;
                     }
                 }
+                if (EPI == EPI_LOGLIK || EPI == EPI_GRAD) log_queue_push(sv != 0.0, lamv, sv);
             }
     }
     if (EPI == EPI_LOGLIK || EPI == EPI_GRAD) {
+        NHP_LDS_SYNC();
+        if (lane < qn) t_sum += qs[lane] * nhp_log(qlam[lane]);    // what is left in the wave's queue
+        __syncthreads();                                           // (the queues overlap nothing of red / wcol, but keep the phases apart)
         const double s1 = nhp_block_sum(t_sum, red);
         const double s2 = nhp_block_sum(t_sum2, red);
         if (tid == 0) {
@@ -696,19 +859,22 @@ static int gemm1_tile_m(int64_t M, int N, int cu_count)
 template <bool AMC, int EPI>
 static void launch_gemm(const gemm_args &g, int splits, hipStream_t st, int bm = BM)
 {
+    // whole tiles only (and every reduction chunk whole BK-tiles): the branch-free, instruction-scheduled main loop
+    const int tbm = AMC && bm == 160 ? 160 : BM;
+    const bool whole = g.M % tbm == 0 && g.N % BN == 0 && g.K % BK == 0 && g.k_chunk % BK == 0 && g.K > 0 && !getenv("NHP_GEMM_PLAIN");
+    auto go = [&](auto kernel, int rows) {
+        dim3 grid((unsigned)((g.N + BN - 1) / BN), (unsigned)((g.M + rows - 1) / rows), (unsigned)splits);
+        const size_t lds = 8 * 2 * ((AMC ? BK * (rows + 16) : BM * KC_LD) + BN * KC_LD);   // two stages (>= the epilogue's NHP_WAVES * 65 doubles)
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, g);
+    };
     if (AMC && bm == 160) {
-        dim3 grid((unsigned)((g.N + BN - 1) / BN), (unsigned)((g.M + 159) / 160), (unsigned)splits);
-        const size_t lds = 8 * (BK * (160 + 16) + BN * KC_LD + NHP_WAVES + NHP_WAVES * 64);
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void *)k_gemm_f64<AMC, EPI, (AMC ? 160 : BM)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_gemm_f64<AMC, EPI, (AMC ? 160 : BM)>), grid, dim3(256), lds, st, g);
+        if (whole) go(k_gemm_f64<AMC, EPI, (AMC ? 160 : BM), true>, 160);
+        else go(k_gemm_f64<AMC, EPI, (AMC ? 160 : BM), false>, 160);
         return;
     }
-    dim3 grid((unsigned)((g.N + BN - 1) / BN), (unsigned)((g.M + BM - 1) / BM), (unsigned)splits);
-    const size_t lds = 8 * ((AMC ? BK * A_MC_LD : BM * KC_LD) + BN * KC_LD + NHP_WAVES + NHP_WAVES * 64);
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)k_gemm_f64<AMC, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_gemm_f64<AMC, EPI>), grid, dim3(256), lds, st, g);
+    if (whole) go(k_gemm_f64<AMC, EPI, BM, true>, BM);
+    else go(k_gemm_f64<AMC, EPI, BM, false>, BM);
 }
 
 // uploads the model pieces, builds E and base on the device; returns pointers into scratch
