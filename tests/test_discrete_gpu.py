@@ -202,3 +202,42 @@ def test_both_gemm_tile_heights_agree(nhp, orc, N, T, B, L, monkeypatch):
     assert abs(a[0] - b[0]) < 1e-12 * abs(a[0]) and abs(a[1] - b[1]) < 1e-12 * abs(a[1])
     for x, y in zip(a[2:], b[2:]):
         assert np.allclose(x, y, rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("N,T,B,L,bm", [(128, 1280, 2, 4, "128"), (128, 1280, 2, 4, "160"), (256, 640, 4, 5, "160")])
+def test_whole_tile_gemm_variant_matches_the_oracle_and_the_general_one(nhp, orc, N, T, B, L, bm, monkeypatch):
+    """Shapes made of whole tiles (T a multiple of the tile height, N of 128, N·B and the VB reduction chunks of 16) take
+    the branch-free, instruction-scheduled main loop (k_gemm_f64<.., WHOLE = true>); NHP_GEMM_PLAIN forces the general
+    loop.  Both give the oracle's intensity, log-likelihood, gradient and VB step."""
+    proc, data, lam0, W, th, _ = make(nhp, N, T, B, L, seed=N + 3)
+    conv = orc.disc_convolve(data, proc.impulses.basis())
+    want = orc.disc_intensity(conv, lam0, W, th, 1.0)
+    wll = orc.disc_loglik(data, want)
+    monkeypatch.setenv("NHP_GEMM_BM", bm)
+    got = {}
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("NHP_GEMM_PLAIN", "1")
+        else:
+            monkeypatch.delenv("NHP_GEMM_PLAIN", raising=False)
+        ds = nhp.convolve(proc, data)
+        lam = nhp.intensity(proc, ds)
+        assert np.max(np.abs(lam - want) / want) < 1e-12
+        ll = nhp.loglikelihood(proc, data, convolved=ds)
+        assert abs(ll - wll) < 1e-11 * abs(wll)
+        ll2, g = nhp.loglikelihood_gradient(proc, data, convolved=ds)
+        import copy
+        p2 = copy.deepcopy(proc)
+        nhp.update_(p2, data, ds)
+        got[plain] = (ll, ll2, g, p2.weights.κv.copy(), p2.impulses.γv.copy(), p2.baseline.αv.copy())
+    a, b = got[False], got[True]
+    assert abs(a[0] - b[0]) < 1e-12 * abs(a[0]) and abs(a[1] - b[1]) < 1e-12 * abs(a[1])
+    for x, y in zip(a[2:], b[2:]):
+        assert np.allclose(x, y, rtol=1e-11, atol=1e-13)
+    p3 = copy.deepcopy(proc)
+    want_vb = orc.disc_vb_step(data, conv, 1.0, proc.baseline.α0, proc.baseline.β0, proc.weights.κ, proc.weights.ν,
+                               proc.impulses.γ, proc.baseline.αv, proc.baseline.βv, proc.weights.κv, proc.weights.νv,
+                               proc.impulses.γv)
+    monkeypatch.delenv("NHP_GEMM_PLAIN", raising=False)
+    nhp.update_(p3, data, nhp.convolve(p3, data))
+    assert np.allclose(p3.impulses.γv, want_vb[4], rtol=1e-10, atol=1e-12)
