@@ -1,6 +1,8 @@
 // Discrete-time Gibbs sampling on the GPU: parent counts of a sweep and the adjacency-matrix
 // sweep of the network process.  The shared pieces -- dataset, bump table staging, the intensity GEMM -- live
 // in disc.hip (declared in nhp_internal.h).
+#include <math.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -22,7 +24,6 @@
 #define RP_TT 64
 #define RP_CT 128
 #define RP_KC 16
-#define RP_SLOTS 4
 #define RP_KEY 0xD15C0DE5EEDC0FFEull
 
 __device__ __attribute__((noinline)) double rp_next_u(double u_prev, int remaining, uint64_t seed, uint64_t step, uint64_t bin, int j)
@@ -34,6 +35,10 @@ __device__ __attribute__((noinline)) double rp_next_u(double u_prev, int remaini
     return u_prev + (1.0 - u_prev) * w;
 }
 
+// RP_SLOTS = occupied bins a thread carries through one pair of walks: the host picks the smallest of 1, 2, 4 whose
+// 256·RP_SLOTS slots hold a tile's occupied bins (an empty slot costs the walk as much as a full one: at config 4 a
+// 64 x 128 tile holds ~400, and two slots per thread take 14.7 ms where four took 20.9).
+template <int RP_SLOTS>
 __global__ __launch_bounds__(256, 3) void k_disc_resample_parents(const double *__restrict__ dataT, const double *__restrict__ conv,
                                                                const double *__restrict__ E2, const double *__restrict__ base,
                                                                const double *__restrict__ baseT, int64_t T, int N, int B,
@@ -160,6 +165,7 @@ __global__ __launch_bounds__(256, 3) void k_disc_resample_parents(const double *
                     if (++j[s] < n[s]) { u[s] = rp_next_u(u[s], n[s] - j[s], seed, step, bin, j[s]); thr[s] = u[s] * total[s]; }
                 }
             }
+            if (j[s] >= n[s]) thr[s] = __builtin_inf();                      // nothing (left) to place: walk 2 never stops here
         }
         // ---- walk 2: categories by inverse CDF
         fetch(0);
@@ -172,13 +178,16 @@ __global__ __launch_bounds__(256, 3) void k_disc_resample_parents(const double *
 #pragma unroll
                 for (int s = 0; s < RP_SLOTS; ++s) {
                     cum[s] = cum[s] + Gt[kk][tl[s]] * Et[kk][cl[s]];
-                    if (j[s] < n[s] && cum[s] > thr[s] && q0 + kk < K) {
+                    // ONE test per multiply-add: a bin with nothing left to place carries thr = +inf, and categories
+                    // past K are staged as zeros (the sum cannot pass a threshold there that it had not passed before)
+                    if (cum[s] > thr[s]) {
                         const int c = c0 + cl[s];
                         const uint64_t bin = (uint64_t)(t0 + tl[s]) + (uint64_t)T * (uint64_t)c;
                         do {
                             atomicAdd(&counts[(size_t)c + (size_t)N * (1 + q0 + kk)], 1);
                             if (++j[s] < n[s]) { u[s] = rp_next_u(u[s], n[s] - j[s], seed, step, bin, j[s]); thr[s] = u[s] * total[s]; }
-                        } while (j[s] < n[s] && cum[s] > thr[s]);
+                            else thr[s] = __builtin_inf();
+                        } while (cum[s] > thr[s]);
                     }
                 }
             }
@@ -207,8 +216,15 @@ static nhp_status disc_parent_counts(nhp_ctx *ctx, const nhp_disc_dataset *ds, c
     // q / B for q < 2^24 as a multiply-high: exact with magic = floor(2^32 / B) + 1 while q·B < 2^32
     const unsigned b_magic = (unsigned)((((uint64_t)1 << 32) / (uint64_t)ds->B + 1) & 0xFFFFFFFFu);   // unused for B = 1
     if (ds->d_base_counts) NHP_HIP(ctx, hipMemsetAsync(ds->d_base_counts, 0, sizeof(int) * (size_t)ds->T * N, st));
-    hipLaunchKernelGGL(k_disc_resample_parents, grid, dim3(256), 0, st, ds->d_dataT, ds->d_conv, E2, base,
-                       lambda0 ? nullptr : ds->d_baseT, ds->T, ds->N, ds->B, b_magic, seed, step, d_counts, ds->d_base_counts);
+    // occupied bins of a 64 x 128 tile: the mean plus three standard deviations (a tile that overflows its slots walks twice)
+    const double mean = (double)ds->nocc * (double)(RP_TT * RP_CT) / ((double)ds->T * (double)std::max<size_t>(N, RP_CT));
+    const double need = mean + 3.0 * sqrt(mean);
+    const char *fs = getenv("NHP_RP_SLOTS");
+    const int slots = fs ? atoi(fs) : (need <= 256.0 ? 1 : need <= 512.0 ? 2 : 4);
+#define RP_LAUNCH(S) hipLaunchKernelGGL(k_disc_resample_parents<S>, grid, dim3(256), 0, st, ds->d_dataT, ds->d_conv, E2, base, \
+                       lambda0 ? nullptr : ds->d_baseT, ds->T, ds->N, ds->B, b_magic, seed, step, d_counts, ds->d_base_counts)
+    if (slots == 1) RP_LAUNCH(1); else if (slots == 2) RP_LAUNCH(2); else RP_LAUNCH(4);
+#undef RP_LAUNCH
     if (ds->d_base_counts) const_cast<nhp_disc_dataset *>(ds)->base_counts_valid = true;
     NHP_HIP(ctx, hipGetLastError());
     *d_counts_out = d_counts;
