@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 
 #include <atomic>
 #include "nhp_internal.h"
@@ -208,11 +209,29 @@ extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double
     }
     std::vector<nhp_event> ev((size_t)M);
     for (int64_t i = 0; i < M; ++i) { ev[i].t = events[i]; ev[i].node = node32[i]; ev[i].pad = 0; }
+    // 8-byte records (nhp_internal.h): only where a node fits 16 bits and the span is a finite positive number
+    std::vector<uint64_t> ev8;
+    if (N <= 65535 && M > 0 && std::isfinite(events[0]) && std::isfinite(events[M - 1]) && events[M - 1] > events[0]) {
+        const double t0 = events[0], range = events[M - 1] - t0;
+        const int s2 = 47 - std::ilogb(range);                      // range * 2^s2 < 2^48
+        if (s2 > -900 && s2 < 900) {
+            const double scale = std::ldexp(1.0, s2);
+            ev8.resize((size_t)M);
+            for (int64_t i = 0; i < M; ++i) {
+                double q = std::nearbyint((events[i] - t0) * scale);
+                if (q < 0.0) q = 0.0;
+                if (q > 281474976710655.0) q = 281474976710655.0;
+                ev8[(size_t)i] = ((uint64_t)(uint32_t)node32[i] << 48) | (uint64_t)q;
+            }
+            ds->ev8_t0 = t0; ds->ev8_scale = scale;
+        }
+    }
 
     nhp_status s;
     if ((s = upload(ctx, &ds->d_times, events, (size_t)M)) != NHP_OK ||
         (s = upload(ctx, &ds->d_nodes, node32.data(), (size_t)M)) != NHP_OK ||
         (s = upload(ctx, &ds->d_ev, ev.data(), (size_t)M)) != NHP_OK ||
+        (!ev8.empty() && (s = upload(ctx, &ds->d_ev8, ev8.data(), (size_t)M)) != NHP_OK) ||
         (s = upload(ctx, &ds->d_child, child.data(), (size_t)M)) != NHP_OK ||
         (s = upload(ctx, &ds->d_child_w, child_w.data(), (size_t)M)) != NHP_OK ||
         (s = upload(ctx, &ds->d_wpos, wpos.data(), (size_t)M)) != NHP_OK ||
@@ -238,7 +257,7 @@ extern "C" void nhp_cont_dataset_destroy(nhp_cont_dataset *ds)
     if (!ds) return;
     (void)hipSetDevice(ds->ctx->device);
     (void)hipStreamSynchronize(ds->ctx->stream);
-    (void)hipFree(ds->d_times); (void)hipFree(ds->d_nodes); (void)hipFree(ds->d_child); (void)hipFree(ds->d_child_w); (void)hipFree(ds->d_wpos); (void)hipFree(ds->d_ev);
+    (void)hipFree(ds->d_times); (void)hipFree(ds->d_nodes); (void)hipFree(ds->d_child); (void)hipFree(ds->d_child_w); (void)hipFree(ds->d_wpos); (void)hipFree(ds->d_ev); (void)hipFree(ds->d_ev8);
     (void)hipFree(ds->d_boff); (void)hipFree(ds->d_items); (void)hipFree(ds->d_cnt); (void)hipFree(ds->d_pn);
     (void)hipFree(ds->d_adj_k); (void)hipFree(ds->d_adj_p); (void)hipFree(ds->d_adj_dt); (void)hipFree(ds->d_adj_start); (void)hipFree(ds->d_adj_off); (void)hipFree(ds->d_adj_group); (void)hipFree(ds->d_child_cut);
     delete ds;
@@ -371,6 +390,8 @@ extern "C" void nhp_cont_model_destroy(nhp_cont_model *m)
 nhp_cont_args nhp_make_args(const nhp_cont_dataset *ds, const nhp_cont_model *m)
 {
     nhp_cont_args a;
+    static const bool ev8_off = getenv("NHP_EV8") && atoi(getenv("NHP_EV8")) == 0;       // (A/B switch: exact 16-byte records everywhere)
+    a.ev8 = ev8_off ? nullptr : ds->d_ev8; a.ev8_t0 = ds->ev8_t0; a.ev8_scale = ds->ev8_scale; a.ev8_inv = ds->ev8_scale > 0.0 ? 1.0 / ds->ev8_scale : 0.0;
     a.times = ds->d_times; a.nodes = ds->d_nodes; a.ev = ds->d_ev; a.child = ds->d_child; a.child_w = ds->d_child_w; a.boff = ds->d_boff;
     a.items = ds->d_items; a.cnt = ds->d_cnt;
     a.lambda0 = m->d_lambda0; a.grid = m->d_grid; a.p1 = m->d_p1; a.p2 = m->d_p2; a.W = m->d_W;

@@ -99,7 +99,13 @@ extern "C" int nhp_debug_stamps(unsigned long long *out, int n)
 // (clamped address, masked accumulate) rather than branched, which is what lets the loads batch.
 #define NHP_SHARDS 64
 
-template <int IMP, int G, int U>
+// PACK: the parents come as 8-byte records (node << 48 | fixed-point time, nhp_cont_dataset::d_ev8) instead of 16-byte
+// {t, node} -- half the bytes of the scattered window fetches that bound the short-window kernel.  The time field is decoded
+// with the 2^52 trick (the 48 bits OR-ed under the exponent of 2^52 ARE the double 2^52 + q; one exact subtraction), Δt =
+// ((t_child - t0)·2^s - q)·2^-s: the only error is the parent's rounding to 2^-s, below 2^-49 of the data's span (log-
+// likelihood of the metric data: 4·10^-14 relative; the window bounds come from the exact times either way).  Exponential
+// impulses without the λ output only: a logit-normal Δt/Δtmax must stay strictly inside (0, 1).
+template <int IMP, int G, int U, bool PACK = false>
 __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int mask_integral,
                                                         double *__restrict__ partials,
                                                         double *__restrict__ lambda_out,
@@ -144,6 +150,21 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
     constexpr int GROUPS = NHP_WBLOCK / G;
     const int gid = tid / G, gl = tid % G;
     const int nchild = it.kend - it.kbeg;
+    static_assert(!PACK || IMP == NHP_IMPULSE_EXPONENTIAL, "packed records: exponential impulses only");
+    struct rec { nhp_event e; unsigned long long w; };             // (one of the two is used; the other is never loaded)
+    auto fetch = [&](const int jj) {
+        rec r;
+        if (PACK) r.w = a.ev8[jj > 0 ? jj : 0];
+        else r.e = a.ev[jj > 0 ? jj : 0];
+        return r;
+    };
+    auto node_of = [&](const rec &r) { return PACK ? (int)(r.w >> 48) : r.e.node; };
+    // Δt of a parent: tc = the child's time, exact, or (t_child - t0)·2^s for packed records
+    auto delay = [&](const double tc, const rec &r) {
+        if (!PACK) return tc - r.e.t;
+        const double d = __hiloint2double((int)(((unsigned)(r.w >> 32) & 0xFFFFu) | 0x43300000u), (int)(unsigned)r.w);
+        return (tc - (d - 4503599627370496.0)) * a.ev8_inv;
+    };
     // slot of (wave, u, group-in-wave) inside a round: a wave's U*GW children are contiguous in the
     // round's window-sorted order
     constexpr int GW = 64 / G;
@@ -153,7 +174,7 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
     double prod = 1.0;
     int pexp = 0;
     for (int r0 = 0; r0 < (NHP_SKIP(a, 1) ? 0 : nchild); r0 += GROUPS * U) {
-        double t[U], s[U];
+        double t[U], tc[U], s[U];
         int j[U], f[U], idx[U];
         bool valid[U];
 #pragma unroll
@@ -162,6 +183,7 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
             valid[u] = kk < nchild;
             const nhp_child ch = a.child_w[it.kbeg + (valid[u] ? kk : r0)];
             t[u] = ch.t; idx[u] = ch.idx;
+            tc[u] = PACK ? (ch.t - a.ev8_t0) * a.ev8_scale : ch.t;
             j[u] = ch.idx - 1 - gl;
             f[u] = valid[u] ? ch.first : 0x7fffffff;
             s[u] = 0.0;
@@ -170,9 +192,9 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
 #pragma unroll
         for (int u = 0; u < U; ++u) more |= j[u] >= f[u];
         if (NHP_SKIP(a, 8)) more = false;
-        nhp_event e[U];
+        rec e[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) e[u] = a.ev[j[u] > 0 ? j[u] : 0];
+        for (int u = 0; u < U; ++u) e[u] = fetch(j[u]);
         // steady state (wide groups = long windows only; measured slower for G <= 16): iterations in
         // which every one of this lane's U slots still has a parent, so nothing is predicated ...
         int nfull = G >= 32 ? 0x7fffffff : 0;
@@ -185,16 +207,16 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
         }
         if (NHP_SKIP(a, 8)) nfull = 0;
         for (int itn = 0; itn < nfull; ++itn) {
-            nhp_event en[U];
+            rec en[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) en[u] = a.ev[j[u] - G > 0 ? j[u] - G : 0];
+            for (int u = 0; u < U; ++u) en[u] = fetch(j[u] - G);
             asm volatile("" ::: "memory");          // keeps the prefetch a prefetch (see k_windowed_batch)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const double dt = t[u] - e[u].t;
-                const double2 q = col[e[u].node];
+                const double dt = delay(tc[u], e[u]);
+                const double2 q = col[node_of(e[u])];
                 if (IMP == NHP_IMPULSE_EXPONENTIAL) s[u] += q.y * nhp_pdf_exponential_tab(q.x, dt, etab);
-                else s[u] += colw[e[u].node] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
+                else s[u] += colw[node_of(e[u])] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
                 j[u] -= G;
                 e[u] = en[u];
             }
@@ -205,9 +227,9 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
         for (int u = 0; u < U; ++u) more |= j[u] >= f[u];
         if (NHP_SKIP(a, 8)) more = false;
         while (more) {
-            nhp_event en[U];                       // next iteration's parents, in flight under the math
+            rec en[U];                             // next iteration's parents, in flight under the math
 #pragma unroll
-            for (int u = 0; u < U; ++u) en[u] = a.ev[j[u] - G > 0 ? j[u] - G : 0];
+            for (int u = 0; u < U; ++u) en[u] = fetch(j[u] - G);
             // Wide groups (long windows): keep the prefetch a prefetch (see k_windowed_batch).  Narrow groups run one or two
             // trips per child: there the compiler's folding of the prefetch into the consuming trip SAVES the load a last
             // trip would waste (K = 8: 41.5 us folded, 52.7 us with the barrier).
@@ -215,11 +237,11 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
             more = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const double dt = t[u] - e[u].t;
-                const double2 q = col[e[u].node];
+                const double dt = delay(tc[u], e[u]);
+                const double2 q = col[node_of(e[u])];
                 double term;
                 if (IMP == NHP_IMPULSE_EXPONENTIAL) term = q.y * nhp_pdf_exponential_tab(q.x, dt, etab);
-                else term = colw[e[u].node] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
+                else term = colw[node_of(e[u])] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
                 s[u] += (j[u] >= f[u]) ? term : 0.0;
                 j[u] -= G;
                 more |= j[u] >= f[u];
@@ -817,6 +839,18 @@ static void launch_group(int G, dim3 grid, size_t lds, hipStream_t st, const nhp
         hipLaunchKernelGGL((k_windowed<IMP, g, u>), grid, dim3(NHP_WBLOCK), lds, st, a, mask, partials,       \
                            lambda_out, counter, out);                                                         \
         break;
+    // short windows, exponential impulses, no λ output: the 8-byte parent records (the fetches bound these launches)
+    if (IMP == NHP_IMPULSE_EXPONENTIAL && a.ev8 && !lambda_out && G <= 8) {
+        constexpr int EI = NHP_IMPULSE_EXPONENTIAL;
+#define NHP_PCASE(g)                                                                                          \
+    case g:                                                                                                   \
+        if (lds > 64 * 1024)                                                                                  \
+            (void)hipFuncSetAttribute((const void *)k_windowed<EI, g, NHP_U_SMALL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_windowed<EI, g, NHP_U_SMALL, true>), grid, dim3(NHP_WBLOCK), lds, st, a, mask, partials, lambda_out, counter, out); \
+        return;
+        switch (G) { NHP_PCASE(1) NHP_PCASE(2) NHP_PCASE(4) NHP_PCASE(8) default: break; }
+#undef NHP_PCASE
+    }
     switch (G) {
         NHP_CASE(1, NHP_U_SMALL) NHP_CASE(2, NHP_U_SMALL) NHP_CASE(4, NHP_U_SMALL) NHP_CASE(8, NHP_U_SMALL) NHP_CASE(16, NHP_U_MID) NHP_CASE(32, NHP_U_MID)
     default:

@@ -83,6 +83,11 @@ struct nhp_cont_dataset {
     int32_t max_item = 0;               // most children in one item (sizes the deferred-log LDS buffer)
     int32_t max_window = 0;             // longest look-back window, in parents
     nhp_event *d_ev = nullptr;          // [M] time order, packed (t, node)
+    // the same records in 8 bytes: node << 48 | round((t - ev8_t0) * ev8_scale), ev8_scale = 2^s with the largest s that keeps
+    // the time field below 2^48 (a resolution of 2^-49 of the data's span).  Read by the short-window log-likelihood kernel,
+    // whose time goes into fetching ~8 scattered parent records per event: half the bytes per record.
+    uint64_t *d_ev8 = nullptr;
+    double ev8_t0 = 0.0, ev8_scale = 0.0;
     // device arrays
     double *d_times = nullptr;          // [M] time order
     int32_t *d_nodes = nullptr;         // [M] 0-based
@@ -165,6 +170,8 @@ struct nhp_cont_args {
     const double *times;
     const int32_t *nodes;
     const nhp_event *ev;
+    const uint64_t *ev8;             // packed records (or null): see nhp_cont_dataset::d_ev8
+    double ev8_t0, ev8_scale, ev8_inv;
     const nhp_child *child;
     const nhp_child *child_w;
     const int32_t *wpos;             // child_w position -> bucket position
