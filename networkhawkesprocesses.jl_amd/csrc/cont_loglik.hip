@@ -848,7 +848,10 @@ static void launch_group(int G, dim3 grid, size_t lds, hipStream_t st, const nhp
             (void)hipFuncSetAttribute((const void *)k_windowed<EI, g, NHP_U_SMALL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_windowed<EI, g, NHP_U_SMALL, true>), grid, dim3(NHP_WBLOCK), lds, st, a, mask, partials, lambda_out, counter, out); \
         return;
-        switch (G) { NHP_PCASE(1) NHP_PCASE(2) NHP_PCASE(4) NHP_PCASE(8) default: break; }
+        // half the bytes per record move the best width down: 4 lanes per child where the 16-byte records want 8
+        // (N = 1024, M = 1e6, K = 8: G = 8 37.0 us, G = 4 32.4, G = 2 42.7; tools/kbench.py under NHP_GROUP)
+        const int Gp = G == 8 && !getenv("NHP_GROUP") ? 4 : G;
+        switch (Gp) { NHP_PCASE(1) NHP_PCASE(2) NHP_PCASE(4) NHP_PCASE(8) default: break; }
 #undef NHP_PCASE
     }
     switch (G) {
