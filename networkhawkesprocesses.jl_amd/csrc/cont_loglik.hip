@@ -839,8 +839,9 @@ static void launch_group(int G, dim3 grid, size_t lds, hipStream_t st, const nhp
         hipLaunchKernelGGL((k_windowed<IMP, g, u>), grid, dim3(NHP_WBLOCK), lds, st, a, mask, partials,       \
                            lambda_out, counter, out);                                                         \
         break;
-    // short windows, exponential impulses, no λ output: the 8-byte parent records (the fetches bound these launches)
-    if (IMP == NHP_IMPULSE_EXPONENTIAL && a.ev8 && !lambda_out && G <= 8) {
+    // short and middle windows, exponential impulses, no λ output: the 8-byte parent records (the fetches bound these launches;
+    // K = 64: 133.9 -> 124.1 us)
+    if (IMP == NHP_IMPULSE_EXPONENTIAL && a.ev8 && !lambda_out && G <= (getenv("NHP_PACK_G") ? atoi(getenv("NHP_PACK_G")) : 16)) {   // (wider groups are VALU-bound: the decode costs more than the bytes save: K = 512 570 -> 611 us)
         constexpr int EI = NHP_IMPULSE_EXPONENTIAL;
 #define NHP_PCASE(g)                                                                                          \
     case g:                                                                                                   \
@@ -851,7 +852,7 @@ static void launch_group(int G, dim3 grid, size_t lds, hipStream_t st, const nhp
         // half the bytes per record move the best width down: 4 lanes per child where the 16-byte records want 8
         // (N = 1024, M = 1e6, K = 8: G = 8 37.0 us, G = 4 32.4, G = 2 42.7; tools/kbench.py under NHP_GROUP)
         const int Gp = G == 8 && !getenv("NHP_GROUP") ? 4 : G;
-        switch (Gp) { NHP_PCASE(1) NHP_PCASE(2) NHP_PCASE(4) NHP_PCASE(8) default: break; }
+        switch (Gp) { NHP_PCASE(1) NHP_PCASE(2) NHP_PCASE(4) NHP_PCASE(8) NHP_PCASE(16) NHP_PCASE(32) default: break; }
 #undef NHP_PCASE
     }
     switch (G) {
