@@ -526,7 +526,9 @@ static nhp_status enqueue_multi(nhp_ctx *ctx, const nhp_cont_dataset *ds, const 
 // model's {θ, a·w} from LDS, and keep their own sum, their own log.  What is left per evaluation is its S-independent
 // share of the gathers plus its own exponentials -- the fp64 VALU, not the fabric, becomes the bound.
 // LDS image: model m's column at m·(N+1) double2s: the +1 skews the S models of one child onto different banks.
-template <int IMP, int S, int THREADS>
+// PACK: the loaders fetch the 8-byte parent records (k_windowed) and expand them to {t, node} when they park them in the
+// window buffer -- once per record, not once per term -- so only the global fetch changes.
+template <int IMP, int S, int THREADS, bool PACK = false>
 __global__ __launch_bounds__(THREADS) void k_windowed_batch(nhp_cont_args a, nhp_multi mm, double *__restrict__ partials,
                                                            unsigned int *__restrict__ counter)
 {
@@ -629,10 +631,26 @@ __global__ __launch_bounds__(THREADS) void k_windowed_batch(nhp_cont_args a, nhp
     // consecutive records -- one contiguous run, one request -- and park them in the child's row of the window buffer,
     // where all S model-lanes then read them back (same address: a broadcast, no bank conflict).  Parents past the window
     // are stored as {t, node N}: Δt = 0 on the zero-weight entry.
+    struct raw { nhp_event e; unsigned long long w; };              // (one of the two is loaded)
     auto fetch = [&](const nhp_child &ch, int c0) {
-        const int r = c0 + m, jj = ch.idx - 1 - r;
-        nhp_event e = a.ev[jj > 0 ? jj : 0];
-        if (r >= ch.idx - ch.first) { e.t = ch.t; e.node = N; }
+        const int jj = ch.idx - 1 - (c0 + m);
+        raw x;
+        if (PACK) x.w = a.ev8[jj > 0 ? jj : 0];
+        else x.e = a.ev[jj > 0 ? jj : 0];
+        return x;
+    };
+    // the record as it is parked (expanded where the load is CONSUMED: next to the load it would wait for it)
+    auto settle = [&](const raw &x, const nhp_child &ch, int c0) {
+        nhp_event e;
+        if (PACK) {
+            const double d = __hiloint2double((int)(((unsigned)(x.w >> 32) & 0xFFFFu) | 0x43300000u), (int)(unsigned)x.w);
+            e.t = __builtin_fma(d - 4503599627370496.0, a.ev8_inv, a.ev8_t0);
+            e.node = (int)(x.w >> 48);
+            e.pad = 0;
+        } else {
+            e = x.e;
+        }
+        if (c0 + m >= ch.idx - ch.first) { e.t = ch.t; e.node = N; }
         return e;
     };
     // Two dependent global round trips lead into a round (child record, then its parents) and a round is only a few
@@ -642,7 +660,7 @@ __global__ __launch_bounds__(THREADS) void k_windowed_batch(nhp_cont_args a, nhp
     constexpr int RB = 4;
     for (int rb = 0; rb < nrounds; rb += RB) {
         nhp_child chs[RB];
-        nhp_event m0s[RB], m1s[RB];
+        raw m0s[RB], m1s[RB];
         int kmaxs[RB];
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) chs[rr] = load_child(group_of(rb + rr));
@@ -663,10 +681,10 @@ __global__ __launch_bounds__(THREADS) void k_windowed_batch(nhp_cont_args a, nhp
             const bool valid = g * CW + kc < nchild;
             const int kmax = kmaxs[rr];                             // longest window of the wave's CW children
             double s = 0.0;
-            nhp_event mine = m0s[rr];
+            raw mine = m0s[rr];
             for (int c0 = 0; c0 < kmax; c0 += S) {
                 NHP_LDS_SYNC();                                      // the previous chunk's reads precede this overwrite
-                myrow[m] = mine;
+                myrow[m] = settle(mine, ch0, c0);
                 if (c0 == 0) mine = m1s[rr];                         // (already requested above)
                 else if (c0 + S < kmax) mine = fetch(ch0, c0 + S);   // third and later chunks: in flight under this chunk's math
                 NHP_LDS_SYNC();
@@ -798,7 +816,10 @@ static nhp_status enqueue_batch(nhp_ctx *ctx, const nhp_cont_dataset *ds, const 
         mm.out[k] = ctx->d_results + slot0 + (k < S ? k : 0);
     }
     dim3 grid((unsigned)ds->n_items);
-    if (expo) {
+    if (expo && a.ev8) {
+        if (lds > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_windowed_batch<NHP_IMPULSE_EXPONENTIAL, S, THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_windowed_batch<NHP_IMPULSE_EXPONENTIAL, S, THREADS, true>), grid, dim3(THREADS), lds, ctx->stream, a, mm, ctx->d_partials, ctx->d_counter);
+    } else if (expo) {
         if (lds > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_windowed_batch<NHP_IMPULSE_EXPONENTIAL, S, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((k_windowed_batch<NHP_IMPULSE_EXPONENTIAL, S, THREADS>), grid, dim3(THREADS), lds, ctx->stream, a, mm, ctx->d_partials, ctx->d_counter);
     } else {
