@@ -12,7 +12,7 @@ from .components import (BernoulliNetworkModel, DenseNetworkModel, DenseWeightMo
                          PeriodicKernel, SquaredExponentialKernel, split_extract)
 from .continuous import (ContinuousHawkesProcess, ContinuousNetworkHawkesProcess,  # noqa: F401
                          ContinuousStandardHawkesProcess, DeviceDataset, HawkesProcess, device_dataset,
-                         total_intensity)
+                         invalidate_device_datasets, total_intensity)
 from . import continuous as _cont
 from .discrete import (DiscreteDataset, DiscreteGaussianImpulseResponse, DiscreteHawkesProcess,  # noqa: F401
                        DiscreteHomogeneousProcess, DiscreteLogGaussianCoxProcess, DiscreteNetworkHawkesProcess,

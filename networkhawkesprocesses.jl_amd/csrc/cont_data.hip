@@ -207,6 +207,14 @@ extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double
         }
         for (int64_t k = 0; k < M; ++k) child_w[(size_t)k] = child[(size_t)wpos[(size_t)k]];
     }
+    // pair offsets in child_w order (see nhp_cont_dataset::d_poff)
+    std::vector<uint32_t> poff;
+    if (pairs > 0 && pairs <= 16 * M && pairs < ((int64_t)1 << 31) && std::isfinite(dt_max) && dt_max > 0.0 && N <= 65535) {
+        poff.resize((size_t)M + 1);
+        uint32_t run = 0;
+        for (int64_t k = 0; k < M; ++k) { poff[(size_t)k] = run; run += (uint32_t)(child_w[(size_t)k].idx - child_w[(size_t)k].first); }
+        poff[(size_t)M] = run;
+    }
     std::vector<nhp_event> ev((size_t)M);
     for (int64_t i = 0; i < M; ++i) { ev[i].t = events[i]; ev[i].node = node32[i]; ev[i].pad = 0; }
     // 8-byte records (nhp_internal.h): only where a node fits 16 bits and the span is a finite positive number
@@ -232,6 +240,7 @@ extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double
         (s = upload(ctx, &ds->d_nodes, node32.data(), (size_t)M)) != NHP_OK ||
         (s = upload(ctx, &ds->d_ev, ev.data(), (size_t)M)) != NHP_OK ||
         (!ev8.empty() && (s = upload(ctx, &ds->d_ev8, ev8.data(), (size_t)M)) != NHP_OK) ||
+        (!poff.empty() && (s = upload(ctx, &ds->d_poff, poff.data(), (size_t)M + 1)) != NHP_OK) ||
         (s = upload(ctx, &ds->d_child, child.data(), (size_t)M)) != NHP_OK ||
         (s = upload(ctx, &ds->d_child_w, child_w.data(), (size_t)M)) != NHP_OK ||
         (s = upload(ctx, &ds->d_wpos, wpos.data(), (size_t)M)) != NHP_OK ||
@@ -257,7 +266,7 @@ extern "C" void nhp_cont_dataset_destroy(nhp_cont_dataset *ds)
     if (!ds) return;
     (void)hipSetDevice(ds->ctx->device);
     (void)hipStreamSynchronize(ds->ctx->stream);
-    (void)hipFree(ds->d_times); (void)hipFree(ds->d_nodes); (void)hipFree(ds->d_child); (void)hipFree(ds->d_child_w); (void)hipFree(ds->d_wpos); (void)hipFree(ds->d_ev); (void)hipFree(ds->d_ev8);
+    (void)hipFree(ds->d_times); (void)hipFree(ds->d_nodes); (void)hipFree(ds->d_child); (void)hipFree(ds->d_child_w); (void)hipFree(ds->d_wpos); (void)hipFree(ds->d_ev); (void)hipFree(ds->d_ev8); (void)hipFree(ds->d_poff); (void)hipFree(ds->d_plist);
     (void)hipFree(ds->d_boff); (void)hipFree(ds->d_items); (void)hipFree(ds->d_cnt); (void)hipFree(ds->d_pn);
     (void)hipFree(ds->d_adj_k); (void)hipFree(ds->d_adj_p); (void)hipFree(ds->d_adj_dt); (void)hipFree(ds->d_adj_start); (void)hipFree(ds->d_adj_off); (void)hipFree(ds->d_adj_group); (void)hipFree(ds->d_child_cut);
     delete ds;
@@ -390,8 +399,9 @@ extern "C" void nhp_cont_model_destroy(nhp_cont_model *m)
 nhp_cont_args nhp_make_args(const nhp_cont_dataset *ds, const nhp_cont_model *m)
 {
     nhp_cont_args a;
-    static const bool ev8_off = getenv("NHP_EV8") && atoi(getenv("NHP_EV8")) == 0;       // (A/B switch: exact 16-byte records everywhere)
+    const bool ev8_off = getenv("NHP_EV8") && atoi(getenv("NHP_EV8")) == 0;             // (A/B switch, read per call: exact 16-byte records everywhere)
     a.ev8 = ev8_off ? nullptr : ds->d_ev8; a.ev8_t0 = ds->ev8_t0; a.ev8_scale = ds->ev8_scale; a.ev8_inv = ds->ev8_scale > 0.0 ? 1.0 / ds->ev8_scale : 0.0;
+    a.poff = ds->d_poff; a.plist = ds->d_plist;
     a.times = ds->d_times; a.nodes = ds->d_nodes; a.ev = ds->d_ev; a.child = ds->d_child; a.child_w = ds->d_child_w; a.boff = ds->d_boff;
     a.items = ds->d_items; a.cnt = ds->d_cnt;
     a.lambda0 = m->d_lambda0; a.grid = m->d_grid; a.p1 = m->d_p1; a.p2 = m->d_p2; a.W = m->d_W;

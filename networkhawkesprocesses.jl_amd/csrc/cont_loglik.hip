@@ -18,6 +18,8 @@
 //  * Sums are reduced lane -> wave -> block -> one partial per workgroup; a one-block second
 //    kernel adds the partials in a fixed order (deterministic, no atomics).
 #include <utility>
+#include <stdio.h>
+
 #include "nhp_internal.h"
 #include "nhp_math.h"
 
@@ -307,6 +309,183 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
     if (tid == 0) {
         *out = (0.0 - si) + sl;                  // si: baseline integrals + Σ cnt·w, column by column
     }
+    if (tid <= NHP_SHARDS) __hip_atomic_store(&counter[32 * tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- short windows through the cached pair list --------------------------------------------------------------
+//   At K̄ ≈ 8 a launch of k_windowed spends its time waiting: per round of children three DEPENDENT global
+// round trips (child records -> first parents -> second parents) to ~10⁶ scattered 64-byte windows.  Which pairs exist
+// and their delays are data, not parameters: the dataset keeps them as a list, child by child in the order the items
+// visit them, 8 bytes a pair -- parent node << 48 | Δt as a 48-bit fraction of Δtmax (resolution 2⁻⁴⁹·Δtmax: finer than
+// the fp64 subtraction t_child - t_parent itself resolves at t ~ 10⁵) -- built once on the device (k_pairs_build) at the
+// first evaluation.  A workgroup then stages its item's pair OFFSETS with the column (4 bytes a child) and every round is
+// ONE round trip to a contiguous run of the list: 8·P + 4·M bytes per evaluation, streamed, against 133 MB of scattered
+// sectors.  Same sum in the same order as k_windowed (lane g of a child's group takes its pairs g, g+G, ..., most recent
+// parent first; the same group reduction), exponential impulses, no λ output.
+__global__ __launch_bounds__(256) void k_pairs_build(nhp_cont_args a, uint64_t *__restrict__ plist)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= a.M) return;
+    const nhp_child ch = a.child_w[k];
+    const uint32_t o = a.poff[k];
+    const double scale = a.inv_dtmax * 281474976710656.0;          // 2^48 / Δtmax
+    for (int r = 0; r < ch.idx - ch.first; ++r) {
+        const nhp_event e = a.ev[ch.idx - 1 - r];
+        double q = __builtin_rint((ch.t - e.t) * scale);
+        q = q < 1.0 ? 1.0 : (q > 281474976710655.0 ? 281474976710655.0 : q);
+        plist[(size_t)o + r] = ((uint64_t)(uint32_t)e.node << 48) | (uint64_t)q;
+    }
+}
+
+template <int G, int U, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_windowed_pairs(nhp_cont_args a, int mask_integral, int max_item,
+                                                              double *__restrict__ partials,
+                                                              unsigned int *__restrict__ counter,
+                                                              double *__restrict__ out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *red = reinterpret_cast<double *>(smem);                 // [2 * waves <= 32] + flag at [32]
+    double2 *col = reinterpret_cast<double2 *>(smem + 320);         // [N] {θ·Δtmax·2⁻⁴⁸, a·w·θ}: the delay arrives as an integer
+    double *etab = reinterpret_cast<double *>(col + a.N);           // [64] 2^(j/64) for nhp_exp_neg_tab
+    uint32_t *off = reinterpret_cast<uint32_t *>(etab + 64);        // [max_item + 1] pair offsets of the item's children
+    nhp_exp_tab_init(etab);
+
+    const nhp_item it = a.items[blockIdx.x];
+    const int c = it.node, N = a.N, tid = threadIdx.x;
+    NHP_STAMP_AT(0);
+    const int nchild = it.kend - it.kbeg;
+    const uint32_t base = a.poff[it.kbeg];
+    const double unit = a.dt_max * 3.5527136788005009e-15;         // Δtmax · 2⁻⁴⁸
+    double integ = 0.0;
+    for (int p = tid; p < N; p += BLOCK) {
+        const size_t k = (size_t)p + (size_t)c * N;
+        double w = a.W[k], wint = w;
+        if (a.A) {
+            w = a.A[k] * w;
+            if (mask_integral) wint = w;
+        }
+        const double th = a.p1[k];
+        col[p] = make_double2(th * unit, w * th);                   // term = (a·w·θ)·exp(-(θ·unit)·q)
+        if (it.first) integ += a.cnt[p] * wint;
+    }
+    for (int i = tid; i <= nchild; i += BLOCK) off[i] = a.poff[it.kbeg + i] - base;
+    if (out && it.first) integ += baseline_integral_col(a, c);
+    __syncthreads();
+    NHP_STAMP_AT(1);
+
+    constexpr int GROUPS = BLOCK / G, GW = 64 / G;
+    const int gid = tid / G, gl = tid % G;
+    const int slot0 = (gid / GW) * (GW * U) + (gid % GW);
+    const uint64_t *pl = a.plist + base;
+    const bool flat = a.baseline_kind == NHP_BASELINE_HOMOGENEOUS;
+    const double lam0 = flat ? a.lambda0[c] : 0.0;
+    double prod = 1.0;
+    int pexp = 0;
+    auto term = [&](const uint64_t w) {
+        const double q = __hiloint2double((int)(((unsigned)(w >> 32) & 0xFFFFu) | 0x43300000u), (int)(unsigned)w) - 4503599627370496.0;
+        const double2 cw = col[(int)(w >> 48)];
+        return cw.y * nhp_exp_neg_tab(-(cw.x * q), etab);
+    };
+    // Every address of every round is known once the offsets are staged, so a round's two trips are requested while the
+    // round before it is being summed (two register sets, the loop unrolled by two: no set is ever copied).  Both trips are
+    // always requested -- a lane without a second pair re-reads its first, the same sector -- so that the requests in
+    // flight are the same on every path.
+    struct slot_set { int j[U], e[U]; uint64_t w[U], w2[U]; };
+    auto issue = [&](const int r0, slot_set &q) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = r0 + slot0 + u * GW;
+            const bool v = kk < nchild;
+            q.j[u] = v ? (int)off[kk] + gl : 0;
+            q.e[u] = v ? (int)off[kk + 1] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j1 = q.j[u] < q.e[u] ? q.j[u] : 0;
+            q.w[u] = pl[j1];
+            q.w2[u] = pl[q.j[u] + G < q.e[u] ? q.j[u] + G : j1];
+        }
+    };
+    auto consume = [&](const int r0, slot_set &q) {
+        double s[U];
+        bool more = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            s[u] = q.j[u] < q.e[u] ? term(q.w[u]) : 0.0;
+            s[u] += q.j[u] + G < q.e[u] ? term(q.w2[u]) : 0.0;
+            q.j[u] += 2 * G;
+            more |= q.j[u] < q.e[u];
+        }
+        while (more) {                                              // third and later trips: long windows, rare
+            more = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (q.j[u] < q.e[u]) s[u] += term(pl[q.j[u]]);
+                q.j[u] += G;
+                more |= q.j[u] < q.e[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            s[u] = group_sum<G>(s[u]);
+            const int kk = r0 + slot0 + u * GW;
+            if (gl == 0 && kk < nchild) {
+                const double lam = (flat ? lam0 : baseline_at(a, c, a.child_w[it.kbeg + kk].t)) + s[u];
+                prod *= lam < 0.0 ? __builtin_nan("") : __builtin_amdgcn_frexp_mant(lam);
+                pexp += __builtin_amdgcn_frexp_exp(lam);
+            }
+        }
+        pexp += __builtin_amdgcn_frexp_exp(prod);
+        prod = __builtin_amdgcn_frexp_mant(prod);
+    };
+    constexpr int STEP = GROUPS * U;
+    slot_set qa, qb;
+    issue(0, qa);
+    for (int r0 = 0; r0 < nchild; r0 += 2 * STEP) {
+        issue(r0 + STEP, qb);
+        asm volatile("" ::: "memory");
+        consume(r0, qa);
+        issue(r0 + 2 * STEP, qa);
+        asm volatile("" ::: "memory");
+        consume(r0 + STEP, qb);
+    }
+    NHP_STAMP_AT(2);
+    double acc = nhp_log(prod) + (double)pexp * 6.93147180559945286e-01;
+    if (prod == 0.0) acc = -__builtin_inf();
+    double blk = acc, blk_int = integ;
+    nhp_block_sum2_n<BLOCK / 64>(blk, blk_int, red);
+    if (!out) {
+        if (tid == 0) {
+            partials[2 * (size_t)blockIdx.x] = blk;
+            partials[2 * (size_t)blockIdx.x + 1] = blk_int;
+        }
+        return;
+    }
+    // fused second stage: as k_windowed
+    int *flag = reinterpret_cast<int *>(red + 32);
+    if (tid == 0) {
+        __hip_atomic_store(&partials[2 * (size_t)blockIdx.x], blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&partials[2 * (size_t)blockIdx.x + 1], blk_int, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int nb = gridDim.x, sh = blockIdx.x % NHP_SHARDS;
+        const unsigned int pop = (nb - sh + NHP_SHARDS - 1) / NHP_SHARDS;
+        const unsigned int used = nb < NHP_SHARDS ? nb : NHP_SHARDS;
+        int last = 0;
+        if (__hip_atomic_fetch_add(&counter[32 * (1 + sh)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pop - 1)
+            last = __hip_atomic_fetch_add(&counter[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == used - 1;
+        *flag = last;
+    }
+    __syncthreads();
+    NHP_STAMP_AT(3);
+    NHP_STAMP_AT(4);
+    if (!*flag) return;
+    double sl = 0.0, si = 0.0;
+    for (unsigned int i = tid; i < gridDim.x; i += BLOCK) {
+        sl += __hip_atomic_load(&partials[2 * (size_t)i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        si += __hip_atomic_load(&partials[2 * (size_t)i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    nhp_block_sum2_n<BLOCK / 64>(sl, si, red);
+    if (tid == 0) *out = (0.0 - si) + sl;
     if (tid <= NHP_SHARDS) __hip_atomic_store(&counter[32 * tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -899,6 +1078,45 @@ static nhp_status run_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const n
     if (child_w) a.child_w = child_w;                     // same children, other window starts (recursive path)
     const int G = group ? group : ds->group;
     dim3 grid((unsigned)ds->n_items);
+    // the dataset's own short windows, exponential impulses, no λ output: through the cached pair list (k_windowed_pairs)
+    const bool plist_off = getenv("NHP_PLIST") && atoi(getenv("NHP_PLIST")) == 0;       // (read per call: the tests switch it)
+    if (m->impulse_kind == NHP_IMPULSE_EXPONENTIAL && !d_lambda && !child_w && ds->d_poff && !plist_off && G <= 8) {
+        if (!ds->d_plist) {                                        // first use: build the list (data only)
+            nhp_cont_dataset *mds = const_cast<nhp_cont_dataset *>(ds);
+            if (hipMalloc((void **)&mds->d_plist, 8 * (size_t)std::max<int64_t>(ds->pairs, 1)) != hipSuccess) {
+                mds->d_plist = nullptr;
+                (void)hipGetLastError();
+            } else {
+                hipLaunchKernelGGL(k_pairs_build, dim3((unsigned)((ds->M + 255) / 256)), dim3(256), 0, ctx->stream, a, mds->d_plist);
+                NHP_HIP(ctx, hipGetLastError());
+                a.plist = mds->d_plist;
+            }
+        }
+        const size_t lds2 = 320 + 16 * (size_t)ds->N + 512 + 4 * ((size_t)ds->max_item + 1) + 16;
+        if (ds->d_plist && lds2 <= 160 * 1024) {
+            // lanes per child, children per group in flight, workgroup size: measured at N = 1024, M = 1e6, K = 8
+            // (tools/dbg/pairsweep.sh); NHP_PAIRS_CFG = "G,U,BLOCK" overrides
+            int Gp = G == 8 ? 4 : G, Up = 2, Bp = 512;
+            if (const char *cfg = getenv("NHP_PAIRS_CFG")) sscanf(cfg, "%d,%d,%d", &Gp, &Up, &Bp);
+            bool ok = false;
+#define NHP_LCASE(g, u, b)                                                                                    \
+    if (!ok && Gp == g && Up == u && Bp == b) {                                                               \
+        ok = true;                                                                                            \
+        if (lds2 > 64 * 1024)                                                                                 \
+            (void)hipFuncSetAttribute((const void *)k_windowed_pairs<g, u, b>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+        hipLaunchKernelGGL((k_windowed_pairs<g, u, b>), grid, dim3(b), lds2, ctx->stream, a, mask_integral, ds->max_item,  \
+                           ctx->d_partials, ctx->d_counter, d_out);                                           \
+    }
+#define NHP_LROW(g) NHP_LCASE(g, 1, 256) NHP_LCASE(g, 2, 256) NHP_LCASE(g, 4, 256) NHP_LCASE(g, 1, 512) NHP_LCASE(g, 2, 512) NHP_LCASE(g, 4, 512) \
+                    NHP_LCASE(g, 1, 1024) NHP_LCASE(g, 2, 1024)
+            NHP_LROW(1) NHP_LROW(2) NHP_LROW(4) NHP_LROW(8)
+            if (!ok) { Gp = 4; Up = 2; Bp = 512; NHP_LCASE(4, 2, 512) }
+#undef NHP_LROW
+#undef NHP_LCASE
+            NHP_HIP(ctx, hipGetLastError());
+            return NHP_OK;
+        }
+    }
     if (m->impulse_kind == NHP_IMPULSE_EXPONENTIAL)
         launch_group<NHP_IMPULSE_EXPONENTIAL>(G, grid, lds, ctx->stream, a, mask_integral, ctx->d_partials, d_lambda, ctx->d_counter, d_out);
     else

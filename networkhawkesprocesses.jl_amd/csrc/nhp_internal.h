@@ -88,6 +88,13 @@ struct nhp_cont_dataset {
     // whose time goes into fetching ~8 scattered parent records per event: half the bytes per record.
     uint64_t *d_ev8 = nullptr;
     double ev8_t0 = 0.0, ev8_scale = 0.0;
+    // Short windows only (pairs <= 16 per event on average, finite dt_max): the parent-child pairs themselves, child by child
+    // in child_w order, most recent parent first -- node << 48 | Δt as a 48-bit fraction of dt_max, 8 bytes a pair.  The
+    // exponential log-likelihood kernel then STREAMS its item's pairs (contiguous) instead of fetching ~8 scattered records per
+    // child behind each child record.  d_poff: pair offsets by child_w position (host-made with the dataset);
+    // d_plist: built on the device at the first evaluation that wants it.
+    uint32_t *d_poff = nullptr;         // [M + 1]
+    uint64_t *d_plist = nullptr;        // [pairs]
     // device arrays
     double *d_times = nullptr;          // [M] time order
     int32_t *d_nodes = nullptr;         // [M] 0-based
@@ -171,6 +178,8 @@ struct nhp_cont_args {
     const int32_t *nodes;
     const nhp_event *ev;
     const uint64_t *ev8;             // packed records (or null): see nhp_cont_dataset::d_ev8
+    const uint32_t *poff;            // pair list of short-window datasets (or null): see nhp_cont_dataset::d_poff
+    const uint64_t *plist;
     double ev8_t0, ev8_scale, ev8_inv;
     const nhp_child *child;
     const nhp_child *child_w;

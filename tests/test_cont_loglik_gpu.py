@@ -310,3 +310,33 @@ def test_batch_handles_empty_windows_and_degenerate_intensities(nhp, orc):
             assert out[k] == -np.inf
         else:
             assert rel(out[k], orc.loglik_windowed(oms[k], times, nodes, T)) < TOL
+
+
+@pytest.mark.parametrize("network,lgcp", [(False, False), (True, True)])
+def test_pair_list_and_packed_records_agree_with_the_exact_records(nhp, orc, network, lgcp, monkeypatch):
+    """Short-window exponential evaluations run through the cached pair list (k_windowed_pairs: Δt as a 48-bit fraction of
+    Δtmax) and, failing that, through the 8-byte event records (k_windowed<.., PACK>); NHP_PLIST=0 / NHP_EV8=0 switch them
+    off one after the other.  All three equal the oracle on the ORIGINAL times, for every (lanes per child, children in
+    flight, workgroup size) the pair kernel is built with, with ties (Δt = 0) and ragged windows in the data."""
+    c = random_case(12, 6000, 500.0, "exponential", 1.0, network=network, lgcp=lgcp, seed=11, nhp=nhp, orc=orc)
+    t = c["times"].copy()
+    t[1000:1040:2] = t[1001:1041:2]                                  # ties: parents at Δt = 0
+    t[3000:3120] = np.sort(np.random.default_rng(3).uniform(t[3000], t[3000] + 0.7, 120))   # a burst: windows of ~100 parents
+    t = np.sort(t)
+    data = (t, c["nodes"], c["T"])
+    want = orc.loglik(c["om"], t, c["nodes"], c["T"], recursive=False)
+    got = {}
+    for name, env in (("pairs", {}), ("ev8", {"NHP_PLIST": "0"}), ("exact", {"NHP_PLIST": "0", "NHP_EV8": "0"})):
+        for k in ("NHP_PLIST", "NHP_EV8"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        nhp.invalidate_device_datasets()
+        got[name] = nhp.loglikelihood(c["proc"], data, recursive=False)
+        assert rel(got[name], want) < TOL, name
+    assert rel(got["pairs"], got["exact"]) < 1e-13 and rel(got["ev8"], got["exact"]) < 1e-13
+    monkeypatch.delenv("NHP_PLIST", raising=False)
+    monkeypatch.delenv("NHP_EV8", raising=False)
+    for cfg in ("1,1,256", "2,4,256", "4,2,512", "8,4,512", "4,1,1024", "8,2,1024", "2,2,512"):
+        monkeypatch.setenv("NHP_PAIRS_CFG", cfg)
+        assert rel(nhp.loglikelihood(c["proc"], data, recursive=False), want) < TOL, cfg
