@@ -182,13 +182,20 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_build(nhp_cont_args a, const 
     }
 }
 
+__global__ __launch_bounds__(256) void k_adj_lq(int64_t n, double inv_dtmax, const double *__restrict__ ent_dt, double2 *__restrict__ ent_lq)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) ent_lq[i] = nhp_logitnormal_data(inv_dtmax, ent_dt[i]);
+}
+
 // Per sweep: x = W[p,c]·ħ(Δt) for every cached entry of column c (a streaming pass: coalesced reads of
 // {k, p, Δt}, the column of the tables in LDS) and λ_k = λ0 + Σ A[p,c]·x per child.
 template <int IMP>
 __global__ __launch_bounds__(NHP_BLOCK) void k_adj_eval(nhp_cont_args a, const double *__restrict__ A,
                                                         const int64_t *__restrict__ pair_off,
                                                         const int32_t *__restrict__ ent_k, const int32_t *__restrict__ ent_p,
-                                                        const double *__restrict__ ent_dt, double *__restrict__ ent_x,
+                                                        const double *__restrict__ ent_dt, const double2 *__restrict__ ent_lq,
+                                                        double *__restrict__ ent_x,
                                                         int max_children, double *__restrict__ lam_g,
                                                         const double *__restrict__ rho_mat, double rho_host,
                                                         const double *__restrict__ rho_dev, const double *__restrict__ u,
@@ -229,10 +236,13 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_eval(nhp_cont_args a, const d
     for (int64_t eb = e0 + tid; eb < e1; eb += EU * NHP_BLOCK) {
         int p[EU], k[EU];
         double dt[EU], x[EU];
+        double2 lq[EU];
 #pragma unroll
         for (int u = 0; u < EU; ++u) {
             const int64_t e = eb + u * NHP_BLOCK < e1 ? eb + u * NHP_BLOCK : eb;       // clamped: value unused
-            p[u] = ent_p[e]; dt[u] = ent_dt[e]; k[u] = ent_k[e];
+            p[u] = ent_p[e]; k[u] = ent_k[e];
+            if (IMP == NHP_IMPULSE_EXPONENTIAL) dt[u] = ent_dt[e];
+            else lq[u] = ent_lq[e];                                  // {logit(x), 1/(x(1-x))}: the logarithm and the division are data
         }
         int run[EU];
 #pragma unroll
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_eval(nhp_cont_args a, const d
             run[u] = p[u] >> NHP_ADJ_RUN_SHIFT; p[u] &= (1 << NHP_ADJ_RUN_SHIFT) - 1;
             const double2 q = col[p[u]];
             if (IMP == NHP_IMPULSE_EXPONENTIAL) x[u] = q.y * nhp_pdf_exponential(q.x, dt[u]);
-            else x[u] = colw[p[u]] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt[u]);
+            else x[u] = colw[p[u]] * nhp_pdf_logitnormal_cached(q.x, q.y, lq[u]);
         }
 #pragma unroll
         for (int u = 0; u < EU; ++u) {
@@ -250,9 +260,8 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_eval(nhp_cont_args a, const d
                 // repeats themselves (child -1) are dead
                 for (int r = 1; r <= run[u]; ++r) {
                     const double2 q = col[p[u]];
-                    const double dr = ent_dt[e + r];
-                    if (IMP == NHP_IMPULSE_EXPONENTIAL) x[u] += q.y * nhp_pdf_exponential(q.x, dr);
-                    else x[u] += colw[p[u]] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dr);
+                    if (IMP == NHP_IMPULSE_EXPONENTIAL) x[u] += q.y * nhp_pdf_exponential(q.x, ent_dt[e + r]);
+                    else x[u] += colw[p[u]] * nhp_pdf_logitnormal_cached(q.x, q.y, ent_lq[e + r]);
                 }
                 if (k[u] < 0) x[u] = 0.0;
                 ent_x[e] = x[u];
@@ -578,11 +587,20 @@ nhp_status nhp_adj_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_mo
     if (expo) {
         if (lds_eval > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_eval<NHP_IMPULSE_EXPONENTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval));
         hipLaunchKernelGGL((k_adj_eval<NHP_IMPULSE_EXPONENTIAL>), dim3(ncol), dim3(NHP_BLOCK), lds_eval, st, a, m->d_A,
-                           d_off, d_k, ds->d_adj_p, ds->d_adj_dt, d_x, max_children, d_lam, d_rho, rho, d_rho_scalar, d_u, seed, step, d_uni, d_bias);
+                           d_off, d_k, ds->d_adj_p, ds->d_adj_dt, (const double2 *)nullptr, d_x, max_children, d_lam, d_rho, rho, d_rho_scalar, d_u, seed, step, d_uni, d_bias);
     } else {
         if (lds_eval > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_eval<NHP_IMPULSE_LOGITNORMAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval));
+        if (!ds->d_adj_lq) {                                         // first logit-normal sweep on this dataset: the data half of the pdf
+            nhp_cont_dataset *mds = const_cast<nhp_cont_dataset *>(ds);
+            if (hipMalloc((void **)&mds->d_adj_lq, 16 * P) != hipSuccess) {
+                mds->d_adj_lq = nullptr;
+                nhp_set_error(ctx, "resample_adjacency: out of device memory for %zu cached pairs", P);
+                return NHP_ENOMEM;
+            }
+            hipLaunchKernelGGL(k_adj_lq, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, (int64_t)ds->pairs, a.inv_dtmax, ds->d_adj_dt, mds->d_adj_lq);
+        }
         hipLaunchKernelGGL((k_adj_eval<NHP_IMPULSE_LOGITNORMAL>), dim3(ncol), dim3(NHP_BLOCK), lds_eval, st, a, m->d_A,
-                           d_off, d_k, ds->d_adj_p, ds->d_adj_dt, d_x, max_children, d_lam, d_rho, rho, d_rho_scalar, d_u, seed, step, d_uni, d_bias);
+                           d_off, d_k, ds->d_adj_p, ds->d_adj_dt, ds->d_adj_lq, d_x, max_children, d_lam, d_rho, rho, d_rho_scalar, d_u, seed, step, d_uni, d_bias);
     }
     NHP_HIP(ctx, hipGetLastError());
     if (lds_sweep > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sweep));

@@ -266,9 +266,9 @@ extern "C" void nhp_cont_dataset_destroy(nhp_cont_dataset *ds)
     if (!ds) return;
     (void)hipSetDevice(ds->ctx->device);
     (void)hipStreamSynchronize(ds->ctx->stream);
-    (void)hipFree(ds->d_times); (void)hipFree(ds->d_nodes); (void)hipFree(ds->d_child); (void)hipFree(ds->d_child_w); (void)hipFree(ds->d_wpos); (void)hipFree(ds->d_ev); (void)hipFree(ds->d_ev8); (void)hipFree(ds->d_poff); (void)hipFree(ds->d_plist);
+    (void)hipFree(ds->d_times); (void)hipFree(ds->d_nodes); (void)hipFree(ds->d_child); (void)hipFree(ds->d_child_w); (void)hipFree(ds->d_wpos); (void)hipFree(ds->d_ev); (void)hipFree(ds->d_ev8); (void)hipFree(ds->d_poff); (void)hipFree(ds->d_plist); (void)hipFree(ds->d_plq); (void)hipFree(ds->d_pnode);
     (void)hipFree(ds->d_boff); (void)hipFree(ds->d_items); (void)hipFree(ds->d_cnt); (void)hipFree(ds->d_pn);
-    (void)hipFree(ds->d_adj_k); (void)hipFree(ds->d_adj_p); (void)hipFree(ds->d_adj_dt); (void)hipFree(ds->d_adj_start); (void)hipFree(ds->d_adj_off); (void)hipFree(ds->d_adj_group); (void)hipFree(ds->d_child_cut);
+    (void)hipFree(ds->d_adj_k); (void)hipFree(ds->d_adj_p); (void)hipFree(ds->d_adj_dt); (void)hipFree(ds->d_adj_lq); (void)hipFree(ds->d_adj_start); (void)hipFree(ds->d_adj_off); (void)hipFree(ds->d_adj_group); (void)hipFree(ds->d_child_cut);
     delete ds;
 }
 
@@ -401,7 +401,7 @@ nhp_cont_args nhp_make_args(const nhp_cont_dataset *ds, const nhp_cont_model *m)
     nhp_cont_args a;
     const bool ev8_off = getenv("NHP_EV8") && atoi(getenv("NHP_EV8")) == 0;             // (A/B switch, read per call: exact 16-byte records everywhere)
     a.ev8 = ev8_off ? nullptr : ds->d_ev8; a.ev8_t0 = ds->ev8_t0; a.ev8_scale = ds->ev8_scale; a.ev8_inv = ds->ev8_scale > 0.0 ? 1.0 / ds->ev8_scale : 0.0;
-    a.poff = ds->d_poff; a.plist = ds->d_plist;
+    a.poff = ds->d_poff; a.plist = ds->d_plist; a.plq = ds->d_plq; a.pnode = ds->d_pnode;
     a.times = ds->d_times; a.nodes = ds->d_nodes; a.ev = ds->d_ev; a.child = ds->d_child; a.child_w = ds->d_child_w; a.boff = ds->d_boff;
     a.items = ds->d_items; a.cnt = ds->d_cnt;
     a.lambda0 = m->d_lambda0; a.grid = m->d_grid; a.p1 = m->d_p1; a.p2 = m->d_p2; a.W = m->d_W;

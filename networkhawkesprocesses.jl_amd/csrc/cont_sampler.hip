@@ -42,6 +42,29 @@ __device__ __forceinline__ double samp_weight(const nhp_cont_args &a, const samp
     return sc.colw[p] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
 }
 
+// Weight k of a child through the logit-normal pair cache (lq, nd already point at the child's first pair): the logarithm and
+// the division of the pdf were taken when the cache was built, with the same operations -- the same bits.
+__device__ __forceinline__ double samp_weight_cached(const samp_col &sc, const double2 d, const int p)
+{
+#pragma clang fp contract(off)
+    const double2 q = sc.col[p];
+    return sc.colw[p] * nhp_pdf_logitnormal_cached(q.x, q.y, d);
+}
+
+__global__ __launch_bounds__(256) void k_plq_build(nhp_cont_args a, double2 *__restrict__ plq, uint16_t *__restrict__ pnode)
+{
+#pragma clang fp contract(off)
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= a.M) return;
+    const nhp_child ch = a.child_w[k];
+    const uint32_t o = a.poff[k];
+    for (int r = 0; r < ch.idx - ch.first; ++r) {
+        const nhp_event e = a.ev[ch.idx - 1 - r];
+        plq[(size_t)o + r] = nhp_logitnormal_data(a.inv_dtmax, ch.t - e.t);
+        pnode[(size_t)o + r] = (uint16_t)e.node;
+    }
+}
+
 __device__ __forceinline__ double samp_baseline(const nhp_cont_args &a, int c, double t)
 {
 #pragma clang fp contract(off)
@@ -58,7 +81,7 @@ __device__ __forceinline__ double samp_baseline(const nhp_cont_args &a, int c, d
 }
 
 // weight k of child i: k < n-1 -> parent i-1-k, k == n-1 -> baseline
-#define SAMP_W(k) ((k) < n - 1 ? samp_weight<IMP>(a, sc, t, i - 1 - (k)) : base)
+#define SAMP_W(k) ((k) < n - 1 ? (IMP != NHP_IMPULSE_EXPONENTIAL && lq ? samp_weight_cached(sc, lq[k], nd[k]) : samp_weight<IMP>(a, sc, t, i - 1 - (k))) : base)
 
 // Sequential left fold over [lo, hi] -- Julia's mapreduce_impl leaf (and the n < 16 path).
 #define SAMP_CACHE 16      // weights per child kept in LDS between the sum pass and the scan pass (8: 133 us vs 122 us at mean window 8)
@@ -80,17 +103,27 @@ __device__ __forceinline__ double samp_weight_of(const nhp_cont_args &a, const s
 #define SAMP_FU 4
 template <int IMP>
 __device__ __forceinline__ double samp_fold(const nhp_cont_args &a, const samp_col &sc, double t, int i,
-                                            int n, double base, int lo, int hi, double *wcache)
+                                            int n, double base, int lo, int hi, double *wcache,
+                                            const double2 *lq, const uint16_t *nd)
 {
 #pragma clang fp contract(off)
     double v = 0.0;
     for (int k0 = lo; k0 <= hi; k0 += SAMP_FU) {
-        nhp_event e[SAMP_FU];
-#pragma unroll
-        for (int u = 0; u < SAMP_FU; ++u) e[u] = a.ev[k0 + u < n - 1 ? i - 1 - (k0 + u) : i - 1];
         double w[SAMP_FU];
+        if (IMP != NHP_IMPULSE_EXPONENTIAL && lq) {                  // (wave-uniform) the cached data half of the pdf
+            double2 d[SAMP_FU];
+            int p[SAMP_FU];
 #pragma unroll
-        for (int u = 0; u < SAMP_FU; ++u) w[u] = samp_weight_of<IMP>(a, sc, t, e[u]);
+            for (int u = 0; u < SAMP_FU; ++u) { const int k = k0 + u < n - 1 ? k0 + u : 0; d[u] = lq[k]; p[u] = nd[k]; }
+#pragma unroll
+            for (int u = 0; u < SAMP_FU; ++u) w[u] = samp_weight_cached(sc, d[u], p[u]);
+        } else {
+            nhp_event e[SAMP_FU];
+#pragma unroll
+            for (int u = 0; u < SAMP_FU; ++u) e[u] = a.ev[k0 + u < n - 1 ? i - 1 - (k0 + u) : i - 1];
+#pragma unroll
+            for (int u = 0; u < SAMP_FU; ++u) w[u] = samp_weight_of<IMP>(a, sc, t, e[u]);
+        }
 #pragma unroll
         for (int u = 0; u < SAMP_FU; ++u) {
             const int k = k0 + u;
@@ -107,10 +140,11 @@ __device__ __forceinline__ double samp_fold(const nhp_cont_args &a, const samp_c
 // Julia Base `sum` over n boxed elements: sequential for n <= 1024, otherwise split at
 // lo + (hi-lo)>>1 recursively (reduce.jl, pairwise_blocksize = 1024).  Iterative post-order.
 template <int IMP>
-__device__ double samp_sum(const nhp_cont_args &a, const samp_col &sc, double t, int i, int n, double base, double *wcache)
+__device__ double samp_sum(const nhp_cont_args &a, const samp_col &sc, double t, int i, int n, double base, double *wcache,
+                           const double2 *lq, const uint16_t *nd)
 {
 #pragma clang fp contract(off)
-    if (n <= 1024) return samp_fold<IMP>(a, sc, t, i, n, base, 0, n - 1, wcache);
+    if (n <= 1024) return samp_fold<IMP>(a, sc, t, i, n, base, 0, n - 1, wcache, lq, nd);
     int s_lo[24], s_hi[24], s_state[24];
     double s_left[24];
     int sp = 0;
@@ -121,7 +155,7 @@ __device__ double samp_sum(const nhp_cont_args &a, const samp_col &sc, double t,
         const int lo = s_lo[f], hi = s_hi[f];
         if (s_state[f] == 0) {
             if (hi - lo < 1024) {
-                ret = samp_fold<IMP>(a, sc, t, i, n, base, lo, hi, wcache);
+                ret = samp_fold<IMP>(a, sc, t, i, n, base, lo, hi, wcache, lq, nd);
                 --sp;
             } else {
                 s_state[f] = 1;
@@ -182,7 +216,9 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_sampler(nhp_cont_args a, const do
         if (i > 0) {                                       // index == 1 -> (0, 0): src/parents.jl:26-28
             const int n = i - ch.first + 1;
             const double base = samp_baseline(a, c, t);
-            const double s = samp_sum<IMP>(a, sc, t, i, n, base, wcache);
+            const double2 *lq = (IMP != NHP_IMPULSE_EXPONENTIAL && a.plq) ? a.plq + a.poff[kw] : nullptr;
+            const uint16_t *nd = lq ? a.pnode + a.poff[kw] : nullptr;
+            const double s = samp_sum<IMP>(a, sc, t, i, n, base, wcache, lq, nd);
             if (!(s > 0.0) || !(s < __builtin_inf())) *err = 1;
             const double draw = u ? u[i] : nhp_philox_uniform(seed, step, (uint64_t)i);
             int kk = 0;
@@ -458,6 +494,20 @@ static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
 
     nhp_cont_args a = nhp_make_args(ds, m);
     const bool expo = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
+    // logit-normal impulses on a short-window dataset: the data half of every pair's pdf, once (k_plq_build)
+    if (!expo && ds->d_poff && !ds->d_plq && !(getenv("NHP_PLQ") && atoi(getenv("NHP_PLQ")) == 0)) {
+        nhp_cont_dataset *mds = const_cast<nhp_cont_dataset *>(ds);
+        const size_t P = (size_t)std::max<int64_t>(ds->pairs, 1);
+        if (hipMalloc((void **)&mds->d_plq, 16 * P) != hipSuccess || hipMalloc((void **)&mds->d_pnode, 2 * P) != hipSuccess) {
+            (void)hipFree(mds->d_plq); mds->d_plq = nullptr; mds->d_pnode = nullptr;
+            (void)hipGetLastError();                        // no room: the sampler evaluates the whole pdf per pair, as before
+        } else {
+            hipLaunchKernelGGL(k_plq_build, dim3((unsigned)((ds->M + 255) / 256)), dim3(256), 0, ctx->stream, a, mds->d_plq, mds->d_pnode);
+            NHP_HIP(ctx, hipGetLastError());
+            a.plq = mds->d_plq; a.pnode = mds->d_pnode;
+        }
+    }
+    if (getenv("NHP_PLQ") && atoi(getenv("NHP_PLQ")) == 0) { a.plq = nullptr; a.pnode = nullptr; }
     // 8 lanes per child (k_sampler8) from a mean window of 24 parents: measured (N=1024, M=1e6, exp | logit-normal)
     // 508 | 846 µs vs 681 | 1228 µs at K̄=64 and 3.3 | 6.3 ms vs 5.0 | 8.9 ms at K̄=512, but 144 | 198 µs vs 115 | 174 µs
     // at K̄=8, where the 8-step chains outweigh the better gathers.  Never when some window reaches Julia's

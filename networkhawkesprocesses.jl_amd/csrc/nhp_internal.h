@@ -95,6 +95,11 @@ struct nhp_cont_dataset {
     // d_plist: built on the device at the first evaluation that wants it.
     uint32_t *d_poff = nullptr;         // [M + 1]
     uint64_t *d_plist = nullptr;        // [pairs]
+    // the same pairs for the logit-normal parent sampler: {logit(x), 1/(x(1-x))} at x = Δt/Δtmax -- the data half of the
+    // impulse pdf, evaluated ONCE with the operation sequence the sampler (and the oracle) use, so the weights keep their
+    // bits -- and the parent's node; built at the first logit-normal sweep
+    double2 *d_plq = nullptr;           // [pairs]
+    uint16_t *d_pnode = nullptr;        // [pairs]
     // device arrays
     double *d_times = nullptr;          // [M] time order
     int32_t *d_nodes = nullptr;         // [M] 0-based
@@ -112,6 +117,7 @@ struct nhp_cont_dataset {
     // adjacency sweep: the data-only pair lists (per child column, sorted by parent node), built on first use
     int32_t *d_adj_k = nullptr, *d_adj_p = nullptr;   // [pairs] child slot within the column, parent node
     double *d_adj_dt = nullptr;                       // [pairs] t_child - t_parent
+    double2 *d_adj_lq = nullptr;                      // [pairs] logit-normal impulses: {logit(x), 1/(x(1-x))} at x = Δt/Δtmax (data only; {0, 0} outside (0, 1)), made at the first logit-normal sweep
     int32_t *d_adj_start = nullptr;                   // [N*(N+1)] per-column offsets by parent node
     int64_t *d_adj_off = nullptr;                     // [N+1] first pair of each column
     // recursive ll evaluated as a truncated window (cont_recursive.hip): children with window starts for `cut_cached`
@@ -180,6 +186,8 @@ struct nhp_cont_args {
     const uint64_t *ev8;             // packed records (or null): see nhp_cont_dataset::d_ev8
     const uint32_t *poff;            // pair list of short-window datasets (or null): see nhp_cont_dataset::d_poff
     const uint64_t *plist;
+    const double2 *plq;              // logit-normal pair cache (or null): see nhp_cont_dataset::d_plq
+    const uint16_t *pnode;
     double ev8_t0, ev8_scale, ev8_inv;
     const nhp_child *child;
     const nhp_child *child_w;

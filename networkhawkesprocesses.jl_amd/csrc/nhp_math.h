@@ -240,6 +240,25 @@ __device__ __forceinline__ double nhp_pdf_exponential_ll(double r, double dt)
 #endif
 }
 
+// The same value from its data-only half -- lq = {logit(x), 1/(x(1-x))}, what nhp_logitnormal_data makes of a delay once per
+// dataset -- and the parameters: no logarithm and no division left per evaluation (bit-identical to nhp_pdf_logitnormal).
+__device__ __forceinline__ double2 nhp_logitnormal_data(double inv_dtmax, double dt)
+{
+#pragma clang fp contract(off)
+    const double x = dt * inv_dtmax;
+    if (!(x > 0.0 && x < 1.0)) return make_double2(0.0, 0.0);
+    const double o = 1.0 - x;
+    const double q = 1.0 / (x * o);
+    return make_double2(nhp_log((x * x) * q), q);
+}
+__device__ __forceinline__ double nhp_pdf_logitnormal_cached(double mu, double st, double2 lq)
+{
+#pragma clang fp contract(off)
+    const double z = (lq.x - mu) * st;
+    const double e = nhp_exp_neg(-0.5 * (z * z));
+    return (e * (NHP_INVSQRT2PI * st)) * lq.y;                     // (q = 0 marks a delay outside (0, Δtmax): 0)
+}
+
 // Logit-normal at x = Δt/Δtmax, NOT divided by Δtmax (src/impulses.jl:174-178).
 // st = sqrt(τ).  One division for q = 1/(x(1-x)), logit(x) = log(x*x*q).
 __device__ __forceinline__ double nhp_pdf_logitnormal(double mu, double st, double inv_dtmax, double dt)
