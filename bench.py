@@ -38,7 +38,7 @@ WORKLOADS = {
     # SURVEY 8d "realistic" set: the events are drawn from the model itself (children clustered behind their parents,
     # burstier windows: at kbar 8, mean 9.1, s.d. 4.6, max 46 against 8.0 / 2.8 / 27 for the uniform times); M is what
     # the draw gives.  The default run takes the kbar-32 twin (16 lanes per child): its kernel instantiation differs from
-    # the headline's k_windowed_pairs<4,2,512> (the cached pair list), whose rocprofv3 per-symbol average must stay the headline's alone.
+    # the headline's k_windowed_pairs<0,4,1,512> (the cached pair list), whose rocprofv3 per-symbol average must stay the headline's alone.
     "simulated_k8": dict(kind="exponential", kbar=8.0, recursive=False, simulated=True),
     "simulated_k32": dict(kind="exponential", kbar=32.0, recursive=False, simulated=True),
 }

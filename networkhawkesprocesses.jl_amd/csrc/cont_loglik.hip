@@ -337,7 +337,9 @@ __global__ __launch_bounds__(256) void k_pairs_build(nhp_cont_args a, uint64_t *
     }
 }
 
-template <int G, int U, int BLOCK>
+// IMP = logit-normal reads the sampler's pair cache instead ({logit(x), 1/(x(1-x))} + node, 18 bytes a pair): the pdf's
+// logarithm and division are data (nhp_pdf_logitnormal_cached), what is left per pair is one exponential.
+template <int IMP, int G, int U, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_windowed_pairs(nhp_cont_args a, int mask_integral, int max_item,
                                                               double *__restrict__ partials,
                                                               unsigned int *__restrict__ counter,
@@ -345,8 +347,9 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_pairs(nhp_cont_args a, int m
 {
     extern __shared__ __align__(16) unsigned char smem[];
     double *red = reinterpret_cast<double *>(smem);                 // [2 * waves <= 32] + flag at [32]
-    double2 *col = reinterpret_cast<double2 *>(smem + 320);         // [N] {θ·Δtmax·2⁻⁴⁸, a·w·θ}: the delay arrives as an integer
-    double *etab = reinterpret_cast<double *>(col + a.N);           // [64] 2^(j/64) for nhp_exp_neg_tab
+    double2 *col = reinterpret_cast<double2 *>(smem + 320);         // [N] exp: {θ·Δtmax·2⁻⁴⁸, a·w·θ} (the delay arrives as an integer); logit: {μ, √τ}
+    double *colw = reinterpret_cast<double *>(col + a.N);           // [N] logit-normal: a·w
+    double *etab = colw + (IMP == NHP_IMPULSE_EXPONENTIAL ? 0 : a.N);   // [64] 2^(j/64) for nhp_exp_neg_tab
     uint32_t *off = reinterpret_cast<uint32_t *>(etab + 64);        // [max_item + 1] pair offsets of the item's children
     nhp_exp_tab_init(etab);
 
@@ -365,7 +368,12 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_pairs(nhp_cont_args a, int m
             if (mask_integral) wint = w;
         }
         const double th = a.p1[k];
-        col[p] = make_double2(th * unit, w * th);                   // term = (a·w·θ)·exp(-(θ·unit)·q)
+        if (IMP == NHP_IMPULSE_EXPONENTIAL) {
+            col[p] = make_double2(th * unit, w * th);               // term = (a·w·θ)·exp(-(θ·unit)·q)
+        } else {
+            col[p] = make_double2(th, __builtin_sqrt(a.p2[k]));
+            colw[p] = w;
+        }
         if (it.first) integ += a.cnt[p] * wint;
     }
     for (int i = tid; i <= nchild; i += BLOCK) off[i] = a.poff[it.kbeg + i] - base;
@@ -376,21 +384,35 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_pairs(nhp_cont_args a, int m
     constexpr int GROUPS = BLOCK / G, GW = 64 / G;
     const int gid = tid / G, gl = tid % G;
     const int slot0 = (gid / GW) * (GW * U) + (gid % GW);
-    const uint64_t *pl = a.plist + base;
+    const uint64_t *pl = a.plist + (IMP == NHP_IMPULSE_EXPONENTIAL ? base : 0);
+    const double2 *plq = a.plq + (IMP == NHP_IMPULSE_EXPONENTIAL ? 0 : base);
+    const uint16_t *pnd = a.pnode + (IMP == NHP_IMPULSE_EXPONENTIAL ? 0 : base);
     const bool flat = a.baseline_kind == NHP_BASELINE_HOMOGENEOUS;
     const double lam0 = flat ? a.lambda0[c] : 0.0;
     double prod = 1.0;
     int pexp = 0;
-    auto term = [&](const uint64_t w) {
-        const double q = __hiloint2double((int)(((unsigned)(w >> 32) & 0xFFFFu) | 0x43300000u), (int)(unsigned)w) - 4503599627370496.0;
-        const double2 cw = col[(int)(w >> 48)];
-        return cw.y * nhp_exp_neg_tab(-(cw.x * q), etab);
+    struct rec { uint64_t w; double2 d; int p; };                  // (exp: w; logit-normal: d, p)
+    auto fetch = [&](const int jj) {
+        rec r;
+        if (IMP == NHP_IMPULSE_EXPONENTIAL) r.w = pl[jj];
+        else { r.d = plq[jj]; r.p = pnd[jj]; }
+        return r;
+    };
+    auto term = [&](const rec &r) {
+        if (IMP == NHP_IMPULSE_EXPONENTIAL) {
+            const double q = __hiloint2double((int)(((unsigned)(r.w >> 32) & 0xFFFFu) | 0x43300000u), (int)(unsigned)r.w) - 4503599627370496.0;
+            const double2 cw = col[(int)(r.w >> 48)];
+            return cw.y * nhp_exp_neg_tab(-(cw.x * q), etab);
+        } else {
+            const double2 cw = col[r.p];
+            return colw[r.p] * nhp_pdf_logitnormal_cached(cw.x, cw.y, r.d);
+        }
     };
     // Every address of every round is known once the offsets are staged, so a round's two trips are requested while the
     // round before it is being summed (two register sets, the loop unrolled by two: no set is ever copied).  Both trips are
     // always requested -- a lane without a second pair re-reads its first, the same sector -- so that the requests in
     // flight are the same on every path.
-    struct slot_set { int j[U], e[U]; uint64_t w[U], w2[U]; };
+    struct slot_set { int j[U], e[U]; rec w[U], w2[U]; };
     auto issue = [&](const int r0, slot_set &q) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -402,8 +424,8 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_pairs(nhp_cont_args a, int m
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j1 = q.j[u] < q.e[u] ? q.j[u] : 0;
-            q.w[u] = pl[j1];
-            q.w2[u] = pl[q.j[u] + G < q.e[u] ? q.j[u] + G : j1];
+            q.w[u] = fetch(j1);
+            q.w2[u] = fetch(q.j[u] + G < q.e[u] ? q.j[u] + G : j1);
         }
     };
     auto consume = [&](const int r0, slot_set &q) {
@@ -420,7 +442,7 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_pairs(nhp_cont_args a, int m
             more = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (q.j[u] < q.e[u]) s[u] += term(pl[q.j[u]]);
+                if (q.j[u] < q.e[u]) s[u] += term(fetch(q.j[u]));
                 q.j[u] += G;
                 more |= q.j[u] < q.e[u];
             }
@@ -1078,10 +1100,11 @@ static nhp_status run_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const n
     if (child_w) a.child_w = child_w;                     // same children, other window starts (recursive path)
     const int G = group ? group : ds->group;
     dim3 grid((unsigned)ds->n_items);
-    // the dataset's own short windows, exponential impulses, no λ output: through the cached pair list (k_windowed_pairs)
+    // the dataset's own short windows, no λ output: through the cached pair list (k_windowed_pairs)
     const bool plist_off = getenv("NHP_PLIST") && atoi(getenv("NHP_PLIST")) == 0;       // (read per call: the tests switch it)
-    if (m->impulse_kind == NHP_IMPULSE_EXPONENTIAL && !d_lambda && !child_w && ds->d_poff && !plist_off && G <= 8) {
-        if (!ds->d_plist) {                                        // first use: build the list (data only)
+    const bool expo_p = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
+    if (!d_lambda && !child_w && ds->d_poff && !plist_off && G <= 8 && (expo_p || nhp_ensure_pair_cache(ctx, ds, &a) == NHP_OK)) {
+        if (expo_p && !ds->d_plist) {                              // first use: build the list (data only)
             nhp_cont_dataset *mds = const_cast<nhp_cont_dataset *>(ds);
             if (hipMalloc((void **)&mds->d_plist, 8 * (size_t)std::max<int64_t>(ds->pairs, 1)) != hipSuccess) {
                 mds->d_plist = nullptr;
@@ -1092,25 +1115,32 @@ static nhp_status run_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const n
                 a.plist = mds->d_plist;
             }
         }
-        const size_t lds2 = 320 + 16 * (size_t)ds->N + 512 + 4 * ((size_t)ds->max_item + 1) + 16;
-        if (ds->d_plist && lds2 <= 160 * 1024) {
+        const size_t lds2 = 320 + (expo_p ? 16 : 24) * (size_t)ds->N + 512 + 4 * ((size_t)ds->max_item + 1) + 16;
+        if ((expo_p ? ds->d_plist != nullptr : ds->d_plq != nullptr) && lds2 <= 160 * 1024) {
             // lanes per child, children per group in flight, workgroup size: measured at N = 1024, M = 1e6, K = 8
             // (tools/dbg/pairsweep.sh); NHP_PAIRS_CFG = "G,U,BLOCK" overrides
-            int Gp = G == 8 ? 4 : G, Up = 2, Bp = 512;
+            int Gp = G == 8 ? 4 : G, Up = 1, Bp = 512;               // (with a round requested ahead, one child per group in flight: 24.6 us; two: 26.3)
             if (const char *cfg = getenv("NHP_PAIRS_CFG")) sscanf(cfg, "%d,%d,%d", &Gp, &Up, &Bp);
             bool ok = false;
 #define NHP_LCASE(g, u, b)                                                                                    \
     if (!ok && Gp == g && Up == u && Bp == b) {                                                               \
         ok = true;                                                                                            \
-        if (lds2 > 64 * 1024)                                                                                 \
-            (void)hipFuncSetAttribute((const void *)k_windowed_pairs<g, u, b>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
-        hipLaunchKernelGGL((k_windowed_pairs<g, u, b>), grid, dim3(b), lds2, ctx->stream, a, mask_integral, ds->max_item,  \
-                           ctx->d_partials, ctx->d_counter, d_out);                                           \
+        if (expo_p) {                                                                                         \
+            if (lds2 > 64 * 1024)                                                                             \
+                (void)hipFuncSetAttribute((const void *)k_windowed_pairs<NHP_IMPULSE_EXPONENTIAL, g, u, b>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+            hipLaunchKernelGGL((k_windowed_pairs<NHP_IMPULSE_EXPONENTIAL, g, u, b>), grid, dim3(b), lds2, ctx->stream, a, mask_integral, ds->max_item, \
+                               ctx->d_partials, ctx->d_counter, d_out);                                       \
+        } else {                                                                                              \
+            if (lds2 > 64 * 1024)                                                                             \
+                (void)hipFuncSetAttribute((const void *)k_windowed_pairs<NHP_IMPULSE_LOGITNORMAL, g, u, b>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+            hipLaunchKernelGGL((k_windowed_pairs<NHP_IMPULSE_LOGITNORMAL, g, u, b>), grid, dim3(b), lds2, ctx->stream, a, mask_integral, ds->max_item, \
+                               ctx->d_partials, ctx->d_counter, d_out);                                       \
+        }                                                                                                     \
     }
 #define NHP_LROW(g) NHP_LCASE(g, 1, 256) NHP_LCASE(g, 2, 256) NHP_LCASE(g, 4, 256) NHP_LCASE(g, 1, 512) NHP_LCASE(g, 2, 512) NHP_LCASE(g, 4, 512) \
                     NHP_LCASE(g, 1, 1024) NHP_LCASE(g, 2, 1024)
             NHP_LROW(1) NHP_LROW(2) NHP_LROW(4) NHP_LROW(8)
-            if (!ok) { Gp = 4; Up = 2; Bp = 512; NHP_LCASE(4, 2, 512) }
+            if (!ok) { Gp = 4; Up = 1; Bp = 512; NHP_LCASE(4, 1, 512) }
 #undef NHP_LROW
 #undef NHP_LCASE
             NHP_HIP(ctx, hipGetLastError());

@@ -173,6 +173,28 @@ __device__ double samp_sum(const nhp_cont_args &a, const samp_col &sc, double t,
     return ret;
 }
 
+// Logit-normal impulses on a short-window dataset: the data half of every pair's pdf, made once (k_plq_build) and shared by
+// the parent sampler and the log-likelihood kernel.  NHP_EINVAL when the dataset has no pair offsets, the cache is switched
+// off (NHP_PLQ=0) or there is no room for it; the callers then evaluate the whole pdf per pair.
+nhp_status nhp_ensure_pair_cache(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_args *a)
+{
+    if (!ds->d_poff || (getenv("NHP_PLQ") && atoi(getenv("NHP_PLQ")) == 0)) { a->plq = nullptr; a->pnode = nullptr; return NHP_EINVAL; }
+    if (!ds->d_plq) {
+        nhp_cont_dataset *mds = const_cast<nhp_cont_dataset *>(ds);
+        const size_t P = (size_t)std::max<int64_t>(ds->pairs, 1);
+        if (hipMalloc((void **)&mds->d_plq, 16 * P) != hipSuccess || hipMalloc((void **)&mds->d_pnode, 2 * P) != hipSuccess) {
+            (void)hipFree(mds->d_plq); mds->d_plq = nullptr; mds->d_pnode = nullptr;
+            (void)hipGetLastError();
+            a->plq = nullptr; a->pnode = nullptr;
+            return NHP_EINVAL;
+        }
+        hipLaunchKernelGGL(k_plq_build, dim3((unsigned)((ds->M + 255) / 256)), dim3(256), 0, ctx->stream, *a, mds->d_plq, mds->d_pnode);
+        NHP_HIP(ctx, hipGetLastError());
+    }
+    a->plq = ds->d_plq; a->pnode = ds->d_pnode;
+    return NHP_OK;
+}
+
 template <int IMP>
 __global__ __launch_bounds__(NHP_BLOCK) void k_sampler(nhp_cont_args a, const double *__restrict__ u,
                                                        uint64_t seed, uint64_t step,
@@ -494,20 +516,7 @@ static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
 
     nhp_cont_args a = nhp_make_args(ds, m);
     const bool expo = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
-    // logit-normal impulses on a short-window dataset: the data half of every pair's pdf, once (k_plq_build)
-    if (!expo && ds->d_poff && !ds->d_plq && !(getenv("NHP_PLQ") && atoi(getenv("NHP_PLQ")) == 0)) {
-        nhp_cont_dataset *mds = const_cast<nhp_cont_dataset *>(ds);
-        const size_t P = (size_t)std::max<int64_t>(ds->pairs, 1);
-        if (hipMalloc((void **)&mds->d_plq, 16 * P) != hipSuccess || hipMalloc((void **)&mds->d_pnode, 2 * P) != hipSuccess) {
-            (void)hipFree(mds->d_plq); mds->d_plq = nullptr; mds->d_pnode = nullptr;
-            (void)hipGetLastError();                        // no room: the sampler evaluates the whole pdf per pair, as before
-        } else {
-            hipLaunchKernelGGL(k_plq_build, dim3((unsigned)((ds->M + 255) / 256)), dim3(256), 0, ctx->stream, a, mds->d_plq, mds->d_pnode);
-            NHP_HIP(ctx, hipGetLastError());
-            a.plq = mds->d_plq; a.pnode = mds->d_pnode;
-        }
-    }
-    if (getenv("NHP_PLQ") && atoi(getenv("NHP_PLQ")) == 0) { a.plq = nullptr; a.pnode = nullptr; }
+    if (!expo) (void)nhp_ensure_pair_cache(ctx, ds, &a);            // (no cache: the whole pdf per pair, as before)
     // 8 lanes per child (k_sampler8) from a mean window of 24 parents: measured (N=1024, M=1e6, exp | logit-normal)
     // 508 | 846 µs vs 681 | 1228 µs at K̄=64 and 3.3 | 6.3 ms vs 5.0 | 8.9 ms at K̄=512, but 144 | 198 µs vs 115 | 174 µs
     // at K̄=8, where the 8-step chains outweigh the better gathers.  Never when some window reaches Julia's

@@ -262,6 +262,7 @@ nhp_status nhp_launch_event_intensity_as(nhp_ctx *ctx, const nhp_cont_dataset *d
 nhp_status nhp_launch_windowed_as(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, const nhp_child *child_w,
                                   int group, int mask_integral, double *d_out);
 nhp_status nhp_ctx_reserve_scratch(nhp_ctx *ctx, size_t bytes);
+nhp_status nhp_ensure_pair_cache(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_args *a);   // cont_sampler.hip
 nhp_cont_args nhp_make_args(const nhp_cont_dataset *ds, const nhp_cont_model *m);
 nhp_status nhp_check_pair(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m);
 // Device -> caller memory through the context's pinned staging buffer: DMA at link speed into pinned memory, then one

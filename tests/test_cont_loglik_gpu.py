@@ -340,3 +340,22 @@ def test_pair_list_and_packed_records_agree_with_the_exact_records(nhp, orc, net
     for cfg in ("1,1,256", "2,4,256", "4,2,512", "8,4,512", "4,1,1024", "8,2,1024", "2,2,512"):
         monkeypatch.setenv("NHP_PAIRS_CFG", cfg)
         assert rel(nhp.loglikelihood(c["proc"], data, recursive=False), want) < TOL, cfg
+    monkeypatch.delenv("NHP_PAIRS_CFG", raising=False)
+    # logit-normal impulses: the pair kernel reads {logit(x), 1/(x(1-x))} made once per dataset -- the same operations, so
+    # the same bits per term as the kernel that evaluates the whole pdf
+    cl = random_case(12, 6000, 500.0, "logitnormal", 1.0, network=network, lgcp=lgcp, seed=11, nhp=nhp, orc=orc)
+    wantl = orc.loglik(cl["om"], t, cl["nodes"], cl["T"], recursive=False)
+    gl = {}
+    for name, off in (("pairs", None), ("records", "0")):
+        if off is None:
+            monkeypatch.delenv("NHP_PLIST", raising=False)
+        else:
+            monkeypatch.setenv("NHP_PLIST", off)
+        nhp.invalidate_device_datasets()
+        gl[name] = nhp.loglikelihood(cl["proc"], (t, cl["nodes"], cl["T"]), recursive=False)
+        assert rel(gl[name], wantl) < TOL, name
+    assert rel(gl["pairs"], gl["records"]) < 1e-13
+    monkeypatch.delenv("NHP_PLIST", raising=False)
+    for cfg in ("2,2,256", "4,1,512", "8,2,1024"):
+        monkeypatch.setenv("NHP_PAIRS_CFG", cfg)
+        assert rel(nhp.loglikelihood(cl["proc"], (t, cl["nodes"], cl["T"]), recursive=False), wantl) < TOL, cfg

@@ -23,7 +23,7 @@ def mean(tag, kern, name):
          for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"] and r["Counter_Name"] == name]
     return sum(v) / len(v) if v else None
 out = {}
-for key, pre, kern, label in (("windowed_k8", "k8", "k_windowed_pairs<", "k_windowed_pairs<4,2,512>"), ("batch_8_sets", "b8", "k_windowed_batch", "k_windowed_batch<0,8,1024>")):
+for key, pre, kern, label in (("windowed_k8", "k8", "k_windowed_pairs<", "k_windowed_pairs<0,4,1,512>"), ("batch_8_sets", "b8", "k_windowed_batch", "k_windowed_batch<0,8,1024>")):
     f, w = mean(pre + "_fetch", kern, "FETCH_SIZE"), mean(pre + "_write", kern, "WRITE_SIZE")
     h, m = mean(pre + "_tcc", kern, "TCC_HIT_sum"), mean(pre + "_tcc", kern, "TCC_MISS_sum")
     if f is None: continue
