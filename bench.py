@@ -323,18 +323,22 @@ def config_workloads(nhp, ctx, which):
     out = []
 
     def timed(fn, reps):
+        """median of three blocks of `reps` calls (one warm-up first): wall times of host-involving legs vary run to run"""
         fn()
         ctx.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        ctx.synchronize()
-        return (time.perf_counter() - t0) / reps
+        blocks = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            ctx.synchronize()
+            blocks.append((time.perf_counter() - t0) / reps)
+        return sorted(blocks)[1]
 
     if "c2" in which:      # continuous exponential standard Hawkes, N=128, ~1e5 events: ll + mle! gradient
         N, M = 128, 100_000
         # mean window 32 -> 16 lanes per child: a different k_windowed instantiation from the headline's
-        # <0, 8, 4>, so that rocprofv3's per-symbol average of the headline kernel is not mixed with these calls
+        # (k_windowed_pairs), so that rocprofv3's per-symbol average of the headline kernel is not mixed with these calls
         times, nodes, T = nhp.synthetic.s_metric_data(N, M, kbar=32.0)
         proc = nhp.synthetic.s_metric_process(N, M, T, "exponential", 1.0)
         ds = nhp.device_dataset(proc, (times, nodes, T), ctx)
