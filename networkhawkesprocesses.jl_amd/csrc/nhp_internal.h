@@ -225,7 +225,9 @@ struct nhp_disc_dataset {
     std::vector<double> h_grid_x;                     // the LGCP grid [G]
 };
 
+#ifndef NHP_DA_TT
 #define NHP_DA_TT 128    // bins per workgroup tile of the discrete adjacency sweep (also the granularity of d_occ_off)
+#endif
 
 // disc.hip pieces shared with disc_gibbs.hip: upload W, θ, A (and λ0) and build the bump table E [N·B x N] on the device
 // (GEMM order k = p + b·N, or the reference's category order p·B + b with cat_order) plus base[c] = λ0[c]·dt; `extra`
