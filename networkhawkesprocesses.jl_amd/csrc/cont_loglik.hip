@@ -1103,7 +1103,7 @@ static nhp_status run_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const n
     // the dataset's own short windows, no λ output: through the cached pair list (k_windowed_pairs)
     const bool plist_off = getenv("NHP_PLIST") && atoi(getenv("NHP_PLIST")) == 0;       // (read per call: the tests switch it)
     const bool expo_p = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
-    if (!d_lambda && !child_w && ds->d_poff && !plist_off && G <= 8 && (expo_p || nhp_ensure_pair_cache(ctx, ds, &a) == NHP_OK)) {
+    if (!d_lambda && !child_w && ds->d_poff && !plist_off && G <= 16 && (expo_p || nhp_ensure_pair_cache(ctx, ds, &a) == NHP_OK)) {
         if (expo_p && !ds->d_plist) {                              // first use: build the list (data only)
             nhp_cont_dataset *mds = const_cast<nhp_cont_dataset *>(ds);
             if (hipMalloc((void **)&mds->d_plist, 8 * (size_t)std::max<int64_t>(ds->pairs, 1)) != hipSuccess) {
@@ -1119,7 +1119,7 @@ static nhp_status run_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const n
         if ((expo_p ? ds->d_plist != nullptr : ds->d_plq != nullptr) && lds2 <= 160 * 1024) {
             // lanes per child, children per group in flight, workgroup size: measured at N = 1024, M = 1e6, K = 8
             // (tools/dbg/pairsweep.sh); NHP_PAIRS_CFG = "G,U,BLOCK" overrides
-            int Gp = G == 8 ? 4 : G, Up = 1, Bp = 512;               // (with a round requested ahead, one child per group in flight: 24.6 us; two: 26.3)
+            int Gp = G >= 16 ? 8 : G == 8 ? 4 : G, Up = 1, Bp = 512;                // (with a round requested ahead, one child per group in flight: 24.6 us; two: 26.3)
             if (const char *cfg = getenv("NHP_PAIRS_CFG")) sscanf(cfg, "%d,%d,%d", &Gp, &Up, &Bp);
             bool ok = false;
 #define NHP_LCASE(g, u, b)                                                                                    \

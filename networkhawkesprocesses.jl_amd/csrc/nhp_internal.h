@@ -88,7 +88,7 @@ struct nhp_cont_dataset {
     // whose time goes into fetching ~8 scattered parent records per event: half the bytes per record.
     uint64_t *d_ev8 = nullptr;
     double ev8_t0 = 0.0, ev8_scale = 0.0;
-    // Short windows only (pairs <= 16 per event on average, finite dt_max): the parent-child pairs themselves, child by child
+    // Short windows only (pairs <= 40 per event on average, finite dt_max): the parent-child pairs themselves, child by child
     // in child_w order, most recent parent first -- node << 48 | Δt as a 48-bit fraction of dt_max, 8 bytes a pair.  The
     // exponential log-likelihood kernel then STREAMS its item's pairs (contiguous) instead of fetching ~8 scattered records per
     // child behind each child record.  d_poff: pair offsets by child_w position (host-made with the dataset);
