@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void k_pairs_build(nhp_cont_args a, uint64_t *
 // logarithm and division are data (nhp_pdf_logitnormal_cached), what is left per pair is one exponential.
 template <int IMP, int G, int U, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_windowed_pairs(nhp_cont_args a, int mask_integral, int max_item,
-                                                              double *__restrict__ partials,
+                                                              double *__restrict__ partials, double *__restrict__ lambda_out,
                                                               unsigned int *__restrict__ counter,
                                                               double *__restrict__ out)
 {
@@ -453,6 +453,7 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_pairs(nhp_cont_args a, int m
             const int kk = r0 + slot0 + u * GW;
             if (gl == 0 && kk < nchild) {
                 const double lam = (flat ? lam0 : baseline_at(a, c, a.child_w[it.kbeg + kk].t)) + s[u];
+                if (lambda_out) lambda_out[a.child_w[it.kbeg + kk].idx] = lam;          // (total_intensity, the gradient's 1/λ)
                 prod *= lam < 0.0 ? __builtin_nan("") : __builtin_amdgcn_frexp_mant(lam);
                 pexp += __builtin_amdgcn_frexp_exp(lam);
             }
@@ -1100,10 +1101,10 @@ static nhp_status run_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const n
     if (child_w) a.child_w = child_w;                     // same children, other window starts (recursive path)
     const int G = group ? group : ds->group;
     dim3 grid((unsigned)ds->n_items);
-    // the dataset's own short windows, no λ output: through the cached pair list (k_windowed_pairs)
+    // the dataset's own short windows: through the cached pair list (k_windowed_pairs)
     const bool plist_off = getenv("NHP_PLIST") && atoi(getenv("NHP_PLIST")) == 0;       // (read per call: the tests switch it)
     const bool expo_p = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
-    if (!d_lambda && !child_w && ds->d_poff && !plist_off && G <= 16 && (expo_p || nhp_ensure_pair_cache(ctx, ds, &a) == NHP_OK)) {
+    if (!child_w && ds->d_poff && !plist_off && G <= 16 && (expo_p || nhp_ensure_pair_cache(ctx, ds, &a) == NHP_OK)) {
         if (expo_p && !ds->d_plist) {                              // first use: build the list (data only)
             nhp_cont_dataset *mds = const_cast<nhp_cont_dataset *>(ds);
             if (hipMalloc((void **)&mds->d_plist, 8 * (size_t)std::max<int64_t>(ds->pairs, 1)) != hipSuccess) {
@@ -1129,12 +1130,12 @@ static nhp_status run_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const n
             if (lds2 > 64 * 1024)                                                                             \
                 (void)hipFuncSetAttribute((const void *)k_windowed_pairs<NHP_IMPULSE_EXPONENTIAL, g, u, b>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
             hipLaunchKernelGGL((k_windowed_pairs<NHP_IMPULSE_EXPONENTIAL, g, u, b>), grid, dim3(b), lds2, ctx->stream, a, mask_integral, ds->max_item, \
-                               ctx->d_partials, ctx->d_counter, d_out);                                       \
+                               ctx->d_partials, d_lambda, ctx->d_counter, d_out);                                       \
         } else {                                                                                              \
             if (lds2 > 64 * 1024)                                                                             \
                 (void)hipFuncSetAttribute((const void *)k_windowed_pairs<NHP_IMPULSE_LOGITNORMAL, g, u, b>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
             hipLaunchKernelGGL((k_windowed_pairs<NHP_IMPULSE_LOGITNORMAL, g, u, b>), grid, dim3(b), lds2, ctx->stream, a, mask_integral, ds->max_item, \
-                               ctx->d_partials, ctx->d_counter, d_out);                                       \
+                               ctx->d_partials, d_lambda, ctx->d_counter, d_out);                                       \
         }                                                                                                     \
     }
 #define NHP_LROW(g) NHP_LCASE(g, 1, 256) NHP_LCASE(g, 2, 256) NHP_LCASE(g, 4, 256) NHP_LCASE(g, 1, 512) NHP_LCASE(g, 2, 512) NHP_LCASE(g, 4, 512) \
