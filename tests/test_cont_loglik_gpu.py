@@ -359,3 +359,43 @@ def test_pair_list_and_packed_records_agree_with_the_exact_records(nhp, orc, net
     for cfg in ("2,2,256", "4,1,512", "8,2,1024"):
         monkeypatch.setenv("NHP_PAIRS_CFG", cfg)
         assert rel(nhp.loglikelihood(cl["proc"], (t, cl["nodes"], cl["T"]), recursive=False), wantl) < TOL, cfg
+
+
+def test_derived_layouts_agree_on_awkward_data(nhp, monkeypatch):
+    """The pair list and the 8-byte records are derived from the data once per dataset: time origins far from zero,
+    ties, a node without events, one node with all of them, tiny and huge Δtmax, N = 1 -- each evaluated through the pair
+    list, the 8-byte records and the exact 16-byte records (the three agree to 1e-12; the exact path is the one the oracle tests
+    pin), for exponential and logit-normal impulses."""
+    rng = np.random.default_rng(123)
+    cases = []
+    for (N, M, t_lo, t_hi, dtm) in ((5, 3000, 1e6, 1e6 + 400.0, 1.0), (7, 2500, 0.25, 350.0, 0.7), (1, 800, 0.0, 90.0, 0.5),
+                                    (9, 4000, 0.0, 2.0, 1e-3), (6, 1500, 10.0, 60.0, 3.0), (12, 5000, 0.0, 5e5, 400.0)):
+        t = np.sort(rng.uniform(t_lo, t_hi, M))
+        t[10:40:3] = t[11:41:3]                                     # ties
+        t = np.sort(t)
+        n = rng.integers(1, N + 1, M).astype(np.int64)
+        if N > 2:
+            n[n == 2] = 1                                           # node 2 has no events
+        cases.append((N, t, n, float(t_hi + 1.0), dtm))
+    for N, t, n, T, dtm in cases:
+        lam0 = rng.uniform(0.5, 1.5, N)
+        W = rng.uniform(0.0, 1.0, (N, N)) / max(N, 2) * 2.0
+        for kind in ("exponential", "logitnormal"):
+            if kind == "exponential":
+                imp = nhp.ExponentialImpulseResponse(rng.uniform(1.0, 5.0, (N, N)) / dtm, 1.0, 1.0, dtm)
+            else:
+                imp = nhp.LogitNormalImpulseResponse(rng.normal(0.0, 1.0, (N, N)), rng.uniform(0.5, 2.0, (N, N)), dtm)
+            proc = nhp.ContinuousStandardHawkesProcess(nhp.HomogeneousProcess(lam0), imp, nhp.DenseWeightModel(W))
+            got = {}
+            for name, env in (("pairs", {}), ("ev8", {"NHP_PLIST": "0"}), ("exact", {"NHP_PLIST": "0", "NHP_EV8": "0"})):
+                for k in ("NHP_PLIST", "NHP_EV8"):
+                    monkeypatch.delenv(k, raising=False)
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                nhp.invalidate_device_datasets()
+                got[name] = nhp.loglikelihood(proc, (t, n, T), recursive=False)
+            assert np.isfinite(got["exact"])
+            assert rel(got["pairs"], got["exact"]) < 1e-12, (N, kind, dtm, got)
+            assert rel(got["ev8"], got["exact"]) < 1e-12, (N, kind, dtm, got)
+    for k in ("NHP_PLIST", "NHP_EV8"):
+        monkeypatch.delenv(k, raising=False)
