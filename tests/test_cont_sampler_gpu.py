@@ -168,3 +168,36 @@ def test_both_sampler_kernels_give_the_oracle_indices(nhp, orc, which, kind, mon
         wp, wpn = orc.resample_parents(c["om"], c["times"], c["nodes"], u, flags=orc.MATH_DET)
         assert np.array_equal(p, wp) and np.array_equal(pn, wpn)
 
+
+
+def test_logitnormal_pair_cache_keeps_every_index(nhp, monkeypatch):
+    """The logit-normal sampler reads {logit(x), 1/(x(1-x))} made once per pair (k_plq_build) instead of taking the logarithm
+    and the division per weight: the same operations in the same order, so parents and statistics are identical with the cache
+    switched off (NHP_PLQ=0) -- ties, a far time origin, a network mask and a time-varying baseline in the data."""
+    for (N, M, t_lo, t_hi, dtm, net, lg, seed) in ((6, 4000, 5e5, 5e5 + 300.0, 1.0, True, False, 1), (9, 5000, 0.0, 40.0, 0.3, False, True, 2),
+                                                   (3, 2500, 0.0, 900.0, 2.5, True, True, 3)):
+        c = random_case(N, M, t_hi - t_lo, "logitnormal", dtm, network=net, lgcp=lg, seed=seed, nhp=nhp)
+        t = np.sort(c["times"] + t_lo)
+        t[100:160:3] = t[101:161:3]
+        t = np.sort(t)
+        if lg:                                                       # the baseline grid of random_case spans [0, T]
+            t = t - t_lo
+        data = (t, c["nodes"], float(t[-1] + 1.0))
+        u = np.random.default_rng(seed).uniform(size=M)
+        out = {}
+        for name, off in (("cache", None), ("plain", "0")):
+            if off is None:
+                monkeypatch.delenv("NHP_PLQ", raising=False)
+            else:
+                monkeypatch.setenv("NHP_PLQ", off)
+            nhp.invalidate_device_datasets()
+            p, pn, st = nhp.resample_parents(c["proc"], data, u=u, with_stats=True)
+            out[name] = (p, pn, st)
+        a, b = out["cache"], out["plain"]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        for k in ("cnt0", "Mn", "Mnm"):
+            assert np.array_equal(a[2][k], b[2][k])
+        assert np.array_equal(np.isnan(a[2]["Xnm"]), np.isnan(b[2]["Xnm"]))
+        m = ~np.isnan(a[2]["Xnm"])
+        assert np.array_equal(a[2]["Xnm"][m], b[2]["Xnm"][m])
+    monkeypatch.delenv("NHP_PLQ", raising=False)
