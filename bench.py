@@ -598,7 +598,10 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"continuous exponential standard Hawkes, N={r['N']}, M={r['M']}, "
                                    f"dt_max=1, {args.workload} (S-metric, SURVEY 8d)",
-                       "pairs_per_eval": r["pairs"], "independent_streams": world},
+                       "pairs_per_eval": r["pairs"], "independent_streams": world,
+                       "data_layout": "per dataset, made once from the events (data only, no parameter in it): children bucketed by node, "
+                                      "parent-child pairs as a list of node | delay; every evaluation computes every pair term "
+                                      "from the parameters it is given (see parameters_changing_every_evaluation)"},
             "roofline": {"bound": "hbm", "achieved": B / (ms_kernel * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": B / (ms_kernel * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": measured_traffic(args.workload)[0], "traffic_measured_at_commit": measured_traffic(args.workload)[1],
