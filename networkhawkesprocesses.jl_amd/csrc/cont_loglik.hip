@@ -774,7 +774,7 @@ __global__ __launch_bounds__(THREADS) void k_windowed_batch(nhp_cont_args a, nhp
 #pragma unroll
             for (int q = 0; q < S; ++q) {
                 if (IMP == NHP_IMPULSE_EXPONENTIAL) {
-                    col[(size_t)q * NP + p] = make_double2(a1[q], w[q]);
+                    col[(size_t)q * NP + p] = make_double2(a1[q], w[q] * a1[q]);     // {θ, a·w·θ}: the term is y·exp(-x·Δt)
                 } else {
                     col[(size_t)q * NP + p] = make_double2(a1[q], __builtin_sqrt(a2[q]));
                     colw[(size_t)q * NP + p] = w[q];
@@ -853,6 +853,7 @@ __global__ __launch_bounds__(THREADS) void k_windowed_batch(nhp_cont_args a, nhp
             e = x.e;
         }
         if (c0 + m >= ch.idx - ch.first) { e.t = ch.t; e.node = N; }
+        e.t = ch.t - e.t;                                           // parked as the DELAY: one subtraction per record, not per (record, set)
         return e;
     };
     // Two dependent global round trips lead into a round (child record, then its parents) and a round is only a few
@@ -898,12 +899,12 @@ __global__ __launch_bounds__(THREADS) void k_windowed_batch(nhp_cont_args a, nhp
                 for (int r = 0; r < S; r += 2) {
                     if (r < nrec && !NHP_SKIP(a, 8)) {
                         const nhp_event e0 = myrow[r], e1 = myrow[r + 1];
-                        const double d0 = ch0.t - e0.t, d1 = ch0.t - e1.t;
+                        const double d0 = e0.t, d1 = e1.t;
                         const double2 q0 = mycol[e0.node], q1 = mycol[e1.node];
                         double t0, t1;
                         if (IMP == NHP_IMPULSE_EXPONENTIAL) {
-                            t0 = q0.y * nhp_pdf_exponential_tab(q0.x, d0, etab);
-                            t1 = q1.y * nhp_pdf_exponential_tab(q1.x, d1, etab);
+                            t0 = q0.y * nhp_exp_neg_tab(-(q0.x * d0), etab);
+                            t1 = q1.y * nhp_exp_neg_tab(-(q1.x * d1), etab);
                         } else {
                             t0 = mycolw[e0.node] * nhp_pdf_logitnormal(q0.x, q0.y, a.inv_dtmax, d0);
                             t1 = mycolw[e1.node] * nhp_pdf_logitnormal(q1.x, q1.y, a.inv_dtmax, d1);
