@@ -774,7 +774,7 @@ __global__ __launch_bounds__(THREADS) void k_windowed_batch(nhp_cont_args a, nhp
 #pragma unroll
             for (int q = 0; q < S; ++q) {
                 if (IMP == NHP_IMPULSE_EXPONENTIAL) {
-                    col[(size_t)q * NP + p] = make_double2(a1[q], w[q] * a1[q]);     // {θ, a·w·θ}: the term is y·exp(-x·Δt)
+                    col[(size_t)q * NP + p] = make_double2(a1[q] * -92.33248261689366, w[q] * a1[q]);     // {-θ·64/ln2, a·w·θ}: the term is y·exp2((x·Δt)/64)
                 } else {
                     col[(size_t)q * NP + p] = make_double2(a1[q], __builtin_sqrt(a2[q]));
                     colw[(size_t)q * NP + p] = w[q];
@@ -903,8 +903,8 @@ __global__ __launch_bounds__(THREADS) void k_windowed_batch(nhp_cont_args a, nhp
                         const double2 q0 = mycol[e0.node], q1 = mycol[e1.node];
                         double t0, t1;
                         if (IMP == NHP_IMPULSE_EXPONENTIAL) {
-                            t0 = q0.y * nhp_exp_neg_tab(-(q0.x * d0), etab);
-                            t1 = q1.y * nhp_exp_neg_tab(-(q1.x * d1), etab);
+                            t0 = q0.y * nhp_exp_neg_tab_scaled(q0.x * d0, etab);
+                            t1 = q1.y * nhp_exp_neg_tab_scaled(q1.x * d1, etab);
                         } else {
                             t0 = mycolw[e0.node] * nhp_pdf_logitnormal(q0.x, q0.y, a.inv_dtmax, d0);
                             t1 = mycolw[e1.node] * nhp_pdf_logitnormal(q1.x, q1.y, a.inv_dtmax, d1);

@@ -153,6 +153,29 @@ __device__ __forceinline__ double nhp_exp_neg_tab(double x, const double *tab)
     return __builtin_ldexp(__builtin_fma(t, p, t), k >> 6);
 }
 
+// The same with the argument already multiplied by 64/ln 2 (the caller folds the factor into its rate table): t = x·64/ln2,
+// r = (t - k)·ln2/64 -- one multiplication fewer; the reduced argument loses |t|·2^-53·ln2/64 absolute (3e-15 at x = -30,
+// 8e-14 at x = -700, where the term is 1e-304): used by the batch kernel, held to the oracle at 1e-11 like the rest.
+__device__ __forceinline__ double nhp_exp_neg_tab_scaled(double t, const double *tab)
+{
+#pragma clang fp contract(off)
+    const double L64 = 1.0830424696249145e-02;            // ln 2 / 64
+    const double kf = __builtin_rint(t);
+    const double r = (t - kf) * L64;
+    const int k = (int)kf;
+    const double tb = tab[k & 63];
+    double p;
+    const double c5 = 8.3333333333333332e-03;
+    asm("v_fma_f64 %0, %1, %2, %3\n\t"
+        "v_fma_f64 %0, %0, %2, %4\n\t"
+        "v_fma_f64 %0, %0, %2, 0.5\n\t"
+        "v_fma_f64 %0, %0, %2, 1.0\n\t"
+        "v_mul_f64 %0, %0, %2"
+        : "=&v"(p)
+        : "v"(c5), "v"(r), "s"(4.1666666666666664e-02), "s"(1.6666666666666666e-01));
+    return __builtin_ldexp(__builtin_fma(tb, p, tb), k >> 6);
+}
+
 __device__ __forceinline__ double nhp_pdf_exponential_tab(double r, double dt, const double *tab)
 {
 #pragma clang fp contract(off)
