@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
     // load or a fragment read after each MFMA.  One wave then keeps the matrix pipe busy through its own LDS/global traffic
     // (each of those issues in a few cycles under a 64-cycle MFMA); clustered, they cost the pipe ~3000 idle cycles per
     // 5120-cycle tile whenever the other workgroup's wave on the SIMD was not there to cover them.
+    frag fw0;                                                      // slab 0 of the tile about to run (tile_whole)
     auto tile_whole = [&](const int k0, const int cur) {
         const double *Ac = gsm + cur * STAGE, *Bc = Ac + SA;
         double *An = gsm + (cur ^ 1) * STAGE, *Bn = An + SA;
@@ -248,35 +249,50 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
                 f.b[n - MI] = Bc[nn * KC_LD + ks * 4 + kk];
             }
         };
-        frag f0, f1;
-        read_slab(Ac, Bc, 0, f0);                                  // (the one exposed LDS latency of the tile)
-        read_slab(Ac, Bc, 1, f1);
-        __builtin_amdgcn_sched_barrier(0);
+        auto rdn = [&](const int n, frag &f) {                     // n-th fragment read of k-slab 0 of the NEXT tile (the other stage)
+            if (n < MI) {
+                const int m = wm * (TBM / 2) + n * 16 + r16;
+                f.a[n] = A_MCONTIG ? An[kk * A_LD + m] : An[m * KC_LD + kk];
+            } else {
+                const int nn = wn * 64 + (n - MI) * 16 + r16;
+                f.b[n - MI] = Bn[nn * KC_LD + kk];
+            }
+        };
+        // fw0 holds this tile's slab 0 (read under the previous tile's last slab); the barrier sits between slabs 2 and 3 --
+        // by then every fragment of this stage has been read and the other stage was written in slab 0 -- so that the next
+        // tile's first fragments travel under slab 3 and no tile starts by waiting for LDS
+        frag f1;
+        constexpr int L0 = NM - NW;                                // global loads placed in slab 0
 #pragma unroll
-        for (int n = 0; n < NM; ++n) {                             // slab 0: the writes, then loads
-            acc[n / 4][n % 4] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0.a[n / 4], f0.b[n % 4], acc[n / 4][n % 4], 0, 0, 0);
+        for (int n = 0; n < NM; ++n) {                             // slab 0: slab 1's fragments and the writes, then loads
+            acc[n / 4][n % 4] = __builtin_amdgcn_mfma_f64_16x16x4f64(fw0.a[n / 4], fw0.b[n % 4], acc[n / 4][n % 4], 0, 0, 0);
+            if (n < NR) rd(1, n, f1);
             if (n < NW) wr(n);
             else if (n - NW < NL) ld(n - NW);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int n = 0; n < NM; ++n) {                             // slab 1: the rest of the loads, then slab 2's fragments
-            constexpr int done = NM - NW;
             acc[n / 4][n % 4] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1.a[n / 4], f1.b[n % 4], acc[n / 4][n % 4], 0, 0, 0);
-            if (done + n < NL) ld(done + n);
-            else if (done + n - NL < NR) rd(2, done + n - NL, f0);
+            if (L0 + n < NL) ld(L0 + n);
+            else if (L0 + n - NL < NR) rd(2, L0 + n - NL, fw0);
             __builtin_amdgcn_sched_barrier(0);
         }
         pa = more ? pa + a_step : pa;
         pb = more ? pb + BK : pb;
 #pragma unroll
         for (int n = 0; n < NM; ++n) {                             // slab 2: slab 3's fragments
-            acc[n / 4][n % 4] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0.a[n / 4], f0.b[n % 4], acc[n / 4][n % 4], 0, 0, 0);
+            acc[n / 4][n % 4] = __builtin_amdgcn_mfma_f64_16x16x4f64(fw0.a[n / 4], fw0.b[n % 4], acc[n / 4][n % 4], 0, 0, 0);
             if (n < NR) rd(3, n, f1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        mfma_slab(f1);
-        __syncthreads();                       // stage cur^1 written by all, stage cur read by all
+        __syncthreads();                       // stage cur^1 written by all (slab 0), stage cur read by all (its last reads: slab 2)
+#pragma unroll
+        for (int n = 0; n < NM; ++n) {                             // slab 3: the next tile's slab 0, from the other stage
+            acc[n / 4][n % 4] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1.a[n / 4], f1.b[n % 4], acc[n / 4][n % 4], 0, 0, 0);
+            if (n < NR) rdn(n, fw0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
     load_tiles(kbeg);
@@ -284,10 +300,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(gemm_args g)      // 2 wave
     __syncthreads();
     if (kbeg + BK < kend) load_tiles(kbeg + BK);
     if (WHOLE) {
+        read_slab(gsm, gsm + SA, 0, fw0);
         for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
             tile_whole(k0, 0);
             if (k0 + BK < kend) tile_whole(k0 + BK, 1);
         }
+        __syncthreads();                       // (the epilogue's arrays reuse stage 0: the last tile's slab-3 reads are behind us)
     } else {
         for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
             tile(k0, 0);
