@@ -186,6 +186,142 @@ __global__ __launch_bounds__(BLOCK) void k_recursive(nhp_cont_args a, double *__
     }
 }
 
+// ---- the recursion without a per-child barrier: one WAVE per (column, part of the parent nodes) ---------------------
+// k_recursive above folds a segment with the whole workgroup (rounds of FU·BLOCK events whatever the segment's length:
+// with ~N events between two children of a column and rounds of 1024, 1.58 rounds are evaluated for every one needed)
+// and then meets at a barrier before the decay: its waves wait 58 % of their time (profiles/README.md).  Here the parent
+// nodes are cut into H parts of NP = 64·PQ nodes and wave h of workgroup c owns S_{p,c} for the parents of part h ONLY:
+// it folds the events that fell on ITS parents (a per-part, time-ordered event list made once per dataset: data only)
+// in rounds of 64 and decays ITS states -- no other wave ever touches its accumulators, so the LDS atomics of a segment and
+// the reads of the decay are ordered by the wave's own instruction stream and the child loop has no barrier at all.  The
+// H partial intensities of a child meet in a ring (one barrier per NHP_RING children, as above).  Exponentials through
+// the 2^(j/64) table with -θ·64/ln 2 held per parent (nhp_exp_neg_tab_scaled).
+struct nhp_rec_parts {          // kernel-side view of the per-part lists (nhp_cont_dataset::d_rec_*)
+    const nhp_event *ev;        // [Σ part lengths + 128] events with t > 0 (D9), part by part, time order inside; node = index inside the part
+    const int32_t *poff;        // [H + 1] first record of each part
+    const int32_t *rank;        // [H][M] by bucket position k: events of the part with time index < idx_k
+};
+
+template <int PQ, int H>
+__global__ __launch_bounds__(64 * H) void k_recursive_waves(nhp_cont_args a, nhp_rec_parts rp, double *__restrict__ partials)
+{
+    constexpr int NP = 64 * PQ;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *red = reinterpret_cast<double *>(smem);              // [16]
+    double *tab = red + 16;                                      // [64] 2^(j/64)
+    double *ring = tab + 64;                                     // [2][NHP_RING][H]
+    const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+    double *th = ring + 2 * NHP_RING * H + (size_t)h * 2 * NP;   // [NP] -θ[p,c]·64/ln2 of this wave's parents
+    double *acc = th + NP;                                       // [NP] segment accumulator (this wave's alone)
+    const int c = a.col_begin + blockIdx.x, N = a.N;
+    const double K64 = 92.33248261689366;                        // 64 / ln 2
+
+    nhp_exp_tab_init(tab);
+    double S[PQ], thr[PQ], wthr[PQ];
+    double integ = 0.0;
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) {
+        const int pl = lane + 64 * q, p = h * NP + pl;
+        S[q] = 0.0; thr[q] = 0.0; wthr[q] = 0.0;
+        if (p < N) {
+            const size_t k = (size_t)p + (size_t)c * N;
+            const double w = a.W[k];
+            const double weff = a.A ? a.A[k] * w : w;
+            const double t = a.p1[k];
+            thr[q] = -(t * K64); wthr[q] = weff * t;
+            integ += a.cnt[p] * w;                               // unmasked: src/continuous.jl:247,413
+        }
+        th[pl] = thr[q];
+        acc[pl] = 0.0;
+    }
+    __syncthreads();                                             // the table (the only LDS shared between the waves besides the ring)
+
+    const nhp_event *ev = rp.ev + rp.poff[h];
+    const int32_t *rk = rp.rank + (size_t)h * (size_t)a.M;
+    const int kb = a.boff[c], ke = a.boff[c + 1];
+    double logsum = 0.0;
+
+    // fold records [j, je) (j = first + lane; `e` = record j, already requested) into acc, referenced to time tk.  The list
+    // carries 128 records of padding, so a lane past the end reads a harmless record and only skips the atomic.
+    auto fold = [&](nhp_event e, int j, int je, double tk) {
+        for (int r = j - lane; r < je; r += 64) {
+            const nhp_event en = ev[j + 64];
+            asm volatile("" ::: "memory");                       // keeps the request ahead of the math
+            const double v = nhp_exp_neg_tab_scaled(th[e.node] * (tk - e.t), tab);
+            if (j < je) atomicAdd(&acc[e.node], v);
+            e = en; j += 64;
+        }
+    };
+
+    double ch_t = 0.0, nx_t = 0.0;
+    int ch_r = 0, nx_r = 0;
+    if (kb < ke) { ch_t = a.child[kb].t; ch_r = rk[kb]; nx_t = ch_t; nx_r = ch_r; }
+    if (kb + 1 < ke) { nx_t = a.child[kb + 1].t; nx_r = rk[kb + 1]; }
+    if (kb < ke) fold(ev[lane], lane, ch_r, ch_t);
+    double prev_t = ch_t;
+    double pending = 0.0;
+    for (int k = kb; k < ke; ++k) {
+        const int kn = k + 2 < ke ? k + 2 : ke - 1;
+        const double nn_t = a.child[kn].t;
+        const int nn_r = rk[kn];
+        const bool more = k + 1 < ke;
+        const int fj = ch_r + lane, fe = more ? nx_r : ch_r;
+        const nhp_event pe = ev[fj];                             // first round of the next segment, requested before the decay
+        NHP_LDS_SYNC();                                          // this wave's atomics of segment k have landed
+        const double gap = ch_t - prev_t;
+        double part = 0.0;
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+            const int pl = lane + 64 * q;
+            double s = S[q] * nhp_exp_neg_tab_scaled(thr[q] * gap, tab);
+            s += acc[pl];
+            acc[pl] = 0.0;
+            S[q] = s;
+            part += wthr[q] * s;
+        }
+        if (k > kb) {                                            // child k-1's reduction, under the decay's arithmetic
+            const double r = nhp_wave_sum(pending);
+            const int o = k - 1 - kb;
+            if (lane == 0) ring[(((o / NHP_RING) & 1) * NHP_RING + (o & (NHP_RING - 1))) * H + h] = r;
+        }
+        pending = part;
+        fold(pe, fj, fe, nx_t);
+        const int done = k - kb;
+        if (done > 0 && (done & (NHP_RING - 1)) == 0) {          // a full half of the ring: the only barrier of the loop
+            __syncthreads();
+            const int half = ((done - 1) / NHP_RING) & 1;
+            if (tid < NHP_RING) {
+                const double tk = a.child[k - NHP_RING + tid].t;
+                double lam = rec_baseline(a, c, tk);
+                for (int w = 0; w < H; ++w) lam += ring[(half * NHP_RING + tid) * H + w];
+                logsum += nhp_log(lam);
+            }
+        }
+        prev_t = ch_t;
+        ch_t = nx_t; ch_r = nx_r;
+        nx_t = nn_t; nx_r = nn_r;
+    }
+    if (kb < ke) {
+        const int o = ke - 1 - kb;
+        const double r = nhp_wave_sum(pending);
+        if (lane == 0) ring[(((o / NHP_RING) & 1) * NHP_RING + (o & (NHP_RING - 1))) * H + h] = r;
+        __syncthreads();
+        const int slot = o & (NHP_RING - 1), half = (o / NHP_RING) & 1;
+        if (tid <= slot && tid < NHP_RING) {
+            const double tk = a.child[ke - 1 - slot + tid].t;
+            double lam = rec_baseline(a, c, tk);
+            for (int w = 0; w < H; ++w) lam += ring[(half * NHP_RING + tid) * H + w];
+            logsum += nhp_log(lam);
+        }
+    }
+    const double blk = nhp_block_sum_n<H>(logsum, red);
+    const double blk_int = nhp_block_sum_n<H>(integ, red);
+    if (tid == 0) {
+        partials[2 * (size_t)blockIdx.x] = blk;
+        partials[2 * (size_t)blockIdx.x + 1] = blk_int;
+    }
+}
+
 // ---- the same sum through a truncated window ------------------------------------------------------------
 // The recursion adds, for child i, EVERY earlier event j with weight (a·w·θ)·e^{-θ(t_i - t_j)}.  Events older than
 //     cut = ln( M · max(w·θ) / (min λ0 · 2^-60) ) / min θ
@@ -355,6 +491,49 @@ nhp_status nhp_launch_recursive_flags(nhp_ctx *ctx, const nhp_cont_dataset *ds, 
     return nhp_launch_recursive_full(ctx, ds, m, d_out);
 }
 
+// the per-part event lists of k_recursive_waves for parts of `np` nodes (data only; cached in the dataset)
+static nhp_status rec_parts_for(nhp_ctx *ctx, const nhp_cont_dataset *ds, int np, int H)
+{
+    if (ds->d_rec_ev && ds->rec_np == np && ds->rec_h == H) return NHP_OK;
+    nhp_cont_dataset *mds = const_cast<nhp_cont_dataset *>(ds);
+    const size_t M = (size_t)ds->M;
+    std::vector<double> t(M ? M : 1);
+    std::vector<int32_t> node(M ? M : 1);
+    NHP_HIP(ctx, hipMemcpyAsync(t.data(), ds->d_times, sizeof(double) * M, hipMemcpyDeviceToHost, ctx->stream));
+    NHP_HIP(ctx, hipMemcpyAsync(node.data(), ds->d_nodes, sizeof(int32_t) * M, hipMemcpyDeviceToHost, ctx->stream));
+    NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int32_t> poff((size_t)H + 1, 0), seen((size_t)H, 0), rank((size_t)H * (M ? M : 1));
+    for (size_t i = 0; i < M; ++i)
+        if (t[i] > 0.0) poff[(size_t)(node[i] / np) + 1]++;
+    for (int h = 0; h < H; ++h) poff[(size_t)h + 1] += poff[(size_t)h];
+    std::vector<nhp_event> ev((size_t)poff[(size_t)H] + 128);
+    for (nhp_event &e : ev) { e.t = 0.0; e.node = 0; e.pad = 0; }
+    std::vector<int32_t> cur(ds->h_boff.begin(), ds->h_boff.end() - 1);       // bucket position of the next child of each node
+    for (size_t i = 0; i < M; ++i) {
+        const size_t k = (size_t)cur[(size_t)node[i]]++;
+        for (int h = 0; h < H; ++h) rank[(size_t)h * M + k] = seen[(size_t)h];
+        if (t[i] > 0.0) {
+            const int h = node[i] / np;
+            nhp_event &e = ev[(size_t)poff[(size_t)h] + (size_t)seen[(size_t)h]++];
+            e.t = t[i]; e.node = node[i] - h * np;
+        }
+    }
+    (void)hipFree(mds->d_rec_ev); (void)hipFree(mds->d_rec_poff); (void)hipFree(mds->d_rec_rank);
+    mds->d_rec_ev = nullptr; mds->d_rec_poff = nullptr; mds->d_rec_rank = nullptr; mds->rec_np = 0; mds->rec_h = 0;
+    if (hipMalloc((void **)&mds->d_rec_ev, sizeof(nhp_event) * ev.size()) != hipSuccess ||
+        hipMalloc((void **)&mds->d_rec_poff, sizeof(int32_t) * poff.size()) != hipSuccess ||
+        hipMalloc((void **)&mds->d_rec_rank, sizeof(int32_t) * rank.size()) != hipSuccess) {
+        nhp_set_error(ctx, "out of device memory (recursion: per-part event lists)");
+        return NHP_ENOMEM;
+    }
+    NHP_HIP(ctx, hipMemcpyAsync(mds->d_rec_ev, ev.data(), sizeof(nhp_event) * ev.size(), hipMemcpyHostToDevice, ctx->stream));
+    NHP_HIP(ctx, hipMemcpyAsync(mds->d_rec_poff, poff.data(), sizeof(int32_t) * poff.size(), hipMemcpyHostToDevice, ctx->stream));
+    NHP_HIP(ctx, hipMemcpyAsync(mds->d_rec_rank, rank.data(), sizeof(int32_t) * rank.size(), hipMemcpyHostToDevice, ctx->stream));
+    NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));          // the host vectors go out of scope
+    mds->rec_np = np; mds->rec_h = H;
+    return NHP_OK;
+}
+
 static nhp_status nhp_launch_recursive_full(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_out)
 {
     if (m->impulse_kind != NHP_IMPULSE_EXPONENTIAL) return NHP_EINVAL;
@@ -362,6 +541,37 @@ static nhp_status nhp_launch_recursive_full(nhp_ctx *ctx, const nhp_cont_dataset
     if (ds->N > 4096) { nhp_set_error(ctx, "recursive ll: n_nodes = %d > 4096 not supported", ds->N); return NHP_ENOTIMPL; }
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)ds->N));
     nhp_cont_args a = nhp_make_args(ds, m);
+    // 1: one wave per (column, part of the parents), no barrier in the child loop (k_recursive_waves); 0: the workgroup-wide
+    // fold + barrier per child (k_recursive).  NHP_REC_PARTS = "PQ,H" forces a shape of the first (tools/kbench.py).
+    static const int waves = getenv("NHP_REC_WAVES") ? atoi(getenv("NHP_REC_WAVES")) : 1;
+    if (waves) {
+        int PQ = ds->N <= 256 ? 1 : (ds->N <= 512 ? 2 : 4);
+        int H = 1;
+        if (const char *env = getenv("NHP_REC_PARTS")) { int q = 0, hh = 0; if (sscanf(env, "%d,%d", &q, &hh) == 2 && 64 * q * hh >= ds->N) { PQ = q; H = hh; } }
+        while (64 * PQ * H < ds->N) H *= 2;
+        NHP_TRY(rec_parts_for(ctx, ds, 64 * PQ, H));
+        const nhp_rec_parts rp{ds->d_rec_ev, ds->d_rec_poff, ds->d_rec_rank};
+        const size_t lds = sizeof(double) * (16 + 64 + 2 * NHP_RING * (size_t)H + (size_t)H * 2 * 64 * PQ);
+        bool launched = true;
+#define NHP_RECW(Q, HH)                                                                                                          \
+        hipLaunchKernelGGL((k_recursive_waves<Q, HH>), dim3((unsigned)(ds->col_end - ds->col_begin)), dim3(64 * HH), lds, ctx->stream, a, rp, \
+                           ctx->d_partials)
+        if (PQ == 1 && H == 1) NHP_RECW(1, 1);
+        else if (PQ == 1 && H == 2) NHP_RECW(1, 2);
+        else if (PQ == 1 && H == 4) NHP_RECW(1, 4);
+        else if (PQ == 2 && H == 4) NHP_RECW(2, 4);
+        else if (PQ == 2 && H == 8) NHP_RECW(2, 8);
+        else if (PQ == 1 && H == 16) NHP_RECW(1, 16);
+        else if (PQ == 4 && H == 4) NHP_RECW(4, 4);
+        else if (PQ == 4 && H == 8) NHP_RECW(4, 8);
+        else if (PQ == 4 && H == 16) NHP_RECW(4, 16);
+        else launched = false;
+#undef NHP_RECW
+        if (launched) {
+            NHP_HIP(ctx, hipGetLastError());
+            return nhp_launch_finalize(ctx, a, ds->col_end - ds->col_begin, d_out);
+        }
+    }
 #define NHP_REC_LAUNCH(B, Q)                                                                                   \
     do {                                                                                                       \
         const size_t lds = sizeof(double) * (8 + 2 * NHP_RING * ((B) / 64) + 3 * (size_t)(B) * (Q));          \
