@@ -197,10 +197,24 @@ __global__ __launch_bounds__(BLOCK) void k_recursive(nhp_cont_args a, double *__
 // H partial intensities of a child meet in a ring (one barrier per NHP_RING children, as above).  Exponentials through
 // the 2^(j/64) table with -θ·64/ln 2 held per parent (nhp_exp_neg_tab_scaled).
 struct nhp_rec_parts {          // kernel-side view of the per-part lists (nhp_cont_dataset::d_rec_*)
-    const nhp_event *ev;        // [Σ part lengths + 128] events with t > 0 (D9), part by part, time order inside; node = index inside the part
+    const nhp_event *ev;        // [Σ part lengths + 192] events with t > 0 (D9), part by part, time order inside; node = index inside the part
     const int32_t *poff;        // [H + 1] first record of each part
     const int32_t *rank;        // [H][M] by bucket position k: events of the part with time index < idx_k
 };
+
+// Ordering of one wave's own LDS traffic without draining it: the LDS unit executes a wave's instructions in issue order (an
+// atomic of lane A is seen by a later read of lane B of the same wave), so only the compiler must be kept from reordering.
+#define NHP_LDS_ORDER()                                         \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+    } while (0)
+#ifndef NHP_RECW_SYNC
+#define NHP_RECW_SYNC() NHP_LDS_ORDER()
+#endif
+#define NHP_RECW_TS 66          // row stride of the reduction tile (doubles): 64 lanes + 2 of padding
+#define NHP_RECW_LDS(PQ, H) (sizeof(double) * (16 + 64 + 2 * NHP_RING * (size_t)(H) + (size_t)(H) * (2 * 64 * (PQ) + 8 * NHP_RECW_TS)))
 
 template <int PQ, int H>
 __global__ __launch_bounds__(64 * H) void k_recursive_waves(nhp_cont_args a, nhp_rec_parts rp, double *__restrict__ partials)
@@ -211,8 +225,9 @@ __global__ __launch_bounds__(64 * H) void k_recursive_waves(nhp_cont_args a, nhp
     double *tab = red + 16;                                      // [64] 2^(j/64)
     double *ring = tab + 64;                                     // [2][NHP_RING][H]
     const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
-    double *th = ring + 2 * NHP_RING * H + (size_t)h * 2 * NP;   // [NP] -θ[p,c]·64/ln2 of this wave's parents
+    double *th = ring + 2 * NHP_RING * H + (size_t)h * (2 * NP + 8 * NHP_RECW_TS);   // [NP] -θ[p,c]·64/ln2 of this wave's parents
     double *acc = th + NP;                                       // [NP] segment accumulator (this wave's alone)
+    double *tile = acc + NP;                                     // [8][TS] lane partials of 8 children, summed 8 at a time
     const int c = a.col_begin + blockIdx.x, N = a.N;
     const double K64 = 92.33248261689366;                        // 64 / ln 2
 
@@ -241,15 +256,27 @@ __global__ __launch_bounds__(64 * H) void k_recursive_waves(nhp_cont_args a, nhp
     const int kb = a.boff[c], ke = a.boff[c + 1];
     double logsum = 0.0;
 
-    // fold records [j, je) (j = first + lane; `e` = record j, already requested) into acc, referenced to time tk.  The list
-    // carries 128 records of padding, so a lane past the end reads a harmless record and only skips the atomic.
+    // fold records [j, je) (j = first + lane; `e` = record j, already requested) into acc, referenced to time tk: rounds of
+    // 64, the next round's record requested before this round's arithmetic (two rounds per trip, so the request lands in
+    // the register the next round reads).  The list carries 192 records of padding: a lane past the end reads a harmless
+    // record and only skips the atomic.  (θ gathered from the parameter column in memory instead of LDS, to unload the LDS
+    // unit: 2.08 -> 2.61 ms -- a 64-lane random gather costs the texture path more than the LDS read it replaces.)
+    auto term = [&](const nhp_event &e, bool live, double tk) {
+        const double v = nhp_exp_neg_tab_scaled(th[e.node] * (tk - e.t), tab);
+        if (live) atomicAdd(&acc[e.node], v);
+    };
     auto fold = [&](nhp_event e, int j, int je, double tk) {
-        for (int r = j - lane; r < je; r += 64) {
+        int r = j - lane;
+        while (r < je) {
             const nhp_event en = ev[j + 64];
             asm volatile("" ::: "memory");                       // keeps the request ahead of the math
-            const double v = nhp_exp_neg_tab_scaled(th[e.node] * (tk - e.t), tab);
-            if (j < je) atomicAdd(&acc[e.node], v);
-            e = en; j += 64;
+            term(e, j < je, tk);
+            r += 64;
+            if (r >= je) break;
+            e = ev[j + 128];
+            asm volatile("" ::: "memory");
+            term(en, j + 64 < je, tk);
+            r += 64; j += 128;
         }
     };
 
@@ -259,7 +286,6 @@ __global__ __launch_bounds__(64 * H) void k_recursive_waves(nhp_cont_args a, nhp
     if (kb + 1 < ke) { nx_t = a.child[kb + 1].t; nx_r = rk[kb + 1]; }
     if (kb < ke) fold(ev[lane], lane, ch_r, ch_t);
     double prev_t = ch_t;
-    double pending = 0.0;
     for (int k = kb; k < ke; ++k) {
         const int kn = k + 2 < ke ? k + 2 : ke - 1;
         const double nn_t = a.child[kn].t;
@@ -267,7 +293,7 @@ __global__ __launch_bounds__(64 * H) void k_recursive_waves(nhp_cont_args a, nhp
         const bool more = k + 1 < ke;
         const int fj = ch_r + lane, fe = more ? nx_r : ch_r;
         const nhp_event pe = ev[fj];                             // first round of the next segment, requested before the decay
-        NHP_LDS_SYNC();                                          // this wave's atomics of segment k have landed
+        NHP_RECW_SYNC();                                          // this wave's atomics of segment k have landed
         const double gap = ch_t - prev_t;
         double part = 0.0;
 #pragma unroll
@@ -279,19 +305,28 @@ __global__ __launch_bounds__(64 * H) void k_recursive_waves(nhp_cont_args a, nhp
             S[q] = s;
             part += wthr[q] * s;
         }
-        if (k > kb) {                                            // child k-1's reduction, under the decay's arithmetic
-            const double r = nhp_wave_sum(pending);
-            const int o = k - 1 - kb;
-            if (lane == 0) ring[(((o / NHP_RING) & 1) * NHP_RING + (o & (NHP_RING - 1))) * H + h] = r;
+        // Σ over the lanes, 8 children at a time: every lane parks its partial (one LDS write per child); after the
+        // eighth, lane (child, eighth) adds 8 parked values and three DPP steps finish the sum inside its group of 8 lanes
+        const int o = k - kb;
+        tile[(o & 7) * NHP_RECW_TS + lane] = part;
+        if ((o & 7) == 7 || !more) {
+            NHP_RECW_SYNC();
+            const int chl = lane >> 3, sg = lane & 7;
+            const double *row = tile + chl * NHP_RECW_TS + 8 * sg;
+            double s = ((row[0] + row[1]) + (row[2] + row[3])) + ((row[4] + row[5]) + (row[6] + row[7]));
+            s = nhp_dpp_add(s, 0);
+            s = nhp_dpp_add(s, 1);
+            s = nhp_dpp_add(s, 2);
+            const int oc = (o & ~7) + chl;
+            if (sg == 0 && chl <= (o & 7)) ring[(((oc / NHP_RING) & 1) * NHP_RING + (oc & (NHP_RING - 1))) * H + h] = s;
         }
-        pending = part;
         fold(pe, fj, fe, nx_t);
-        const int done = k - kb;
-        if (done > 0 && (done & (NHP_RING - 1)) == 0) {          // a full half of the ring: the only barrier of the loop
+        const int done = o + 1;                                  // children whose partials are in the ring or the tile
+        if ((done & (NHP_RING - 1)) == 0 || !more) {             // a full half of the ring (or the rest): the only barrier of the loop
             __syncthreads();
-            const int half = ((done - 1) / NHP_RING) & 1;
-            if (tid < NHP_RING) {
-                const double tk = a.child[k - NHP_RING + tid].t;
+            const int n = ((done - 1) & (NHP_RING - 1)) + 1, half = ((done - 1) / NHP_RING) & 1;
+            if (tid < n) {
+                const double tk = a.child[k + 1 - n + tid].t;
                 double lam = rec_baseline(a, c, tk);
                 for (int w = 0; w < H; ++w) lam += ring[(half * NHP_RING + tid) * H + w];
                 logsum += nhp_log(lam);
@@ -300,19 +335,6 @@ __global__ __launch_bounds__(64 * H) void k_recursive_waves(nhp_cont_args a, nhp
         prev_t = ch_t;
         ch_t = nx_t; ch_r = nx_r;
         nx_t = nn_t; nx_r = nn_r;
-    }
-    if (kb < ke) {
-        const int o = ke - 1 - kb;
-        const double r = nhp_wave_sum(pending);
-        if (lane == 0) ring[(((o / NHP_RING) & 1) * NHP_RING + (o & (NHP_RING - 1))) * H + h] = r;
-        __syncthreads();
-        const int slot = o & (NHP_RING - 1), half = (o / NHP_RING) & 1;
-        if (tid <= slot && tid < NHP_RING) {
-            const double tk = a.child[ke - 1 - slot + tid].t;
-            double lam = rec_baseline(a, c, tk);
-            for (int w = 0; w < H; ++w) lam += ring[(half * NHP_RING + tid) * H + w];
-            logsum += nhp_log(lam);
-        }
     }
     const double blk = nhp_block_sum_n<H>(logsum, red);
     const double blk_int = nhp_block_sum_n<H>(integ, red);
@@ -506,7 +528,7 @@ static nhp_status rec_parts_for(nhp_ctx *ctx, const nhp_cont_dataset *ds, int np
     for (size_t i = 0; i < M; ++i)
         if (t[i] > 0.0) poff[(size_t)(node[i] / np) + 1]++;
     for (int h = 0; h < H; ++h) poff[(size_t)h + 1] += poff[(size_t)h];
-    std::vector<nhp_event> ev((size_t)poff[(size_t)H] + 128);
+    std::vector<nhp_event> ev((size_t)poff[(size_t)H] + 192);
     for (nhp_event &e : ev) { e.t = 0.0; e.node = 0; e.pad = 0; }
     std::vector<int32_t> cur(ds->h_boff.begin(), ds->h_boff.end() - 1);       // bucket position of the next child of each node
     for (size_t i = 0; i < M; ++i) {
@@ -551,20 +573,24 @@ static nhp_status nhp_launch_recursive_full(nhp_ctx *ctx, const nhp_cont_dataset
         while (64 * PQ * H < ds->N) H *= 2;
         NHP_TRY(rec_parts_for(ctx, ds, 64 * PQ, H));
         const nhp_rec_parts rp{ds->d_rec_ev, ds->d_rec_poff, ds->d_rec_rank};
-        const size_t lds = sizeof(double) * (16 + 64 + 2 * NHP_RING * (size_t)H + (size_t)H * 2 * 64 * PQ);
+        const size_t lds = NHP_RECW_LDS(PQ, H);
         bool launched = true;
 #define NHP_RECW(Q, HH)                                                                                                          \
-        hipLaunchKernelGGL((k_recursive_waves<Q, HH>), dim3((unsigned)(ds->col_end - ds->col_begin)), dim3(64 * HH), lds, ctx->stream, a, rp, \
-                           ctx->d_partials)
+        do {                                                                                                                     \
+            if (lds > 64 * 1024)                                                                                                 \
+                (void)hipFuncSetAttribute((const void *)k_recursive_waves<Q, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_recursive_waves<Q, HH>), dim3((unsigned)(ds->col_end - ds->col_begin)), dim3(64 * HH), lds, ctx->stream, \
+                               a, rp, ctx->d_partials);                                                                          \
+        } while (0)
         if (PQ == 1 && H == 1) NHP_RECW(1, 1);
         else if (PQ == 1 && H == 2) NHP_RECW(1, 2);
         else if (PQ == 1 && H == 4) NHP_RECW(1, 4);
         else if (PQ == 2 && H == 4) NHP_RECW(2, 4);
         else if (PQ == 2 && H == 8) NHP_RECW(2, 8);
-        else if (PQ == 1 && H == 16) NHP_RECW(1, 16);
         else if (PQ == 4 && H == 4) NHP_RECW(4, 4);
         else if (PQ == 4 && H == 8) NHP_RECW(4, 8);
         else if (PQ == 4 && H == 16) NHP_RECW(4, 16);
+        else if (PQ == 8 && H == 2) NHP_RECW(8, 2);
         else launched = false;
 #undef NHP_RECW
         if (launched) {

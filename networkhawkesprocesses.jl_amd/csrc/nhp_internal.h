@@ -126,7 +126,7 @@ struct nhp_cont_dataset {
     mutable int64_t cut_pairs = 0;
     int64_t n_zero_time = 0;            // events at exactly t = 0.0 (the recursion's seen-flag skips them: SURVEY D9)
     // O(M·N) recursion, one wave per (column, part of the parent nodes) (k_recursive_waves): the events with t > 0 part by
-    // part (rec_h parts of rec_np nodes; node = index inside the part; 128 records of padding), the parts' offsets and,
+    // part (rec_h parts of rec_np nodes; node = index inside the part; 192 records of padding), the parts' offsets and,
     // per part and bucket position, how many of the part's events precede the child.  Data only; made at the first call.
     nhp_event *d_rec_ev = nullptr;
     int32_t *d_rec_poff = nullptr;      // [rec_h + 1]
