@@ -262,7 +262,11 @@ __global__ __launch_bounds__(64 * H) void k_recursive_waves(nhp_cont_args a, nhp
     // record and only skips the atomic.  (θ gathered from the parameter column in memory instead of LDS, to unload the LDS
     // unit: 2.08 -> 2.61 ms -- a 64-lane random gather costs the texture path more than the LDS read it replaces.)
     auto term = [&](const nhp_event &e, bool live, double tk) {
+#ifdef NHP_RECW_POLY_FOLD
+        const double v = nhp_exp_neg_ll((th[e.node] * (tk - e.t)) * (1.0 / 92.33248261689366));
+#else
         const double v = nhp_exp_neg_tab_scaled(th[e.node] * (tk - e.t), tab);
+#endif
         if (live) atomicAdd(&acc[e.node], v);
     };
     auto fold = [&](nhp_event e, int j, int je, double tk) {
@@ -299,7 +303,11 @@ __global__ __launch_bounds__(64 * H) void k_recursive_waves(nhp_cont_args a, nhp
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
             const int pl = lane + 64 * q;
+#ifdef NHP_RECW_POLY_DECAY
+            double s = S[q] * nhp_exp_neg_ll((thr[q] * gap) * (1.0 / 92.33248261689366));
+#else
             double s = S[q] * nhp_exp_neg_tab_scaled(thr[q] * gap, tab);
+#endif
             s += acc[pl];
             acc[pl] = 0.0;
             S[q] = s;

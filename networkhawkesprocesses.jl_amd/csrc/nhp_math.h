@@ -154,25 +154,25 @@ __device__ __forceinline__ double nhp_exp_neg_tab(double x, const double *tab)
 }
 
 // The same with the argument already multiplied by 64/ln 2 (the caller folds the factor into its rate table): t = x·64/ln2,
-// r = (t - k)·ln2/64 -- one multiplication fewer; the reduced argument loses |t|·2^-53·ln2/64 absolute (3e-15 at x = -30,
-// 8e-14 at x = -700, where the term is 1e-304): used by the batch kernel, held to the oracle at 1e-11 like the rest.
+// u = t - k in [-1/2, 1/2] and e^(u·ln2/64) - 1 as a degree-5 polynomial in u itself (coefficients (ln2/64)^i / i!: no
+// multiplication by ln2/64 either); the reduced argument loses |t|·2^-53·ln2/64 absolute (3e-15 at x = -30, 8e-14 at x = -700,
+// where the term is 1e-304): used by the batch kernel and the recursion, held to the oracle at 1e-11 like the rest.
 __device__ __forceinline__ double nhp_exp_neg_tab_scaled(double t, const double *tab)
 {
 #pragma clang fp contract(off)
-    const double L64 = 1.0830424696249145e-02;            // ln 2 / 64
     const double kf = __builtin_rint(t);
-    const double r = (t - kf) * L64;
+    const double u = t - kf;
     const int k = (int)kf;
     const double tb = tab[k & 63];
     double p;
-    const double c5 = 8.3333333333333332e-03;
+    const double c5 = 0x1.5d87fe78a6731p-40;
     asm("v_fma_f64 %0, %1, %2, %3\n\t"
         "v_fma_f64 %0, %0, %2, %4\n\t"
-        "v_fma_f64 %0, %0, %2, 0.5\n\t"
-        "v_fma_f64 %0, %0, %2, 1.0\n\t"
+        "v_fma_f64 %0, %0, %2, %5\n\t"
+        "v_fma_f64 %0, %0, %2, %6\n\t"
         "v_mul_f64 %0, %0, %2"
         : "=&v"(p)
-        : "v"(c5), "v"(r), "s"(4.1666666666666664e-02), "s"(1.6666666666666666e-01));
+        : "v"(c5), "v"(u), "s"(0x1.3b2ab6fba4e77p-31), "s"(0x1.c6b08d704a0c0p-23), "s"(0x1.ebfbdff82c58fp-15), "s"(0x1.62e42fefa39efp-7));
     return __builtin_ldexp(__builtin_fma(tb, p, tb), k >> 6);
 }
 
