@@ -135,7 +135,10 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
             if (mask_integral) wint = w;
         }
         if (IMP == NHP_IMPULSE_EXPONENTIAL) {
-            col[p] = make_double2(a.p1[k], w);
+            const double th = a.p1[k];
+            // term = (a·w·θ)·exp(-θ·Δt): the rate times 64/ln 2 (nhp_exp_neg_tab_scaled) and, for packed records, times the
+            // time unit of their delays
+            col[p] = make_double2(-(th * 92.33248261689366) * (PACK ? a.ev8_inv : 1.0), w * th);
         } else {
             col[p] = make_double2(a.p1[k], __builtin_sqrt(a.p2[k]));
             colw[p] = w;
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
     auto delay = [&](const double tc, const rec &r) {
         if (!PACK) return tc - r.e.t;
         const double d = __hiloint2double((int)(((unsigned)(r.w >> 32) & 0xFFFFu) | 0x43300000u), (int)(unsigned)r.w);
-        return (tc - (d - 4503599627370496.0)) * a.ev8_inv;
+        return tc - (d - 4503599627370496.0);             // in units of 2^-s: the column's rate carries the factor
     };
     // slot of (wave, u, group-in-wave) inside a round: a wave's U*GW children are contiguous in the
     // round's window-sorted order
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
             for (int u = 0; u < U; ++u) {
                 const double dt = delay(tc[u], e[u]);
                 const double2 q = col[node_of(e[u])];
-                if (IMP == NHP_IMPULSE_EXPONENTIAL) s[u] += q.y * nhp_pdf_exponential_tab(q.x, dt, etab);
+                if (IMP == NHP_IMPULSE_EXPONENTIAL) s[u] += q.y * nhp_exp_neg_tab_scaled(q.x * dt, etab);
                 else s[u] += colw[node_of(e[u])] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
                 j[u] -= G;
                 e[u] = en[u];
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(NHP_WBLOCK) void k_windowed(nhp_cont_args a, int ma
                 const double dt = delay(tc[u], e[u]);
                 const double2 q = col[node_of(e[u])];
                 double term;
-                if (IMP == NHP_IMPULSE_EXPONENTIAL) term = q.y * nhp_pdf_exponential_tab(q.x, dt, etab);
+                if (IMP == NHP_IMPULSE_EXPONENTIAL) term = q.y * nhp_exp_neg_tab_scaled(q.x * dt, etab);
                 else term = colw[node_of(e[u])] * nhp_pdf_logitnormal(q.x, q.y, a.inv_dtmax, dt);
                 s[u] += (j[u] >= f[u]) ? term : 0.0;
                 j[u] -= G;
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_pairs(nhp_cont_args a, int m
         }
         const double th = a.p1[k];
         if (IMP == NHP_IMPULSE_EXPONENTIAL) {
-            col[p] = make_double2(th * unit, w * th);               // term = (a·w·θ)·exp(-(θ·unit)·q)
+            col[p] = make_double2(-((th * unit) * 92.33248261689366), w * th);   // term = (a·w·θ)·exp(-(θ·unit)·q), the rate times 64/ln 2
         } else {
             col[p] = make_double2(th, __builtin_sqrt(a.p2[k]));
             colw[p] = w;
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_pairs(nhp_cont_args a, int m
         if (IMP == NHP_IMPULSE_EXPONENTIAL) {
             const double q = __hiloint2double((int)(((unsigned)(r.w >> 32) & 0xFFFFu) | 0x43300000u), (int)(unsigned)r.w) - 4503599627370496.0;
             const double2 cw = col[(int)(r.w >> 48)];
-            return cw.y * nhp_exp_neg_tab(-(cw.x * q), etab);
+            return cw.y * nhp_exp_neg_tab_scaled(cw.x * q, etab);
         } else {
             const double2 cw = col[r.p];
             return colw[r.p] * nhp_pdf_logitnormal_cached(cw.x, cw.y, r.d);
