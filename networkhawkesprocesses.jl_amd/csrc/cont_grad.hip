@@ -306,7 +306,7 @@ nhp_status nhp_grad_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_
     const nhp_child *child_cut = nullptr;
     int cut_group = 0;
     if ((flags & NHP_LL_RECURSIVE) && !(flags & NHP_LL_FULL_RECURSION) && exp_imp)
-        NHP_TRY(nhp_recursive_window(ctx, ds, m, &child_cut, &cut_group));
+        NHP_TRY(nhp_recursive_window(ctx, ds, m, &child_cut, &cut_group, 1.2));
     if ((flags & NHP_LL_RECURSIVE) && exp_imp && !child_cut) {
         const size_t lds = 8 * (4 + NHP_WAVES + 8 * N);
         if (lds > 160 * 1024) { nhp_set_error(ctx, "recursive gradient: n_nodes = %d exceeds the LDS budget", ds->N); return NHP_ENOTIMPL; }

@@ -461,24 +461,25 @@ static nhp_status nhp_launch_recursive_full(nhp_ctx *ctx, const nhp_cont_dataset
 // *child_cut = the children with truncated-window starts (and *group the lanes-per-child width for them) when the
 // full-history sum may be evaluated through a window for this (data, parameters); nullptr when the recursion must run
 nhp_status nhp_recursive_window(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, const nhp_child **child_cut,
-                                int *group)
+                                int *group, double recursion_cost)
 {
     *child_cut = nullptr;
     static const int mode = getenv("NHP_REC_WINDOW") ? atoi(getenv("NHP_REC_WINDOW")) : 1;     // 0: always the recursion
     if (!mode || ds->M <= 0 || m->impulse_kind != NHP_IMPULSE_EXPONENTIAL) return NHP_OK;
     double cut = 0.0;
     NHP_TRY(rec_cut_for(ctx, ds, m, &cut));
-    // Which is faster?  Measured on MI355X: a workgroup of the recursion spends ≈0.9 µs + 2.2 ns·N per child of its
-    // column (all N <= 1024 columns run at once, so a launch takes that times the largest column), the windowed
-    // kernel evaluates ≈7·10¹¹ pair terms/s at long windows (≈4.5·10¹¹ below 128 parents) plus ≈30 µs per launch.
+    // Which is faster?  Measured on MI355X: the recursion (k_recursive_waves) spends ≈0.6 µs + 1.25 ns·N per child of its
+    // column (all N <= 1024 columns run at once, so a launch takes that times the largest column: 1.98 ms at N = 1024,
+    // M = 1e6), the windowed kernel evaluates ≈9.5·10¹¹ pair terms/s at long windows (≈5.5·10¹¹ below 128 parents) plus
+    // ≈30 µs per launch.
     const double rate = ds->t_last > 0.0 ? (double)ds->M / ds->t_last : 0.0;
     const double kc = cut * rate;                          // expected parents per window
     if (!(cut > 0.0) || kc > 8192.0) return NHP_OK;
     int32_t biggest = 1;
     for (int32_t c = 0; c < ds->N; ++c) biggest = std::max(biggest, ds->h_boff[c + 1] - ds->h_boff[c]);
     const double waves_of_columns = (double)((ds->N + 1023) / 1024);
-    const double t_recursion = waves_of_columns * (double)biggest * (0.9e-6 + 2.2e-9 * (double)ds->N);
-    auto t_window = [&](double k) { return 30e-6 + (double)ds->M * k / (k >= 128.0 ? 7e11 : 4.5e11); };
+    const double t_recursion = recursion_cost * waves_of_columns * (double)biggest * (0.6e-6 + 1.25e-9 * (double)ds->N);
+    auto t_window = [&](double k) { return 30e-6 + (double)ds->M * k / (k >= 128.0 ? 9.5e11 : 5.5e11); };
     if (t_window(kc) >= t_recursion) return NHP_OK;
     nhp_cont_dataset *mds = const_cast<nhp_cont_dataset *>(ds);
     if (!mds->d_child_cut && hipMalloc((void **)&mds->d_child_cut, sizeof(nhp_child) * (size_t)ds->M) != hipSuccess) {

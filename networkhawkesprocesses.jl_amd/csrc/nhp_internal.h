@@ -263,8 +263,10 @@ void nhp_set_error(nhp_ctx *ctx, const char *fmt, ...);
 
 nhp_status nhp_ctx_reserve_partials(nhp_ctx *ctx, size_t n_doubles);
 int nhp_pick_group(double mean_window);
+// recursion_cost: what the caller's O(M·N) kernel costs relative to its windowed route, in units of the log-likelihood's
+// ratio (1 for the log-likelihood; the gradient's recursion is 3.5x the log-likelihood's, its windowed route 2.9x)
 nhp_status nhp_recursive_window(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, const nhp_child **child_cut,
-                                int *group);
+                                int *group, double recursion_cost = 1.0);
 nhp_status nhp_launch_recursive_flags(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, int32_t flags, double *d_out);
 nhp_status nhp_launch_event_intensity_as(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, const nhp_child *child_w,
                                          int group, int mask_integral, double *d_lambda);

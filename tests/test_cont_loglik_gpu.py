@@ -399,3 +399,26 @@ def test_derived_layouts_agree_on_awkward_data(nhp, monkeypatch):
             assert rel(got["ev8"], got["exact"]) < 1e-12, (N, kind, dtm, got)
     for k in ("NHP_PLIST", "NHP_EV8"):
         monkeypatch.delenv(k, raising=False)
+
+
+@pytest.mark.parametrize("N,network,lgcp", [(3, False, False), (70, True, False), (200, False, True), (300, False, False),
+                                           (600, True, False), (1100, False, False), (2100, False, False)])
+def test_full_recursion_every_part_shape(nhp, orc, N, network, lgcp):
+    # NHP_LL_FULL_RECURSION: the O(M·N) recursion itself (k_recursive_waves: one wave per (column, part of the parent
+    # nodes)), never the truncated window.  The node counts walk through every (parents per lane, parts) shape the launcher
+    # picks -- 1x1, 1x2, 1x4, 2x4, 4x4 (ragged last part), 4x8, 4x16 -- incl. parts with no node, columns with no child,
+    # events at exactly t = 0 (D9) and the unmasked integral of the network twin (D7).
+    import ctypes as C
+    from nhp_amd import _lib
+    M = 2500
+    c = random_case(N, M, 300.0, "exponential", 1.0, network=network, lgcp=lgcp, seed=100 + N, nhp=nhp, orc=orc)
+    c["times"][:2] = 0.0
+    data = (c["times"], c["nodes"], c["T"])
+    ctx = nhp.default_context()
+    ds = nhp.device_dataset(c["proc"], data, ctx)
+    model = c["proc"].device_model(ctx)
+    ll = C.c_double()
+    _lib.check(_lib.lib().nhp_cont_loglik(ctx.h, ds.h, model.h, _lib.LL_RECURSIVE | _lib.LL_FULL_RECURSION, C.byref(ll)), ctx.h)
+    assert rel(ll.value, orc.loglik_recursive(c["om"], *data)) < TOL
+    # the default route (truncated window where it applies) gives the same number
+    assert rel(nhp.loglikelihood(c["proc"], data, recursive=True), ll.value) < TOL
