@@ -6,7 +6,6 @@ i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" \
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU" \
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SALU" \
-           "FETCH_SIZE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum" \
            "GRBM_GUI_ACTIVE SQ_LDS_ATOMIC_RETURN SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_rec/s$i -- python3 $R/tools/kbench.py recursive_full 3 > /dev/null 2>&1
