@@ -262,6 +262,111 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_grad_recursive(nhp_cont_args a, d
     }
 }
 
+// ---- recursive exponential, gradient pass of the wave-partitioned recursion -------------------------------------------
+// k_recursive_waves (cont_recursive.hip) has evaluated the log-likelihood and left g_k = 1/λ_k of every child; with g known
+// the gradient needs no sum across parents any more: wave h of column c runs the same recursion on ITS parents -- state
+// S_p(t_k) = Σ_j e^{-θ(t_k - t_j)} and its θ-derivative state R_p(t_k) = Σ_j (t_k - t_j) e^{-θ(t_k - t_j)}, folded from the
+// per-part event lists (one exp, two LDS atomics per event) and decayed per child (one exp per parent) -- and accumulates
+// GS_p = Σ_k g_k S_p(t_k), GR_p = Σ_k g_k R_p(t_k) in registers.  No reduction, no ring, no barrier after the table is staged.
+// Reference: the objective of mle! (src/continuous.jl:144-198) differentiated by hand; same sums as k_grad_recursive.
+template <int PQ, int H>
+__global__ __launch_bounds__(64 * H) void k_grad_recursive_waves(nhp_cont_args a, nhp_rec_parts rp, const double *__restrict__ ginv,
+                                                                 double *__restrict__ grad)
+{
+    constexpr int NP = 64 * PQ;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *tab = reinterpret_cast<double *>(smem);             // [64] 2^(j/64)
+    const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+    double *th = tab + 64 + (size_t)h * 3 * NP;                  // [NP] -θ[p,c]·64/ln2 of this wave's parents
+    double *accS = th + NP, *accR = accS + NP;                   // [NP] segment accumulators (this wave's alone)
+    const int c = a.col_begin + blockIdx.x, N = a.N;
+    const double K64 = 92.33248261689366;                        // 64 / ln 2
+
+    nhp_exp_tab_init(tab);
+    double S[PQ], R[PQ], thr[PQ], GS[PQ], GR[PQ];
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) {
+        const int pl = lane + 64 * q, p = h * NP + pl;
+        S[q] = R[q] = GS[q] = GR[q] = 0.0;
+        thr[q] = p < N ? -(a.p1[(size_t)p + (size_t)c * N] * K64) : 0.0;
+        th[pl] = thr[q];
+        accS[pl] = 0.0; accR[pl] = 0.0;
+    }
+    __syncthreads();                                             // the table
+
+    const nhp_event *ev = rp.ev + rp.poff[h];
+    const int32_t *rk = rp.rank + (size_t)h * (size_t)a.M;
+    const int kb = a.boff[c], ke = a.boff[c + 1];
+
+    auto term = [&](const nhp_event &e, bool live, double tk) {
+        const double d = tk - e.t;
+        const double v = nhp_exp_neg_tab_scaled(th[e.node] * d, tab);
+        if (live) { atomicAdd(&accS[e.node], v); atomicAdd(&accR[e.node], d * v); }
+    };
+    auto fold = [&](nhp_event e, int j, int je, double tk) {      // as in k_recursive_waves
+        int r = j - lane;
+        while (r < je) {
+            const nhp_event en = ev[j + 64];
+            asm volatile("" ::: "memory");
+            term(e, j < je, tk);
+            r += 64;
+            if (r >= je) break;
+            e = ev[j + 128];
+            asm volatile("" ::: "memory");
+            term(en, j + 64 < je, tk);
+            r += 64; j += 128;
+        }
+    };
+
+    double ch_t = 0.0, nx_t = 0.0, gsum = 0.0;
+    int ch_r = 0, nx_r = 0;
+    if (kb < ke) { ch_t = a.child[kb].t; ch_r = rk[kb]; nx_t = ch_t; nx_r = ch_r; }
+    if (kb + 1 < ke) { nx_t = a.child[kb + 1].t; nx_r = rk[kb + 1]; }
+    if (kb < ke) fold(ev[lane], lane, ch_r, ch_t);
+    double prev_t = ch_t;
+    for (int k = kb; k < ke; ++k) {
+        const int kn = k + 2 < ke ? k + 2 : ke - 1;
+        const double nn_t = a.child[kn].t;
+        const int nn_r = rk[kn];
+        const double g = ginv[k];
+        const bool more = k + 1 < ke;
+        const int fj = ch_r + lane, fe = more ? nx_r : ch_r;
+        const nhp_event pe = ev[fj];
+        NHP_RECW_SYNC();
+        const double gap = ch_t - prev_t;
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+            const int pl = lane + 64 * q;
+            const double dec = nhp_exp_neg_tab_scaled(thr[q] * gap, tab);
+            const double r = dec * (R[q] + gap * S[q]) + accR[pl];
+            const double s = dec * S[q] + accS[pl];
+            accS[pl] = 0.0; accR[pl] = 0.0;
+            S[q] = s; R[q] = r;
+            GS[q] += g * s; GR[q] += g * r;
+        }
+        if (h == 0) {                                            // the baseline's share, once per child
+            if (a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) gsum += g;
+            else if (lane == 0) grad_lgcp_scatter(a, c, ch_t, g, grad);
+        }
+        fold(pe, fj, fe, nx_t);
+        prev_t = ch_t;
+        ch_t = nx_t; ch_r = nx_r;
+        nx_t = nn_t; nx_r = nn_r;
+    }
+    const size_t Nn = grad_nbase(a), NN = (size_t)N * (size_t)N;
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) {
+        const int p = h * NP + lane + 64 * q;
+        if (p < N) {
+            const size_t k = (size_t)p + (size_t)c * N;
+            const double av = a.A ? a.A[k] : 1.0, w = a.W[k], t = a.p1[k];
+            grad[Nn + NN + k] = -a.cnt[p] + av * t * GS[q];      // unmasked integral (D7)
+            grad[Nn + k] = av * w * (GS[q] - t * GR[q]);
+        }
+    }
+    if (tid == 0 && a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) grad[c] = -a.duration + gsum;
+}
+
 template <int IMP>
 static void launch_grad_group(int G, dim3 grid, size_t lds, hipStream_t st, const nhp_cont_args &a,
                               const double *lambda, double *grad)
@@ -308,6 +413,35 @@ nhp_status nhp_grad_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_
     if ((flags & NHP_LL_RECURSIVE) && !(flags & NHP_LL_FULL_RECURSION) && exp_imp)
         NHP_TRY(nhp_recursive_window(ctx, ds, m, &child_cut, &cut_group, 1.2));
     if ((flags & NHP_LL_RECURSIVE) && exp_imp && !child_cut) {
+        // two passes of the wave-partitioned recursion: log-likelihood + 1/λ of every child, then the gradient sums
+        int PQ = 0, H = 0;
+        nhp_rec_parts rp{};
+        NHP_TRY(nhp_rec_parts_for(ctx, ds, &PQ, &H, &rp));
+        if (PQ) {
+            bool launched = false;
+            if (lgcp || nhp_is_column_shard(ds)) {
+                hipLaunchKernelGGL(k_grad_init, dim3(1024), dim3(256), 0, st, a, 0, d_grad);
+                NHP_HIP(ctx, hipGetLastError());
+            }
+            NHP_TRY(nhp_launch_recursive_waves(ctx, ds, m, ctx->d_results, d_lambda, &launched));
+            if (launched) {
+                const size_t wl = sizeof(double) * (64 + (size_t)H * 3 * 64 * PQ);
+                const int ncol = ds->col_end - ds->col_begin;
+#define NHP_GRW(Q, HH)                                                                                                           \
+                do {                                                                                                             \
+                    if (wl > 64 * 1024)                                                                                          \
+                        (void)hipFuncSetAttribute((const void *)k_grad_recursive_waves<Q, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl); \
+                    hipLaunchKernelGGL((k_grad_recursive_waves<Q, HH>), dim3((unsigned)ncol), dim3(64 * HH), wl, st, a, rp, d_lambda, d_grad); \
+                } while (0)
+                NHP_REC_SHAPES(NHP_GRW, launched = false);
+#undef NHP_GRW
+                if (launched) {
+                    NHP_HIP(ctx, hipGetLastError());
+                    *d_grad_out = d_grad;
+                    return NHP_OK;
+                }
+            }
+        }
         const size_t lds = 8 * (4 + NHP_WAVES + 8 * N);
         if (lds > 160 * 1024) { nhp_set_error(ctx, "recursive gradient: n_nodes = %d exceeds the LDS budget", ds->N); return NHP_ENOTIMPL; }
         if (lds > 64 * 1024)

@@ -196,28 +196,13 @@ __global__ __launch_bounds__(BLOCK) void k_recursive(nhp_cont_args a, double *__
 // the reads of the decay are ordered by the wave's own instruction stream and the child loop has no barrier at all.  The
 // H partial intensities of a child meet in a ring (one barrier per NHP_RING children, as above).  Exponentials through
 // the 2^(j/64) table with -θ·64/ln 2 held per parent (nhp_exp_neg_tab_scaled).
-struct nhp_rec_parts {          // kernel-side view of the per-part lists (nhp_cont_dataset::d_rec_*)
-    const nhp_event *ev;        // [Σ part lengths + 192] events with t > 0 (D9), part by part, time order inside; node = index inside the part
-    const int32_t *poff;        // [H + 1] first record of each part
-    const int32_t *rank;        // [H][M] by bucket position k: events of the part with time index < idx_k
-};
 
-// Ordering of one wave's own LDS traffic without draining it: the LDS unit executes a wave's instructions in issue order (an
-// atomic of lane A is seen by a later read of lane B of the same wave), so only the compiler must be kept from reordering.
-#define NHP_LDS_ORDER()                                         \
-    do {                                                        \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
-        __builtin_amdgcn_wave_barrier();                        \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
-    } while (0)
-#ifndef NHP_RECW_SYNC
-#define NHP_RECW_SYNC() NHP_LDS_ORDER()
-#endif
 #define NHP_RECW_TS 66          // row stride of the reduction tile (doubles): 64 lanes + 2 of padding
 #define NHP_RECW_LDS(PQ, H) (sizeof(double) * (16 + 64 + 2 * NHP_RING * (size_t)(H) + (size_t)(H) * (2 * 64 * (PQ) + 8 * NHP_RECW_TS)))
 
 template <int PQ, int H>
-__global__ __launch_bounds__(64 * H) void k_recursive_waves(nhp_cont_args a, nhp_rec_parts rp, double *__restrict__ partials)
+__global__ __launch_bounds__(64 * H) void k_recursive_waves(nhp_cont_args a, nhp_rec_parts rp, double *__restrict__ partials,
+                                                            double *__restrict__ ginv /* [M] by bucket position: 1/λ of every child (gradient pass), or null */)
 {
     constexpr int NP = 64 * PQ;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -338,6 +323,7 @@ __global__ __launch_bounds__(64 * H) void k_recursive_waves(nhp_cont_args a, nhp
                 double lam = rec_baseline(a, c, tk);
                 for (int w = 0; w < H; ++w) lam += ring[(half * NHP_RING + tid) * H + w];
                 logsum += nhp_log(lam);
+                if (ginv) ginv[k + 1 - n + tid] = 1.0 / lam;
             }
         }
         prev_t = ch_t;
@@ -523,7 +509,7 @@ nhp_status nhp_launch_recursive_flags(nhp_ctx *ctx, const nhp_cont_dataset *ds, 
 }
 
 // the per-part event lists of k_recursive_waves for parts of `np` nodes (data only; cached in the dataset)
-static nhp_status rec_parts_for(nhp_ctx *ctx, const nhp_cont_dataset *ds, int np, int H)
+static nhp_status rec_parts_build(nhp_ctx *ctx, const nhp_cont_dataset *ds, int np, int H)
 {
     if (ds->d_rec_ev && ds->rec_np == np && ds->rec_h == H) return NHP_OK;
     nhp_cont_dataset *mds = const_cast<nhp_cont_dataset *>(ds);
@@ -565,6 +551,51 @@ static nhp_status rec_parts_for(nhp_ctx *ctx, const nhp_cont_dataset *ds, int np
     return NHP_OK;
 }
 
+// shape (parents per lane, parts) of the wave-partitioned recursion for this dataset, and its lists; *PQ = 0 when the
+// shape is not available (NHP_REC_WAVES=0, or N > 4096)
+nhp_status nhp_rec_parts_for(nhp_ctx *ctx, const nhp_cont_dataset *ds, int *PQ_out, int *H_out, nhp_rec_parts *rp)
+{
+    *PQ_out = 0; *H_out = 0;
+    static const int waves = getenv("NHP_REC_WAVES") ? atoi(getenv("NHP_REC_WAVES")) : 1;
+    if (!waves || ds->N > 4096) return NHP_OK;
+    int PQ = ds->N <= 256 ? 1 : (ds->N <= 512 ? 2 : 4);
+    int H = 1;
+    if (const char *env = getenv("NHP_REC_PARTS")) { int q = 0, hh = 0; if (sscanf(env, "%d,%d", &q, &hh) == 2 && 64 * q * hh >= ds->N) { PQ = q; H = hh; } }
+    while (64 * PQ * H < ds->N) H *= 2;
+    NHP_TRY(rec_parts_build(ctx, ds, 64 * PQ, H));
+    *rp = nhp_rec_parts{ds->d_rec_ev, ds->d_rec_poff, ds->d_rec_rank};
+    *PQ_out = PQ; *H_out = H;
+    return NHP_OK;
+}
+
+// the O(M·N) recursion through k_recursive_waves: log-likelihood -> *d_out and, for the gradient pass, 1/λ of every child
+// -> d_ginv (bucket order; may be null).  *launched = false when no shape applies (the caller falls back).
+nhp_status nhp_launch_recursive_waves(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_out, double *d_ginv,
+                                      bool *launched)
+{
+    *launched = false;
+    int PQ = 0, H = 0;
+    nhp_rec_parts rp{};
+    NHP_TRY(nhp_rec_parts_for(ctx, ds, &PQ, &H, &rp));
+    if (!PQ) return NHP_OK;
+    NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)ds->N));
+    nhp_cont_args a = nhp_make_args(ds, m);
+    const size_t lds = NHP_RECW_LDS(PQ, H);
+    *launched = true;
+#define NHP_RECW(Q, HH)                                                                                                          \
+        do {                                                                                                                     \
+            if (lds > 64 * 1024)                                                                                                 \
+                (void)hipFuncSetAttribute((const void *)k_recursive_waves<Q, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_recursive_waves<Q, HH>), dim3((unsigned)(ds->col_end - ds->col_begin)), dim3(64 * HH), lds, ctx->stream, \
+                               a, rp, ctx->d_partials, d_ginv);                                                                  \
+        } while (0)
+    NHP_REC_SHAPES(NHP_RECW, *launched = false);
+#undef NHP_RECW
+    if (!*launched) return NHP_OK;
+    NHP_HIP(ctx, hipGetLastError());
+    return nhp_launch_finalize(ctx, a, ds->col_end - ds->col_begin, d_out);
+}
+
 static nhp_status nhp_launch_recursive_full(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_out)
 {
     if (m->impulse_kind != NHP_IMPULSE_EXPONENTIAL) return NHP_EINVAL;
@@ -572,40 +603,12 @@ static nhp_status nhp_launch_recursive_full(nhp_ctx *ctx, const nhp_cont_dataset
     if (ds->N > 4096) { nhp_set_error(ctx, "recursive ll: n_nodes = %d > 4096 not supported", ds->N); return NHP_ENOTIMPL; }
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)ds->N));
     nhp_cont_args a = nhp_make_args(ds, m);
-    // 1: one wave per (column, part of the parents), no barrier in the child loop (k_recursive_waves); 0: the workgroup-wide
-    // fold + barrier per child (k_recursive).  NHP_REC_PARTS = "PQ,H" forces a shape of the first (tools/kbench.py).
-    static const int waves = getenv("NHP_REC_WAVES") ? atoi(getenv("NHP_REC_WAVES")) : 1;
-    if (waves) {
-        int PQ = ds->N <= 256 ? 1 : (ds->N <= 512 ? 2 : 4);
-        int H = 1;
-        if (const char *env = getenv("NHP_REC_PARTS")) { int q = 0, hh = 0; if (sscanf(env, "%d,%d", &q, &hh) == 2 && 64 * q * hh >= ds->N) { PQ = q; H = hh; } }
-        while (64 * PQ * H < ds->N) H *= 2;
-        NHP_TRY(rec_parts_for(ctx, ds, 64 * PQ, H));
-        const nhp_rec_parts rp{ds->d_rec_ev, ds->d_rec_poff, ds->d_rec_rank};
-        const size_t lds = NHP_RECW_LDS(PQ, H);
-        bool launched = true;
-#define NHP_RECW(Q, HH)                                                                                                          \
-        do {                                                                                                                     \
-            if (lds > 64 * 1024)                                                                                                 \
-                (void)hipFuncSetAttribute((const void *)k_recursive_waves<Q, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k_recursive_waves<Q, HH>), dim3((unsigned)(ds->col_end - ds->col_begin)), dim3(64 * HH), lds, ctx->stream, \
-                               a, rp, ctx->d_partials);                                                                          \
-        } while (0)
-        if (PQ == 1 && H == 1) NHP_RECW(1, 1);
-        else if (PQ == 1 && H == 2) NHP_RECW(1, 2);
-        else if (PQ == 1 && H == 4) NHP_RECW(1, 4);
-        else if (PQ == 2 && H == 4) NHP_RECW(2, 4);
-        else if (PQ == 2 && H == 8) NHP_RECW(2, 8);
-        else if (PQ == 4 && H == 4) NHP_RECW(4, 4);
-        else if (PQ == 4 && H == 8) NHP_RECW(4, 8);
-        else if (PQ == 4 && H == 16) NHP_RECW(4, 16);
-        else if (PQ == 8 && H == 2) NHP_RECW(8, 2);
-        else launched = false;
-#undef NHP_RECW
-        if (launched) {
-            NHP_HIP(ctx, hipGetLastError());
-            return nhp_launch_finalize(ctx, a, ds->col_end - ds->col_begin, d_out);
-        }
+    // one wave per (column, part of the parents), no barrier in the child loop (k_recursive_waves); NHP_REC_WAVES=0: the
+    // workgroup-wide fold + barrier per child (k_recursive).  NHP_REC_PARTS = "PQ,H" forces a shape (tools/kbench.py).
+    {
+        bool launched = false;
+        NHP_TRY(nhp_launch_recursive_waves(ctx, ds, m, d_out, nullptr, &launched));
+        if (launched) return NHP_OK;
     }
 #define NHP_REC_LAUNCH(B, Q)                                                                                   \
     do {                                                                                                       \

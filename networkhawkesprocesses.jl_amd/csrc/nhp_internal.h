@@ -308,6 +308,41 @@ nhp_status nhp_launch_event_intensity(nhp_ctx *ctx, const nhp_cont_dataset *ds, 
     } while (0)
 
 
+// ---- wave-partitioned O(M·N) recursion (cont_recursive.hip; its gradient pass in cont_grad.hip) -----------------------
+struct nhp_rec_parts {          // kernel-side view of the per-part lists (nhp_cont_dataset::d_rec_*)
+    const nhp_event *ev;        // [Σ part lengths + 192] events with t > 0 (D9), part by part, time order inside; node = index inside the part
+    const int32_t *poff;        // [H + 1] first record of each part
+    const int32_t *rank;        // [H][M] by bucket position k: events of the part with time index < idx_k
+};
+nhp_status nhp_rec_parts_for(nhp_ctx *ctx, const nhp_cont_dataset *ds, int *PQ, int *H, nhp_rec_parts *rp);
+nhp_status nhp_launch_recursive_waves(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_out, double *d_ginv,
+                                      bool *launched);
+// the (parents per lane, parts) shapes both kernels are instantiated for: X(PQ, H) launches, `otherwise` runs when none fits
+#define NHP_REC_SHAPES(X, otherwise)              \
+    do {                                          \
+        if (PQ == 1 && H == 1) X(1, 1);           \
+        else if (PQ == 1 && H == 2) X(1, 2);      \
+        else if (PQ == 1 && H == 4) X(1, 4);      \
+        else if (PQ == 2 && H == 4) X(2, 4);      \
+        else if (PQ == 2 && H == 8) X(2, 8);      \
+        else if (PQ == 4 && H == 4) X(4, 4);      \
+        else if (PQ == 4 && H == 8) X(4, 8);      \
+        else if (PQ == 4 && H == 16) X(4, 16);    \
+        else if (PQ == 8 && H == 2) X(8, 2);      \
+        else { otherwise; }                       \
+    } while (0)
+// Ordering of one wave's own LDS traffic without draining it: the LDS unit executes a wave's instructions in issue order (an
+// atomic of lane A is seen by a later read of lane B of the same wave), so only the compiler must be kept from reordering.
+#define NHP_LDS_ORDER()                                         \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+    } while (0)
+#ifndef NHP_RECW_SYNC
+#define NHP_RECW_SYNC() NHP_LDS_ORDER()
+#endif
+
 // ---- device helpers --------------------------------------------------------------------
 __device__ __forceinline__ double nhp_dpp_add(double v, const int sel)
 {

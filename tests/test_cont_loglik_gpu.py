@@ -422,3 +422,13 @@ def test_full_recursion_every_part_shape(nhp, orc, N, network, lgcp):
     assert rel(ll.value, orc.loglik_recursive(c["om"], *data)) < TOL
     # the default route (truncated window where it applies) gives the same number
     assert rel(nhp.loglikelihood(c["proc"], data, recursive=True), ll.value) < TOL
+    # ... and the gradient of the same recursion (k_recursive_waves leaves 1/λ of every child, k_grad_recursive_waves
+    # accumulates the sums per (column, part)) against the oracle's; P = [λ0 | grid intensities; θ; W]
+    nb = N * 17 if lgcp else N
+    P = nb + 2 * N * N
+    g = np.empty(P)
+    _lib.check(_lib.lib().nhp_cont_loglik_grad(ctx.h, ds.h, model.h, _lib.LL_RECURSIVE | _lib.LL_FULL_RECURSION, C.byref(ll),
+                                               _lib.dptr(g), P), ctx.h)
+    wll, wg = orc.loglik_grad(c["om"], *data, recursive=True)
+    assert rel(ll.value, wll) < TOL
+    assert np.max(np.abs(g - wg) / np.maximum(1.0, np.abs(wg))) < 1e-9
