@@ -104,16 +104,18 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_grad_windowed(nhp_cont_args a, co
 {
     extern __shared__ __align__(16) unsigned char smem[];
     double *red = reinterpret_cast<double *>(smem);
-    double2 *col = reinterpret_cast<double2 *>(smem + 32);       // exp {θ, -}; logit {μ, sqrt τ}
+    double2 *col = reinterpret_cast<double2 *>(smem + 32);       // exp {θ, -θ·64/ln 2}; logit {μ, sqrt τ}
     double *accH = reinterpret_cast<double *>(col + a.N);        // Σ g·ħ
     double *acc1 = accH + a.N;                                   // Σ g·∂ħ/∂θ  |  Σ g·ħ·sqrtτ·z
     double *acc2 = acc1 + a.N;                                   // logit: Σ g·ħ·(1 - z²)
+    double *etab = acc1 + a.N;                                   // exponential (no acc2): [64] 2^(j/64), 512 bytes counted by the launcher
+    if (IMP == NHP_IMPULSE_EXPONENTIAL) nhp_exp_tab_init(etab);
 
     const nhp_item it = a.items[blockIdx.x];
     const int c = it.node, N = a.N, tid = threadIdx.x;
     for (int p = tid; p < N; p += NHP_BLOCK) {
         const size_t k = (size_t)p + (size_t)c * N;
-        if (IMP == NHP_IMPULSE_EXPONENTIAL) col[p] = make_double2(a.p1[k], 0.0);
+        if (IMP == NHP_IMPULSE_EXPONENTIAL) col[p] = make_double2(a.p1[k], -(a.p1[k] * 92.33248261689366));
         else col[p] = make_double2(a.p1[k], __builtin_sqrt(a.p2[k]));
         accH[p] = 0.0; acc1[p] = 0.0;
         if (IMP != NHP_IMPULSE_EXPONENTIAL) acc2[p] = 0.0;
@@ -130,15 +132,27 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_grad_windowed(nhp_cont_args a, co
             if (a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) gsum += g;
             else grad_lgcp_scatter(a, c, ch.t, g, grad);
         }
+        if (IMP == NHP_IMPULSE_EXPONENTIAL) {
+            // one 16-byte record per parent, the next one requested before this one's arithmetic; col = {θ, -θ·64/ln 2}
+            int j = ch.idx - 1 - gl;
+            nhp_event e0 = a.ev[j > 0 ? j : 0];
+            for (; j >= ch.first; j -= G) {
+                const nhp_event en = a.ev[j - G > 0 ? j - G : 0];
+                asm volatile("" ::: "memory");
+                const double dt = ch.t - e0.t;
+                const int p = e0.node;
+                const double2 q = col[p];
+                const double e = nhp_exp_neg_tab_scaled(q.y * dt, etab);
+                atomicAdd(&accH[p], g * (q.x * e));
+                atomicAdd(&acc1[p], g * ((1.0 - q.x * dt) * e));
+                e0 = en;
+            }
+        } else
         for (int j = ch.idx - 1 - gl; j >= ch.first; j -= G) {
             const double dt = ch.t - a.times[j];
             const int p = a.nodes[j];
             const double2 q = col[p];
-            if (IMP == NHP_IMPULSE_EXPONENTIAL) {
-                const double e = nhp_exp_neg(-(q.x * dt));
-                atomicAdd(&accH[p], g * (q.x * e));
-                atomicAdd(&acc1[p], g * ((1.0 - q.x * dt) * e));
-            } else {
+            {
                 const double x = dt * a.inv_dtmax;
                 if (x > 0.0 && x < 1.0) {
                     const double o = 1.0 - x, qq = 1.0 / (x * o);
@@ -465,7 +479,7 @@ nhp_status nhp_grad_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_
         NHP_HIP(ctx, hipGetLastError());
         NHP_TRY(nhp_launch_event_intensity_as(ctx, ds, m, child_cut, G, mask, d_lambda));   // pass A: partials + λ_i
         NHP_TRY(nhp_launch_finalize(ctx, a, ds->n_items, ctx->d_results));
-        const size_t lds = 32 + 16 * N + 8 * N * (exp_imp ? 2 : 3);
+        const size_t lds = 32 + 16 * N + 8 * N * (exp_imp ? 2 : 3) + (exp_imp ? 512 : 0);     // + the exponential's 2^(j/64) table
         if (lds > 160 * 1024) { nhp_set_error(ctx, "gradient: n_nodes = %d exceeds the 160 KiB LDS budget", ds->N); return NHP_ENOTIMPL; }
         dim3 grid((unsigned)ds->n_items);
         if (exp_imp) launch_grad_group<NHP_IMPULSE_EXPONENTIAL>(G, grid, lds, st, a, d_lambda, d_grad);
