@@ -509,6 +509,9 @@ __global__ __launch_bounds__(256) void k_disc_convolve(const double *__restrict_
                 unsigned long long m = ((lo >> sh) | (sh ? hi << (64 - sh) : 0ull)) & lmask;
 #pragma unroll
                 for (int q = 0; q < CONV_CB; ++q) s[j][q] = 0.0;
+#ifdef CONV_FILL                                         // timing experiment (tools/): the stores alone
+                m = 0;
+#endif
                 while (m) {                              // increasing lag = decreasing bit: highest set bit first
                     const int k = 63 - __builtin_clzll(m);
                     m &= ~(1ull << k);
