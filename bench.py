@@ -14,6 +14,7 @@ independent stream (chains / restarts shard embarrassingly), weak sca
 per-rank results are gathered over RCCL.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import threading
 import json
 import os
 import sys
@@ -495,29 +496,69 @@ def chains_leg(nhp, ctx, rank, steps, sync):
     run(3, steps)
     sync()
     wall = time.perf_counter() - t0
-    comm = _lib.comm_for(ctx)                       # RCCL communicator of this rank ("nccl" groups); None in the gloo rehearsal
-    t_gather = 0.0
-    if comm is not None:
-        L = inference.moments_length(proc)
-        s, q = np.empty((comm.world, L)), np.empty((comm.world, L))
-        counts, rho = np.empty(comm.world, dtype=np.int64), np.empty((comm.world, 3))
-        sync()
-        t0 = time.perf_counter()
-        _lib.check(lib.nhp_gather_moments(ctx.h, comm.h, model.h, _lib.dptr(s), _lib.dptr(q), L, _lib.iptr(counts), _lib.dptr(rho)), ctx.h)
-        sync()
-        t_gather = time.perf_counter() - t0
-        assert np.all(counts == steps + 3)
+    # the two parts that exchange are guarded separately (-1 = failed, reported as null): the chains' own rate above stands
+    t_gather = -1.0
+    try:
+        comm = _lib.comm_for(ctx)                   # RCCL communicator of this rank ("nccl" groups); None in the gloo rehearsal
+        t_gather = 0.0
+        if comm is not None:
+            L = inference.moments_length(proc)
+            s, q = np.empty((comm.world, L)), np.empty((comm.world, L))
+            counts, rho = np.empty(comm.world, dtype=np.int64), np.empty((comm.world, 3))
+            sync()
+            t0 = time.perf_counter()
+            _lib.check(lib.nhp_gather_moments(ctx.h, comm.h, model.h, _lib.dptr(s), _lib.dptr(q), L, _lib.iptr(counts), _lib.dptr(rho)), ctx.h)
+            sync()
+            t_gather = time.perf_counter() - t0
+            assert np.all(counts == steps + 3)
+    except Exception as exc:
+        t_gather = -1.0
+        print(f"[rank {rank}] gather of the chains' moments failed: {exc!r}", file=sys.stderr, flush=True)
     # the same chain swept by ALL ranks, each its columns (mcmc_ on a ShardedDataset -> nhp_cont_mcmc_run with the
     # communicator; through the host when the ranks cannot form an RCCL clique)
-    from nhp_amd.sharded import ShardedDataset
-    sproc = nhp.synthetic.s_metric_process(N, M, T, "logitnormal", 1.0, network=True)
-    sd = ShardedDataset(sproc, (times, nodes, T), ctx)
-    nhp.mcmc_(sproc, sd, nsteps=3, seed=1, keep_samples=False, moments=True)
-    sync()
-    t0 = time.perf_counter()
-    nhp.mcmc_(sproc, sd, nsteps=steps, seed=1, keep_samples=False, moments=True)
-    sync()
-    return wall, time.perf_counter() - t0, t_gather
+    t_one = -1.0
+    try:
+        from nhp_amd.sharded import ShardedDataset
+        sproc = nhp.synthetic.s_metric_process(N, M, T, "logitnormal", 1.0, network=True)
+        sd = ShardedDataset(sproc, (times, nodes, T), ctx)
+        nhp.mcmc_(sproc, sd, nsteps=3, seed=1, keep_samples=False, moments=True)
+        sync()
+        t0 = time.perf_counter()
+        nhp.mcmc_(sproc, sd, nsteps=steps, seed=1, keep_samples=False, moments=True)
+        sync()
+        t_one = time.perf_counter() - t0
+    except Exception as exc:
+        print(f"[rank {rank}] one chain over all ranks failed: {exc!r}", file=sys.stderr, flush=True)
+    return wall, t_one, t_gather
+
+
+def headline(args, r, world, wall_s, lls):
+    """The contract's JSON line as a dict: the headline measurement (everything else is added to it)."""
+    B = algorithmic_bytes(r["N"], r["M"], r["kind"])
+    ms_kernel = r["dev_ms"] / args.steps
+    out = {
+        "metric": "log-likelihood evals/sec (N=1024, M=1e6)",
+        "value": world * args.steps / wall_s,
+        "unit": "log-likelihood evals/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * wall_s / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"continuous exponential standard Hawkes, N={r['N']}, M={r['M']}, "
+                               f"dt_max=1, {args.workload} (S-metric, SURVEY 8d)",
+                   "pairs_per_eval": r["pairs"], "independent_streams": world,
+                   "dataset_setup_ms_once": r["dataset_ms"], "first_evaluation_ms_incl_layout_build": r["first_ms"],
+                   "data_layout": "per dataset, made once from the events (data only, no parameter in it): children bucketed by node, "
+                                  "parent-child pairs as a list of node | delay; every evaluation computes every pair term "
+                                  "from the parameters it is given (see parameters_changing_every_evaluation)"},
+        "roofline": {"bound": "hbm", "achieved": B / (ms_kernel * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": B / (ms_kernel * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": measured_traffic(args.workload)[0], "traffic_measured_at_commit": measured_traffic(args.workload)[1],
+                     "algorithmic_bytes": B, "kernel_ms": ms_kernel,
+                     "pair_rate_per_s": r["pairs"] / (ms_kernel * 1e-3)},
+        "loglik": [float(v) for v in lls.cpu()],
+    }
+    return out
 
 
 def main():
@@ -583,97 +624,119 @@ def main():
         if rank == 0:
             lls = torch.cat(gathered)
     wall_s = float(wall.item())
-    chain_wall = None
-    if world > 1 and args.chain_steps > 0:
-        tw = torch.tensor(list(chains_leg(nhp, ctx, rank, args.chain_steps, sync)), dtype=torch.float64, device=tdev)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        chain_wall, one_chain_wall, gather_wall = float(tw[0].item()), float(tw[1].item()), float(tw[2].item())
-    sharded = None
-    if world > 1 and args.sharded:
-        sharded = sharded_leg(nhp, ctx, args.nodes, args.events, world, [x for x in args.sharded.split(",") if x])
+    out = headline(args, r, world, wall_s, lls) if rank == 0 else None
 
-    if rank == 0:
-        B = algorithmic_bytes(r["N"], r["M"], r["kind"])
-        ms_kernel = r["dev_ms"] / args.steps
-        out = {
-            "metric": "log-likelihood evals/sec (N=1024, M=1e6)",
-            "value": world * args.steps / wall_s,
-            "unit": "log-likelihood evals/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * wall_s / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"continuous exponential standard Hawkes, N={r['N']}, M={r['M']}, "
-                                   f"dt_max=1, {args.workload} (S-metric, SURVEY 8d)",
-                       "pairs_per_eval": r["pairs"], "independent_streams": world,
-                       "dataset_setup_ms_once": r["dataset_ms"], "first_evaluation_ms_incl_layout_build": r["first_ms"],
-                       "data_layout": "per dataset, made once from the events (data only, no parameter in it): children bucketed by node, "
-                                      "parent-child pairs as a list of node | delay; every evaluation computes every pair term "
-                                      "from the parameters it is given (see parameters_changing_every_evaluation)"},
-            "roofline": {"bound": "hbm", "achieved": B / (ms_kernel * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": B / (ms_kernel * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(args.workload)[0], "traffic_measured_at_commit": measured_traffic(args.workload)[1],
-                         "algorithmic_bytes": B, "kernel_ms": ms_kernel,
-                         "pair_rate_per_s": r["pairs"] / (ms_kernel * 1e-3)},
-            "loglik": [float(v) for v in lls.cpu()],
-        }
-        if chain_wall is not None:
-            out["config5_independent_chains"] = {
-                "workload": "c3 model (N=1024, M=1e6, logit-normal network), one mcmc! chain per rank, device-side sweep",
-                "chains": world, "steps_per_chain": args.chain_steps,
-                "mcmc_steps_per_sec": world * args.chain_steps / chain_wall, "ms_per_step": 1e3 * chain_wall / args.chain_steps,
-                "rccl_gather_of_the_chains_posterior_moments_ms": 1e3 * gather_wall,
-                "one_chain_over_all_ranks_ms_per_step": 1e3 * one_chain_wall / args.chain_steps}
-        if sharded is not None:
-            out["one_evaluation_over_all_ranks"] = sharded
-        if world == 1 and args.two_streams and not r["recursive"]:
-            try:
-                out["two_independent_streams_on_one_gpu"] = two_streams(nhp, ctx, r, args.steps, local)
-            except Exception as exc:        # secondary number
-                out["two_independent_streams_on_one_gpu"] = {"error": repr(exc)}
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(r)
-            out["speedup_vs_cpu_core"] = out["value"] / out["cpu_baseline"]["value"]
-            if not r["recursive"]:
-                try:
-                    out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(r)
-                    out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline_all_cores"]["value"]
-                except Exception as exc:      # secondary number
-                    out["cpu_baseline_all_cores"] = {"error": repr(exc)}
-        if world == 1 and not args.no_default_dispatch:
-            out["default_dispatch"] = default_dispatch_leg(nhp, ctx, args, sync)
-        if world == 1 and not args.no_batch:
-            try:
-                out["batch"] = batch_leg(nhp, ctx, r, args, sync)
-            except Exception as exc:        # secondary number: never take the headline down with it
-                out["batch"] = {"error": repr(exc)}
-            try:
-                out["parameters_changing_every_evaluation"] = changing_parameters_leg(nhp, ctx, r, args, sync)
-            except Exception as exc:
-                out["parameters_changing_every_evaluation"] = {"error": repr(exc)}
-        if world == 1 and args.extra:
-            others = []
-            for name in [s for s in args.extra.split(",") if s and s != args.workload]:
-                steps = max(3, args.steps // (10 if name in ("recursive", "recursive_full", "windowed_k512") else 2))
-                o = run_workload(nhp, ctx, name, args.nodes, args.events, steps, 2, sync)
-                Bo = algorithmic_bytes(o["N"], o["M"], o["kind"])
-                mk = o["dev_ms"] / steps
-                # exponential pair terms/s against the calibrated fp64-VALU ceiling (nhp_probe_rate, tools/rate.py);
-                # the recursive path evaluates 2·M·N exponentials per call
-                entry = {"workload": name, "events": o["M"], "value": steps / o["wall"], "kernel_ms": mk, "steps": steps,
-                         "pairs_per_eval": o["pairs"], "hbm_frac": Bo / (mk * 1e-3) / 1e9 / HBM_PEAK_GBS, "loglik": o["ll"]}
-                if name != "recursive":        # (the default recursive path runs a model-dependent truncated window)
-                    terms = 2.0 * o["M"] * o["N"] if name == "recursive_full" else float(o["pairs"])
-                    entry["exp_terms_per_s"] = terms / (mk * 1e-3)
-                    entry["fp64_valu_frac"] = terms / (mk * 1e-3) / EXP_TERM_CEILING
-                others.append(entry)
-            out["other_workloads"] = others
-        if world == 1 and args.configs:
-            out["configs"] = config_workloads(nhp, ctx, args.configs.split(","))
-        print(json.dumps(out))
+    # N > 1: the legs after the timed region (config 5's chains, one evaluation / one chain over all ranks) exchange through
+    # RCCL communicators of the library's own.  They are secondary numbers and must never cost the headline line: an
+    # exception is recorded in the line, and a leg that does not return (a rank stuck in a collective) is cut short by a
+    # watchdog thread that prints the line as it stands and ends the process (ctypes and torch collectives release the GIL).
+    watchdog = None
+    state = {"printed": False}
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        deadline = float(os.environ.get("NHP_BENCH_EXTRAS_DEADLINE_S", "300"))
+
+        def give_up():
+            if rank == 0 and not state["printed"]:
+                out["multi_gpu_legs"] = {"error": f"not finished within {deadline:.0f} s: cut short, headline unaffected"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(deadline + (0.0 if rank == 0 else 10.0), give_up)
+        watchdog.daemon = True
+        watchdog.start()
+    def rest():
+        chain_wall = None
+        if world > 1 and args.chain_steps > 0:
+            tw = torch.zeros(4, dtype=torch.float64, device=tdev)
+            try:
+                tw[:3] = torch.tensor(list(chains_leg(nhp, ctx, rank, args.chain_steps, sync)), dtype=torch.float64, device=tdev)
+            except Exception as exc:                # recorded below; the other ranks see the flag
+                tw[3] = 1.0
+                print(f"[rank {rank}] config-5 leg failed: {exc!r}", file=sys.stderr, flush=True)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            if float(tw[3].item()) == 0.0:
+                chain_wall, one_chain_wall, gather_wall = float(tw[0].item()), float(tw[1].item()), float(tw[2].item())
+            elif rank == 0:
+                out["config5_independent_chains"] = {"error": "a rank raised in the chains leg (stderr has the message)"}
+        sharded = None
+        if world > 1 and args.sharded:
+            try:
+                sharded = sharded_leg(nhp, ctx, args.nodes, args.events, world, [x for x in args.sharded.split(",") if x])
+            except Exception as exc:
+                sharded = {"error": repr(exc)}
+        if rank == 0:
+            if chain_wall is not None:
+                out["config5_independent_chains"] = {
+                    "workload": "c3 model (N=1024, M=1e6, logit-normal network), one mcmc! chain per rank, device-side sweep",
+                    "chains": world, "steps_per_chain": args.chain_steps,
+                    "mcmc_steps_per_sec": world * args.chain_steps / chain_wall, "ms_per_step": 1e3 * chain_wall / args.chain_steps,
+                    "rccl_gather_of_the_chains_posterior_moments_ms": 1e3 * gather_wall if gather_wall >= 0.0 else None,
+                    "one_chain_over_all_ranks_ms_per_step": 1e3 * one_chain_wall / args.chain_steps if one_chain_wall >= 0.0 else None}
+            if sharded is not None:
+                out["one_evaluation_over_all_ranks"] = sharded
+            if world == 1 and args.two_streams and not r["recursive"]:
+                try:
+                    out["two_independent_streams_on_one_gpu"] = two_streams(nhp, ctx, r, args.steps, local)
+                except Exception as exc:        # secondary number
+                    out["two_independent_streams_on_one_gpu"] = {"error": repr(exc)}
+            if world == 1 and not args.no_cpu:
+                out["cpu_baseline"] = cpu_baseline(r)
+                out["speedup_vs_cpu_core"] = out["value"] / out["cpu_baseline"]["value"]
+                if not r["recursive"]:
+                    try:
+                        out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(r)
+                        out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline_all_cores"]["value"]
+                    except Exception as exc:      # secondary number
+                        out["cpu_baseline_all_cores"] = {"error": repr(exc)}
+            if world == 1 and not args.no_default_dispatch:
+                out["default_dispatch"] = default_dispatch_leg(nhp, ctx, args, sync)
+            if world == 1 and not args.no_batch:
+                try:
+                    out["batch"] = batch_leg(nhp, ctx, r, args, sync)
+                except Exception as exc:        # secondary number: never take the headline down with it
+                    out["batch"] = {"error": repr(exc)}
+                try:
+                    out["parameters_changing_every_evaluation"] = changing_parameters_leg(nhp, ctx, r, args, sync)
+                except Exception as exc:
+                    out["parameters_changing_every_evaluation"] = {"error": repr(exc)}
+            if world == 1 and args.extra:
+                others = []
+                for name in [s for s in args.extra.split(",") if s and s != args.workload]:
+                    steps = max(3, args.steps // (10 if name in ("recursive", "recursive_full", "windowed_k512") else 2))
+                    o = run_workload(nhp, ctx, name, args.nodes, args.events, steps, 2, sync)
+                    Bo = algorithmic_bytes(o["N"], o["M"], o["kind"])
+                    mk = o["dev_ms"] / steps
+                    # exponential pair terms/s against the calibrated fp64-VALU ceiling (nhp_probe_rate, tools/rate.py);
+                    # the recursive path evaluates 2·M·N exponentials per call
+                    entry = {"workload": name, "events": o["M"], "value": steps / o["wall"], "kernel_ms": mk, "steps": steps,
+                             "pairs_per_eval": o["pairs"], "hbm_frac": Bo / (mk * 1e-3) / 1e9 / HBM_PEAK_GBS, "loglik": o["ll"]}
+                    if name != "recursive":        # (the default recursive path runs a model-dependent truncated window)
+                        terms = 2.0 * o["M"] * o["N"] if name == "recursive_full" else float(o["pairs"])
+                        entry["exp_terms_per_s"] = terms / (mk * 1e-3)
+                        entry["fp64_valu_frac"] = terms / (mk * 1e-3) / EXP_TERM_CEILING
+                    others.append(entry)
+                out["other_workloads"] = others
+            if world == 1 and args.configs:
+                out["configs"] = config_workloads(nhp, ctx, args.configs.split(","))
+            print(json.dumps(out), flush=True)
+            state["printed"] = True
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+
+    # past the headline nothing may cost the line or the exit status: rank 0 prints what it has, every rank leaves with 0
+    try:
+        rest()
+    except BaseException as exc:
+        if world == 1:
+            raise
+        print(f"[rank {rank}] after the headline: {exc!r}", file=sys.stderr, flush=True)
+        if rank == 0 and not state["printed"]:
+            out["multi_gpu_legs"] = {"error": repr(exc)}
+            print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os._exit(0)
+    if watchdog is not None:
+        watchdog.cancel()
 
 
 if __name__ == "__main__":
