@@ -222,3 +222,47 @@ def test_config4_vb_step_invariants_at_full_size(nhp, config4):
     probe.impulses.θ = np.asfortranarray(E / Wp[:, :, None])
     Z = nhp.intensity(probe, ds)                                                          # T x N
     assert np.allclose(b.αv, b.α0 + e0 * (data.T / Z).sum(axis=0), rtol=1e-10)          # src/baselines.jl:444-452
+
+
+# ---------------------------------------------------------------------------------------------- metric size, default dispatch
+def test_default_dispatch_routes_agree_at_the_metric_size(nhp, orc):
+    """`loglikelihood(process, data)` is `recursive=true` in the reference (src/continuous.jl:210-214,241-276): the O(M·N)
+    recursion over the full history.  At N = 1024, M = 1e6 the oracle needs ~20 s per evaluation, so the check is by
+    properties: (1) the recursion itself (k_recursive_waves, forced through the C ABI) and the library's default route
+    (the 2^-60 truncated window) give the same log-likelihood and the same 2.1e6-entry gradient; (2) the recursion has no
+    look-ahead, so a prefix of the events is a complete problem: its value and gradient equal the oracle's literal
+    recursion on that prefix."""
+    import ctypes as C
+    from nhp_amd import _lib
+    N, M = 1024, 1_000_000
+    times, nodes, T = nhp.synthetic.s_metric_data(N, M, kbar=8.0)
+    proc = nhp.synthetic.s_metric_process(N, M, T, "exponential", 1.0)
+    ctx = nhp.default_context()
+    P = N + 2 * N * N
+    full = _lib.LL_RECURSIVE | _lib.LL_FULL_RECURSION
+
+    def both(data, flags):
+        ds = nhp.device_dataset(proc, data, ctx)
+        model = proc.device_model(ctx)
+        ll, g = C.c_double(), np.empty(P)
+        _lib.check(_lib.lib().nhp_cont_loglik_grad(ctx.h, ds.h, model.h, flags, C.byref(ll), _lib.dptr(g), P), ctx.h)
+        l2 = C.c_double()
+        _lib.check(_lib.lib().nhp_cont_loglik(ctx.h, ds.h, model.h, flags, C.byref(l2)), ctx.h)
+        assert rel(l2.value, ll.value) < 1e-13          # the log-likelihood pass alone = the one inside the gradient call
+        return ll.value, g
+
+    data = (times, nodes, T)
+    ll_rec, g_rec = both(data, full)
+    ll_def, g_def = both(data, _lib.LL_RECURSIVE)
+    assert rel(ll_rec, ll_def) < 1e-12
+    assert np.max(np.abs(g_rec - g_def) / np.maximum(1.0, np.abs(g_def))) < 1e-9
+    assert np.isfinite(g_rec).all()
+
+    m = 20_000                                                       # 2·m·N = 4e7 exponentials in the oracle
+    sub = (times[:m].copy(), nodes[:m].copy(), float(times[m - 1]))
+    om = orc.ContModel(proc.baseline.λ, proc.weights.W, theta=proc.impulses.θ, dt_max=1.0)
+    ll_sub, g_sub = both(sub, full)
+    wll, wg = orc.loglik_grad(om, sub[0], sub[1], sub[2], recursive=True)
+    assert rel(ll_sub, orc.loglik_recursive(om, *sub)) < 1e-11
+    assert rel(ll_sub, wll) < 1e-11
+    assert np.max(np.abs(g_sub - wg) / np.maximum(1.0, np.abs(wg))) < 1e-9
