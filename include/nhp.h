@@ -404,6 +404,20 @@ nhp_status nhp_cont_mcmc_run(nhp_ctx *ctx, nhp_comm *comm /* nullable */, const 
                              const nhp_gibbs_priors *priors, double net_alpha, double net_beta, uint64_t seed,
                              uint64_t step0, int64_t n_steps, int64_t burn);
 
+/* mle!(process, data; f_abstol, guess) (src/continuous.jl:144-198) with the optimizer's state on the device: minimises
+ * -loglikelihood(process, data) over params(process) = [λ0 | grid intensities; θ | μ, τ; W] on the reference's box
+ * [lower, upper]^P (1e-6, 10: src/continuous.jl:185-186) by projected L-BFGS fed the analytic gradient; the iterate,
+ * gradient and history stay in HBM, the host reads scalars.  Stops by the reference's callback rule
+ * |f_k - f_{k-1}| < f_abstol (src/continuous.jl:168-181) or at a stationary point of the box problem (*converged = 1),
+ * after max_steps iterations or when no step decreases the objective (*converged = 0).  x [P]: the guess on entry
+ * (clamped to the box), the minimiser on return; the device-resident `model` holds it too (params!(process, x)).
+ * flags: NHP_LL_RECURSIVE as for nhp_cont_loglik (the reference's objective calls loglikelihood with its default).
+ * comm (nullable): `ds` is this rank's column shard, [ll; ∇ll] is summed over the ranks on the device per evaluation and
+ * every rank runs the same iteration.  *evals (nullable): objective + gradient evaluations spent.  Standard process only. */
+nhp_status nhp_cont_mle_run(nhp_ctx *ctx, nhp_comm *comm /* nullable */, const nhp_cont_dataset *ds, nhp_cont_model *model, int32_t flags,
+                            double lower, double upper, double f_abstol, int32_t max_steps, double *x, int64_t len,
+                            double *loss, int32_t *steps, int32_t *converged, int32_t *evals);
+
 #ifdef __cplusplus
 }
 #endif

@@ -166,7 +166,25 @@ extern "C" nhp_status nhp_cont_loglik_allreduce(nhp_ctx *ctx, nhp_comm *comm, co
     return nhp_ctx_fetch(ctx, 0, 1, ll);
 }
 
+
 __global__ void k_pack_ll(const double *__restrict__ res, double *__restrict__ dst) { *dst = *res; }
+
+// log-likelihood -> ctx->d_results[0] and gradient -> *d_grad, both left on the device; with a communicator the shards'
+// [ll; grad] are summed over the ranks first (one collective of P + 1 doubles).  Asynchronous.
+nhp_status nhp_grad_enqueue_reduced(nhp_ctx *ctx, nhp_comm *comm, const nhp_cont_dataset *ds, const nhp_cont_model *m, int32_t flags,
+                                    int64_t grad_len, double **d_grad_out)
+{
+    double *d_grad = nullptr;
+    NHP_TRY(nhp_grad_enqueue(ctx, ds, m, flags, grad_len, &d_grad));
+    *d_grad_out = d_grad;
+    if (!comm) return NHP_OK;
+    NHP_TRY(check_comm(ctx, comm));
+    hipLaunchKernelGGL(k_pack_ll, dim3(1), dim3(1), 0, ctx->stream, ctx->d_results, d_grad - 1);
+    NHP_HIP(ctx, hipGetLastError());
+    NHP_TRY(nhp_comm_allreduce_dev(ctx, comm, d_grad - 1, (size_t)grad_len + 1));
+    NHP_HIP(ctx, hipMemcpyAsync(ctx->d_results, d_grad - 1, 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return NHP_OK;
+}
 
 extern "C" nhp_status nhp_cont_loglik_grad_allreduce(nhp_ctx *ctx, nhp_comm *comm, const nhp_cont_dataset *ds,
                                                      const nhp_cont_model *m, int32_t flags, double *ll, double *grad,
@@ -175,12 +193,7 @@ extern "C" nhp_status nhp_cont_loglik_grad_allreduce(nhp_ctx *ctx, nhp_comm *com
     NHP_TRY(check_comm(ctx, comm));
     if (!ll || !grad) return NHP_EINVAL;
     double *d_grad = nullptr;
-    NHP_TRY(nhp_grad_enqueue(ctx, ds, m, flags, grad_len, &d_grad));
-    // [ll; grad] contiguous: one collective of P + 1 doubles
-    hipLaunchKernelGGL(k_pack_ll, dim3(1), dim3(1), 0, ctx->stream, ctx->d_results, d_grad - 1);
-    NHP_HIP(ctx, hipGetLastError());
-    NHP_TRY(nhp_comm_allreduce_dev(ctx, comm, d_grad - 1, (size_t)grad_len + 1));
-    NHP_HIP(ctx, hipMemcpyAsync(ctx->d_results, d_grad - 1, 8, hipMemcpyDeviceToDevice, ctx->stream));
+    NHP_TRY(nhp_grad_enqueue_reduced(ctx, comm, ds, m, flags, grad_len, &d_grad));
     NHP_TRY(nhp_download(ctx, grad, d_grad, 8 * (size_t)grad_len));
     return nhp_ctx_fetch(ctx, 0, 1, ll);
 }

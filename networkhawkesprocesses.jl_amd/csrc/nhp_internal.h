@@ -180,6 +180,9 @@ nhp_status nhp_comm_allgather_dev(nhp_ctx *ctx, nhp_comm *comm, const double *d_
 // spare double in front of it at (*d_grad)[-1] for the packed [ll; grad] exchange)
 nhp_status nhp_grad_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, int32_t flags, int64_t grad_len,
                             double **d_grad);
+// comm.hip: the same, with the shards' [ll; grad] summed over the ranks on the device when `comm` is given (nullable)
+nhp_status nhp_grad_enqueue_reduced(nhp_ctx *ctx, nhp_comm *comm, const nhp_cont_dataset *ds, const nhp_cont_model *m, int32_t flags,
+                                    int64_t grad_len, double **d_grad);
 // cont_adjacency.hip: enqueue one sweep of A; per-column link counts land at *d_links [N] (scratch)
 nhp_status nhp_adj_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_model *m, const double *rho_matrix, double rho,
                            const double *d_rho_scalar, const double *u, uint64_t seed, uint64_t step, double **d_links);
