@@ -324,6 +324,34 @@ def changing_parameters_leg(nhp, ctx, r, args, sync):
                                                         "bytes_uploaded_per_evaluation": int(8 * len(x)), "loglik": float(ll[0])}}
 
 
+def mle_leg(nhp, ctx, args):
+    """mle!(process, data) end to end on the metric dataset (src/continuous.jl:144-198): iterations of the device-resident
+    optimizer (nhp_cont_mle_run: every objective + gradient evaluation reads parameters the previous iteration wrote ON THE
+    DEVICE -- SURVEY 8d's "parameters changing every evaluation, device-updated") next to the host route (scipy L-BFGS-B on
+    the same analytic gradient: x up, gradient down and a host-side update of 2.1e6-vectors per objective call)."""
+    import numpy as np
+    N, M = args.nodes, args.events
+    times, nodes, T = nhp.synthetic.s_metric_data(N, M, kbar=8.0)
+    out = {"workload": f"mle! on the metric dataset (N={N}, M={M}, exponential, mean window 8), start = the generating parameters "
+                       "perturbed by U(0.5, 1.5), box [1e-6, 10]"}
+    for name, recursive, opt, steps in (("device_optimizer", False, "device", 30), ("device_optimizer_recursive_objective", True, "device", 15),
+                                        ("host_optimizer", False, "L-BFGS-B", 3)):
+        proc = nhp.synthetic.s_metric_process(N, M, T, "exponential", 1.0)
+        guess = np.clip(proc.params() * np.random.default_rng(9).uniform(0.5, 1.5, len(proc.params())), 1e-6, 10.0)
+        nhp.device_dataset(proc, (times, nodes, T), ctx)
+        t0 = time.perf_counter()
+        res = nhp.mle_(proc, (times, nodes, T), guess=guess, recursive=recursive, f_abstol=1e-12, max_steps=steps, optimizer=opt, ctx=ctx)
+        dt = time.perf_counter() - t0
+        e = {"steps": res.steps, "ms_per_step": 1e3 * dt / max(1, res.steps), "loglik_reached": res.maximum, "parameters": len(guess)}
+        ev = getattr(res, "evaluations", None)
+        if ev is not None:
+            e["objective_and_gradient_evaluations"] = ev
+            e["evaluations_per_sec_parameters_updated_on_the_device"] = ev / dt
+        out[name] = e
+    out["host_over_device_ms_per_step"] = out["host_optimizer"]["ms_per_step"] / out["device_optimizer"]["ms_per_step"]
+    return out
+
+
 def config_workloads(nhp, ctx, which):
     """BASELINE.json configs[1..3] as secondary measurements (one GPU): wall time per call through
     the host mirror, i.e. including parameter upload and result download."""
@@ -698,6 +726,10 @@ def main():
                     out["parameters_changing_every_evaluation"] = changing_parameters_leg(nhp, ctx, r, args, sync)
                 except Exception as exc:
                     out["parameters_changing_every_evaluation"] = {"error": repr(exc)}
+                try:
+                    out["mle"] = mle_leg(nhp, ctx, args)
+                except Exception as exc:
+                    out["mle"] = {"error": repr(exc)}
             if world == 1 and args.extra:
                 others = []
                 for name in [s for s in args.extra.split(",") if s and s != args.workload]:

@@ -284,12 +284,33 @@ end
 
 # --- mle!(process, data; optimizer=BFGS, verbose=false, f_abstol=1e-6, regularize=false, guess=nothing)
 #     -> MaximumLikelihood   src/continuous.jl:144-198 ------------------------------------------------------------
-# Extra keywords (not in the reference): recursive (the loglikelihood dispatch), ctx / ds / comm (device handles).
+# Extra keywords (not in the reference): recursive (the loglikelihood dispatch), ctx / ds / comm (device handles), max_steps
+# and optimizer=:device (the whole iteration inside the library, nhp_cont_mle_run).
 function mle!(p::NHP.ContinuousStandardHawkesProcess, data; optimizer=Optim.BFGS, verbose=false, f_abstol=1e-6, regularize=false,
-              guess=nothing, recursive=true, ctx=context(), comm=nothing, ds=Dataset(ctx, data, NHP.ndims(p), p.impulses.Δtmax))
+              guess=nothing, recursive=true, ctx=context(), comm=nothing, max_steps=1000,
+              ds=Dataset(ctx, data, NHP.ndims(p), p.impulses.Δtmax))
     guess = guess === nothing ? NHP._rand_init_(p) : guess
     P = length(guess)
     flags = llflags(p, recursive)
+    if optimizer === :device
+        # the optimizer's state on the device (nhp_cont_mle_run: projected L-BFGS in HBM on the same box [1e-6, 10], the same
+        # |f_k - f_{k-1}| < f_abstol rule; the host reads scalars).  At 2.1e6 parameters one step costs milliseconds instead
+        # of the parameter upload + gradient download + host-side quasi-Newton update of the Optim route.
+        regularize && error("optimizer=:device minimises -loglikelihood only; use an Optim optimizer with regularize=true")
+        x = clamp.(Vector{Float64}(guess), 1e-6, 1e1)
+        loss, steps, conv, evals = Ref{Float64}(0.0), Ref{Int32}(0), Ref{Int32}(0), Ref{Int32}(0)
+        t0 = time()
+        with_model(ctx, p) do m
+            check(ccall((:nhp_cont_mle_run, libnhp), Int32,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float64, Float64, Float64, Int32, Ptr{Float64}, Int64,
+                 Ref{Float64}, Ref{Int32}, Ref{Int32}, Ref{Int32}),
+                ctx.h, comm === nothing ? C_NULL : comm.h, ds.h, m, flags, 1e-6, 1e1, f_abstol, Int32(max_steps), x, P,
+                loss, steps, conv, evals), ctx.h)
+        end
+        verbose && println(" > steps: $(steps[]), objective evaluations: $(evals[]), loss: $(loss[])")
+        NHP.params!(p, x)
+        return NHP.MaximumLikelihood(x, -loss[], Int(steps[]), time() - t0, conv[] == 1 ? "success" : "failure")
+    end
     res = with_model(ctx, p) do m
         ll, g = Ref{Float64}(0.0), Vector{Float64}(undef, P)
         function fg!(G, x)

@@ -43,6 +43,15 @@ CHILD = textwrap.dedent('''
         wll, wg = nhp.loglikelihood_gradient(c["proc"], c["data"], recursive=rec)
         # (columns cut into several work items add their gradient parts with atomics: equal to rounding, not bitwise)
         assert ll == wll and np.allclose(g, wg, rtol=1e-12, atol=1e-12)
+    # mle! with the optimizer on the device, [ll; grad] all-reduced per evaluation == the same run without a communicator
+    m1 = random_case(6, 3000, 200.0, "exponential", 1.0, seed=7, nhp=nhp)
+    m2 = random_case(6, 3000, 200.0, "exponential", 1.0, seed=7, nhp=nhp)
+    guess = np.random.default_rng(1).uniform(0.2, 0.8, len(m1["proc"].params()))
+    # (a few steps: the shard's gradient differs from the whole dataset's in the last bits -- atomics -- and an optimizer
+    # amplifies that over hundreds of iterations)
+    r1 = nhp.mle_(m1["proc"], nhp.ShardedDataset(m1["proc"], m1["data"], ctx), guess=guess, optimizer="device", max_steps=6)
+    r2 = nhp.mle_(m2["proc"], m2["data"], guess=guess, optimizer="device", max_steps=6)
+    assert r1.steps == r2.steps == 6 and np.allclose(r1.maximizer, r2.maximizer, rtol=1e-7, atol=1e-10) and rel(r1.maximum, r2.maximum) < 1e-9
     # one network chain through nhp_cont_mcmc_run with the communicator == the same chain without it
     a = random_case(6, 3000, 200.0, "logitnormal", 1.0, network=True, seed=5, nhp=nhp)
     b = random_case(6, 3000, 200.0, "logitnormal", 1.0, network=True, seed=5, nhp=nhp)
