@@ -418,6 +418,14 @@ nhp_status nhp_cont_mle_run(nhp_ctx *ctx, nhp_comm *comm /* nullable */, const n
                             double lower, double upper, double f_abstol, int32_t max_steps, double *x, int64_t len,
                             double *loss, int32_t *steps, int32_t *converged, int32_t *evals);
 
+/* mle!(process::DiscreteStandardHawkesProcess, data; f_abstol, guess) (src/discrete.jl:211-296) the same way: x = params(process)
+ * = [λ0; vec(W .* θ)] (src/discrete.jl:178-182; homogeneous baseline), the objective -loglikelihood(process, data, convolved) with
+ * params!'s split W = Σ_b, θ = x ./ W (:195-203) redone on the device per evaluation, its gradient from the two GEMMs of
+ * nhp_disc_loglik_grad, the box and the |f_k - f_{k-1}| < f_abstol rule of the callback (:247-258; a monotone line search never
+ * meets its loss-increase rule).  nhp_disc_convolve must have run on `data`. */
+nhp_status nhp_disc_mle_run(nhp_ctx *ctx, const nhp_disc_dataset *data, double dt, double lower, double upper, double f_abstol,
+                            int32_t max_steps, double *x, int64_t len, double *loss, int32_t *steps, int32_t *converged, int32_t *evals);
+
 #ifdef __cplusplus
 }
 #endif

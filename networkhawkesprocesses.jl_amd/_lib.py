@@ -79,6 +79,8 @@ def _declare(lib):
     f("nhp_cont_network_sweep", i32, _vp, _vp, _vp, u64, u64, _dp)
     f("nhp_cont_network_rho", i32, _vp, _vp, dbl, dbl, dbl, dbl, u64, u64)
     f("nhp_cont_mcmc_run", i32, _vp, _vp, _vp, _vp, C.POINTER(GibbsPriors), dbl, dbl, u64, u64, i64, i64)
+    f("nhp_disc_mle_run", i32, _vp, _vp, dbl, dbl, dbl, dbl, i32, _dp, i64, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+      C.POINTER(C.c_int32))
     f("nhp_cont_mle_run", i32, _vp, _vp, _vp, _vp, i32, dbl, dbl, dbl, i32, _dp, i64, C.POINTER(C.c_double), C.POINTER(C.c_int32),
       C.POINTER(C.c_int32), C.POINTER(C.c_int32))
     f("nhp_ctx_create", i32, i32, C.POINTER(_vp))

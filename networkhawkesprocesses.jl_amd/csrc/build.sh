@@ -17,7 +17,7 @@ for f in *.hip; do
   o=$BUILD/${f%.hip}.o
   stale=0
   [ -f "$o" ] || stale=1
-  for dep in "$f" nhp_internal.h nhp_math.h nhp_rng.h ../../include/nhp.h; do [ "$dep" -nt "$o" ] && stale=1; done
+  for dep in "$f" nhp_internal.h nhp_math.h nhp_rng.h nhp_lbfgs.h ../../include/nhp.h; do [ "$dep" -nt "$o" ] && stale=1; done
   if [ $stale = 1 ]; then
     hipcc $FLAGS -c "$f" -o "$o" &
     pids+=($!)

@@ -1078,50 +1078,60 @@ __global__ __launch_bounds__(256) void k_disc_grad_finish(int N, int B, int spli
     }
 }
 
-extern "C" nhp_status nhp_disc_loglik_grad(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
-                                           const double *W, const double *theta, double dt, double *ll, double *grad,
-                                           int64_t grad_len)
+// Sizes of one (log-likelihood, gradient) evaluation and its scratch behind the bump table
+struct disc_grad_plan {
+    size_t N, NN, B, K, T, G, nbase;
+    int bm, row_blocks, splits, k_chunk;
+    size_t extra() const { return T * N + (size_t)row_blocks * N + (size_t)splits * K * N + nbase + NN * B + G; }
+};
+
+static disc_grad_plan disc_grad_sizes(nhp_ctx *ctx, const nhp_disc_dataset *ds, bool homogeneous)
 {
-    if (!ctx || !ds || !ll || !grad) return NHP_EINVAL;
-    NHP_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t N = (size_t)ds->N, NN = N * N, B = (size_t)ds->B, K = N * B, T = (size_t)ds->T;
-    const size_t G = lambda0 ? 0 : ds->h_grid_x.size();
-    const size_t nbase = lambda0 ? N : G * N;                    // params(baseline): λ or vec(λ) (G x N)
-    if ((size_t)grad_len != nbase + NN * B) { nhp_set_error(ctx, "Parameter vector length does not match model parameter length."); return NHP_ESHAPE; }
-    if (!ds->d_convsum) { nhp_set_error(ctx, "convolve(process, data) must run before the gradient"); return NHP_EINVAL; }
-    const int bm = gemm1_tile_m((int64_t)T, (int)N, ctx->cu_count);
-    const int row_blocks = (int)((T + bm - 1) / bm);
-    const int tiles2 = (int)(((K + BM - 1) / BM) * ((N + BN - 1) / BN));
+    disc_grad_plan q{};
+    q.N = (size_t)ds->N; q.NN = q.N * q.N; q.B = (size_t)ds->B; q.K = q.N * q.B; q.T = (size_t)ds->T;
+    q.G = homogeneous ? 0 : ds->h_grid_x.size();
+    q.nbase = homogeneous ? q.N : q.G * q.N;                     // params(baseline): λ or vec(λ) (G x N)
+    q.bm = gemm1_tile_m((int64_t)q.T, (int)q.N, ctx->cu_count);
+    q.row_blocks = (int)((q.T + q.bm - 1) / q.bm);
+    const int tiles2 = (int)(((q.K + BM - 1) / BM) * ((q.N + BN - 1) / BN));
     int splits = (2 * ctx->cu_count + tiles2 - 1) / tiles2;
-    splits = std::max(1, std::min(splits, (int)((T + 4 * BK - 1) / (4 * BK))));
-    int k_chunk = (int)((T + splits - 1) / splits);
+    splits = std::max(1, std::min(splits, (int)((q.T + 4 * BK - 1) / (4 * BK))));
+    int k_chunk = (int)((q.T + splits - 1) / splits);
     k_chunk = ((k_chunk + BK - 1) / BK) * BK;
-    splits = (int)((T + k_chunk - 1) / k_chunk);
-    double *E, *base, *x;
-    NHP_TRY(nhp_disc_stage_bump(ctx, ds, lambda0, W, theta, nullptr, dt, &E, &base, T * N + (size_t)row_blocks * N + (size_t)splits * K * N + nbase + NN * B + G, &x));
+    q.k_chunk = k_chunk;
+    q.splits = (int)((q.T + k_chunk - 1) / k_chunk);
+    return q;
+}
+
+// log-likelihood -> ctx->d_results[0], gradient in [params(baseline); vec(W .* θ)] order -> *dgrad_out (inside `x`, the
+// scratch behind the bump table E / base); asynchronous
+static nhp_status disc_grad_enqueue(nhp_ctx *ctx, const nhp_disc_dataset *ds, const disc_grad_plan &q, bool homogeneous, const double *E,
+                                    const double *base, double *x, double dt, double **dgrad_out)
+{
+    const size_t N = q.N, NN = q.NN, B = q.B, K = q.K, T = q.T, G = q.G, nbase = q.nbase;
     double *dR = x; x += T * N;
-    double *dcolp = x; x += (size_t)row_blocks * N;
-    double *dslab = x; x += (size_t)splits * K * N;
+    double *dcolp = x; x += (size_t)q.row_blocks * N;
+    double *dslab = x; x += (size_t)q.splits * K * N;
     double *dgrad = x;
     hipStream_t st = ctx->stream;
     // GEMM-1 once, with both epilogues: the Poisson log-likelihood partials AND R = data / Z with its column sums
     gemm_args g{};
     g.A = ds->d_conv; g.lda = T; g.B = E; g.ldb = K; g.M = (int)T; g.N = (int)N; g.K = (int)K; g.k_chunk = (int)K;
-    g.base = base; g.baseT = lambda0 ? nullptr : ds->d_baseT; g.dataT = ds->d_dataT;
-    const int blocks = ((g.M + bm - 1) / bm) * ((g.N + BN - 1) / BN);
+    g.base = base; g.baseT = homogeneous ? nullptr : ds->d_baseT; g.dataT = ds->d_dataT;
+    const int blocks = ((g.M + q.bm - 1) / q.bm) * ((g.N + BN - 1) / BN);
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)blocks));
     g.partials2 = ctx->d_partials;
     g.out = dR; g.partials = dcolp;
-    launch_gemm<true, EPI_GRAD>(g, 1, st, bm);
+    launch_gemm<true, EPI_GRAD>(g, 1, st, q.bm);
     hipLaunchKernelGGL(k_sum_pairs, dim3(1), dim3(256), 0, st, ctx->d_partials, blocks, ds->lgamma_sum, ctx->d_results);
     // then Gᵀ·R in T-slabs
     gemm_args g2{};
-    g2.A = ds->d_conv; g2.lda = T; g2.B = dR; g2.ldb = T; g2.M = (int)K; g2.N = (int)N; g2.K = (int)T; g2.k_chunk = k_chunk;
+    g2.A = ds->d_conv; g2.lda = T; g2.B = dR; g2.ldb = T; g2.M = (int)K; g2.N = (int)N; g2.K = (int)T; g2.k_chunk = q.k_chunk;
     g2.out = dslab;
-    launch_gemm<false, EPI_SLAB>(g2, splits, st);
-    hipLaunchKernelGGL(k_disc_grad_finish, dim3((unsigned)((NN * B + 255) / 256)), dim3(256), 0, st, (int)N, (int)B, splits, row_blocks,
+    launch_gemm<false, EPI_SLAB>(g2, q.splits, st);
+    hipLaunchKernelGGL(k_disc_grad_finish, dim3((unsigned)((NN * B + 255) / 256)), dim3(256), 0, st, (int)N, (int)B, q.splits, q.row_blocks,
                        dt, (double)T, dslab, dcolp, ds->d_convsum, dgrad + (nbase - N));
-    if (!lambda0) {
+    if (!homogeneous) {
         // LGCP: ∂λ_base[t,c]/∂λgrid[g,c] = dt·w_g(t) (interpolation weights at bin time t+1), so the baseline block
         // is dt Σ_t (R - 1)[t,c] w_g -- it overwrites the N homogeneous entries k_disc_grad_finish left at its end
         double *dgx = dgrad + nbase + NN * B;
@@ -1131,8 +1141,73 @@ extern "C" nhp_status nhp_disc_loglik_grad(nhp_ctx *ctx, const nhp_disc_dataset 
                            dgx, dt, dgrad);
     }
     NHP_HIP(ctx, hipGetLastError());
-    NHP_HIP(ctx, hipMemcpyAsync(grad, dgrad, 8 * (nbase + NN * B), hipMemcpyDeviceToHost, st));
+    *dgrad_out = dgrad;
+    return NHP_OK;
+}
+
+extern "C" nhp_status nhp_disc_loglik_grad(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
+                                           const double *W, const double *theta, double dt, double *ll, double *grad,
+                                           int64_t grad_len)
+{
+    if (!ctx || !ds || !ll || !grad) return NHP_EINVAL;
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    const disc_grad_plan q = disc_grad_sizes(ctx, ds, lambda0 != nullptr);
+    if ((size_t)grad_len != q.nbase + q.NN * q.B) { nhp_set_error(ctx, "Parameter vector length does not match model parameter length."); return NHP_ESHAPE; }
+    if (!ds->d_convsum) { nhp_set_error(ctx, "convolve(process, data) must run before the gradient"); return NHP_EINVAL; }
+    double *E, *base, *x, *dgrad;
+    NHP_TRY(nhp_disc_stage_bump(ctx, ds, lambda0, W, theta, nullptr, dt, &E, &base, q.extra(), &x));
+    NHP_TRY(disc_grad_enqueue(ctx, ds, q, lambda0 != nullptr, E, base, x, dt, &dgrad));
+    NHP_HIP(ctx, hipMemcpyAsync(grad, dgrad, 8 * (q.nbase + q.NN * q.B), hipMemcpyDeviceToHost, ctx->stream));
     return nhp_ctx_fetch(ctx, 0, 1, ll);
+}
+
+// ---- mle!(process::DiscreteStandardHawkesProcess, data) with the optimizer's state on the device (src/discrete.jl:211-296) ----
+// x = params(process) = [λ0; vec(W .* θ)] (src/discrete.jl:178-182).  params!(process, x) (:195-203) splits the second block
+// into W = Σ_b x[p,c,b] and θ = x ./ W, and the objective's bump is (W·θ)·dt (:381-385): the same three roundings here, from
+// the DEVICE vector.  E[k + c·K], k = p + b·N; base[c] = λ0[c]·dt.
+__global__ __launch_bounds__(256) void k_disc_bump_from_x(int N, int B, double dt, const double *__restrict__ x, double *__restrict__ E,
+                                                          double *__restrict__ base)
+{
+#pragma clang fp contract(off)
+    const size_t NN = (size_t)N * N, K = (size_t)N * B;
+    const size_t pc = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (pc < NN) {
+        const size_t p = pc % N, c = pc / N;
+        const double *xw = x + N;
+        double w = 0.0;
+        for (int b = 0; b < B; ++b) w += xw[pc + (size_t)b * NN];
+        for (int b = 0; b < B; ++b) {
+            const double th = xw[pc + (size_t)b * NN] / w;
+            E[p + (size_t)b * N + c * K] = (w * th) * dt;
+        }
+    }
+    if (pc < (size_t)N) base[pc] = x[pc] * dt;
+}
+
+#include "nhp_lbfgs.h"
+
+extern "C" nhp_status nhp_disc_mle_run(nhp_ctx *ctx, const nhp_disc_dataset *ds, double dt, double lower, double upper, double f_abstol,
+                                       int32_t max_steps, double *x, int64_t P, double *loss, int32_t *steps_out, int32_t *converged_out,
+                                       int32_t *evals_out)
+{
+    if (!ctx || !ds || !x || !loss || !steps_out || !converged_out) return NHP_EINVAL;
+    if (!(lower < upper) || max_steps < 0 || !(dt > 0.0)) return NHP_EDOMAIN;
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ds->d_conv || !ds->d_convsum) { nhp_set_error(ctx, "convolve(process, data) must run before mle!"); return NHP_EINVAL; }
+    const disc_grad_plan q = disc_grad_sizes(ctx, ds, true);
+    if ((size_t)P != q.nbase + q.NN * q.B) { nhp_set_error(ctx, "Parameter vector length does not match model parameter length."); return NHP_ESHAPE; }
+    // scratch: E | base | the evaluation's buffers (nhp_disc_stage_bump's layout without its host-side copies)
+    NHP_TRY(nhp_ctx_reserve_scratch(ctx, 8 * (q.K * q.N + q.N + q.extra())));
+    auto eval = [&](const double *d_x, double *d_g) -> nhp_status {
+        hipStream_t st = ctx->stream;
+        double *E = (double *)ctx->d_scratch, *base = E + q.K * q.N, *xs = base + q.N, *dgrad = nullptr;
+        hipLaunchKernelGGL(k_disc_bump_from_x, dim3((unsigned)((q.NN + 255) / 256)), dim3(256), 0, st, (int)q.N, (int)q.B, dt, d_x, E, base);
+        NHP_TRY(disc_grad_enqueue(ctx, ds, q, true, E, base, xs, dt, &dgrad));
+        hipLaunchKernelGGL(k_mle_neg, dim3((unsigned)std::min<int64_t>(2048, (P + 255) / 256)), dim3(256), 0, st, d_g, (const double *)dgrad, P);
+        NHP_HIP(ctx, hipGetLastError());
+        return NHP_OK;
+    };
+    return nhp_lbfgs_box(ctx, P, lower, upper, f_abstol, max_steps, eval, x, loss, steps_out, converged_out, evals_out);
 }
 
 // (nhp_disc_vb_run is declared in include/nhp.h)

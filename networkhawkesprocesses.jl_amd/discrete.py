@@ -424,6 +424,22 @@ def disc_mle_(process, data, optimizer="L-BFGS-B", verbose=False, f_abstol=1e-6,
     state = {"minloss": np.inf, "steps": 0, "converged": False, "last": None}
     start = time.time()
 
+    if optimizer in ("device", "LBFGS-device"):
+        # the optimizer's state on the device (nhp_disc_mle_run: projected L-BFGS in HBM; params!'s split of x into W and θ
+        # redone on the device per evaluation): no parameter upload, gradient download or host-side update per objective call
+        if isinstance(process.baseline, DiscreteLogGaussianCoxProcess):
+            raise NotImplementedError("optimizer='device' takes the homogeneous baseline; use the host optimizer with an LGCP baseline")
+        x = np.ascontiguousarray(np.clip(x0, lower, upper), dtype=np.float64)
+        loss, steps, conv, evals = C.c_double(), C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib().nhp_disc_mle_run(ctx.h, ds.h, process.dt, lower, upper, float(f_abstol), int(max_steps), _lib.dptr(x), len(x),
+                                               C.byref(loss), C.byref(steps), C.byref(conv), C.byref(evals)), ctx.h)
+        if verbose:
+            print(f" > steps: {steps.value}, objective evaluations: {evals.value}, loss: {loss.value}, elapsed: {time.time() - start}")
+        disc_params_(process, x)
+        res = MaximumLikelihood(x.copy(), -float(loss.value), int(steps.value), time.time() - start, "success" if conv.value else "failure")
+        res.evaluations = int(evals.value)
+        return res
+
     def fg(x):
         disc_params_(process, x)
         ll, g = disc_loglikelihood_gradient(process, convolved=ds, ctx=ctx)

@@ -181,6 +181,45 @@ def test_discrete_mle_finds_the_rates_of_independent_poisson_data(nhp):
         nhp.mle_(proc, data, regularize=True)
 
 
+def test_discrete_device_mle_reaches_a_maximum_the_host_optimizer_cannot_improve(nhp, orc):
+    # nhp_disc_mle_run (projected L-BFGS with its state in HBM; params!'s split of x into W and θ redone on the device) against
+    # scipy's L-BFGS-B on the same analytic gradient and box: the answer is a local maximum -- zero projected gradient, the host
+    # optimizer started there gains nothing -- the process holds it, its value is the oracle's, the independent-Poisson rates
+    # are recovered, and a problem with real excitation (N = 6, B = 3) ends as high as the host route from the same start.
+    rng = np.random.default_rng(3)
+    N, T, B, L = 2, 20000, 2, 4
+    true = np.array([0.2, 0.6])
+    data = rng.poisson(true[:, None] * np.ones((N, T))).astype(np.int64)
+
+    def fresh(N, B, L):
+        return nhp.DiscreteStandardHawkesProcess(nhp.DiscreteHomogeneousProcess(np.ones(N), 1.0),
+                                                 nhp.DiscreteGaussianImpulseResponse(np.full((N, N, B), 1.0 / B), L, 1.0),
+                                                 nhp.DenseWeightModel(np.full((N, N), 0.1)), 1.0)
+    proc = fresh(N, B, L)
+    res = nhp.mle_(proc, data, seed=1, optimizer="device", f_abstol=1e-9)
+    assert res.status == "success"
+    x = res.maximizer
+    assert np.all(x >= 1e-6) and np.all(x <= 10.0) and np.array_equal(proc.params(), nhp.discrete.disc_params_(fresh(N, B, L), x))
+    ll, g = nhp.loglikelihood_gradient(proc, data)
+    assert abs(ll - res.maximum) < 1e-9 * abs(ll)
+    pg = np.where(((x <= 1e-6) & (g < 0)) | ((x >= 10.0) & (g > 0)), 0.0, g)
+    assert np.max(np.abs(pg)) < 5e-2 * abs(ll) ** 0.5
+    W = proc.weights.W
+    assert np.all(W < 0.1) and np.all(np.abs(proc.baseline.λ / (1 - W.sum(axis=0)) - true) / true < 0.1)
+    conv = orc.disc_convolve(data, proc.impulses.basis())
+    assert abs(orc.disc_loglik(data, orc.disc_intensity(conv, proc.baseline.λ, W, proc.impulses.θ, 1.0)) - res.maximum) < 1e-9 * abs(ll)
+    polish = nhp.mle_(fresh(N, B, L), data, guess=x, f_abstol=1e-9)
+    assert polish.maximum - res.maximum < 1e-4 * abs(ll) ** 0.5
+    # excitation present
+    p6, d6, *_ = make(nhp, 6, 4000, 3, 5, seed=8)
+    guess = np.concatenate([rng.uniform(0.05, 0.3, 6), rng.uniform(0.005, 0.05, 6 * 6 * 3)])
+    import copy
+    a, b = copy.deepcopy(p6), copy.deepcopy(p6)
+    dev = nhp.mle_(a, d6, guess=guess, optimizer="device", f_abstol=1e-9, max_steps=3000)
+    host = nhp.mle_(b, d6, guess=guess, f_abstol=1e-9, max_steps=3000)
+    assert dev.status == "success" and dev.maximum >= host.maximum - 1e-3 * abs(host.maximum) ** 0.5
+
+
 @pytest.mark.parametrize("N,T,B,L", [(5, 300, 3, 7), (130, 997, 2, 3)])
 def test_both_gemm_tile_heights_agree(nhp, orc, N, T, B, L, monkeypatch):
     """GEMM-1 picks 128- or 160-row output tiles by how they fill the last round of workgroups (gemm1_tile_m); both give
