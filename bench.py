@@ -454,11 +454,21 @@ def config_workloads(nhp, ctx, which):
         net = nhp.DiscreteNetworkHawkesProcess(proc.baseline, imp, proc.weights, (rng.uniform(size=(N, N)) < 0.5).astype(np.float64),
                                                nhp.BernoulliNetworkModel(0.5, N), 1.0)
         t_adj = timed(lambda: nhp.disc_resample_adjacency_matrix_(net, convolved=dsd, seed=1, step=0, ctx=ctx), 2)
+        # mle! end to end: 8 steps of the device-resident optimizer (nhp_disc_mle_run), 2 of the host route (scipy L-BFGS-B on
+        # the same gradient: parameters up, gradient down and a host-side update of 2.1e6-vectors per objective call)
+        guess = np.concatenate([rng.uniform(0.02, 0.08, N), rng.uniform(0.0, 1.0, N * N * B) / (N * B)])
+        mle = {}
+        for opt, n in (("device", 8), ("L-BFGS-B", 2)):
+            mproc = copy.deepcopy(proc)
+            t0 = time.perf_counter()
+            res = nhp.mle_(mproc, dsd, guess=guess, f_abstol=1e-12, max_steps=n, optimizer=opt, ctx=ctx)
+            mle[opt] = 1e3 * (time.perf_counter() - t0) / max(1, res.steps)
         out.append({"workload": "c4 discrete N=512 B=8 L=32 T=1e5", "convolve_ms": 1e3 * t_c, "loglik_ms": 1e3 * t_ll,
                     "loglik_tflops_fp64": flop / t_ll / 1e12, "vb_step_ms": 1e3 * t_vb,
                     "vb_tflops_fp64": 2 * flop / t_vb / 1e12, "mfma_fp64_peak_tflops": 78.6,
                     "loglik_plus_gradient_ms": 1e3 * t_lg,
                     "gibbs_parent_counts_ms": 1e3 * t_pc, "gibbs_step_ms": 1e3 * t_gs, "gibbs_adjacency_sweep_ms": 1e3 * t_adj,
+                    "mle_ms_per_step_device_optimizer": mle["device"], "mle_ms_per_step_host_optimizer": mle["L-BFGS-B"],
                     "events": int(data.sum())})
     return out
 

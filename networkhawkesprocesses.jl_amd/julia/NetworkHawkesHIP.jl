@@ -496,10 +496,24 @@ end
 # Parameter vector [λ0; vec(W .* θ)] (params / params!, src/discrete.jl:174-201).  regularize=true calls the reference's
 # logprior(process), which reads fields the process does not have (SURVEY D5): it throws here as it does there.
 function mle!(p::NHP.DiscreteStandardHawkesProcess, data::Matrix{Int64}; optimizer=Optim.BFGS, verbose=false, f_abstol=1e-6,
-              regularize=false, guess=nothing, max_increase_steps=3, ctx=context())
+              regularize=false, guess=nothing, max_increase_steps=3, max_steps=1000, ctx=context())
     convolved = convolve(p, data; ctx=ctx)
     guess = guess === nothing ? NHP._rand_init_(p) : guess
     P = length(guess)
+    if optimizer === :device
+        # the whole iteration inside the library (nhp_disc_mle_run): x = params(process) stays on the device, params!'s split
+        # into W and θ is redone there per evaluation; homogeneous baseline
+        regularize && error("optimizer=:device minimises -loglikelihood only")
+        x = clamp.(Vector{Float64}(guess), 1e-6, 1e1)
+        loss, steps, conv, evals = Ref{Float64}(0.0), Ref{Int32}(0), Ref{Int32}(0), Ref{Int32}(0)
+        t0 = time()
+        check(ccall((:nhp_disc_mle_run, libnhp), Int32,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Float64, Float64, Int32, Ptr{Float64}, Int64, Ref{Float64}, Ref{Int32}, Ref{Int32}, Ref{Int32}),
+            ctx.h, convolved.h, p.dt, 1e-6, 1e1, f_abstol, Int32(max_steps), x, P, loss, steps, conv, evals), ctx.h)
+        verbose && println(" > steps: $(steps[]), objective evaluations: $(evals[]), loss: $(loss[])")
+        NHP.params!(p, x)
+        return NHP.MaximumLikelihood(x, -loss[], Int(steps[]), time() - t0, conv[] == 1 ? "success" : "failure")
+    end
     ll, g = Ref{Float64}(0.0), Vector{Float64}(undef, P)
     function fg!(G, x)
         NHP.params!(p, x)
