@@ -334,7 +334,7 @@ def mle_leg(nhp, ctx, args):
     times, nodes, T = nhp.synthetic.s_metric_data(N, M, kbar=8.0)
     out = {"workload": f"mle! on the metric dataset (N={N}, M={M}, exponential, mean window 8), start = the generating parameters "
                        "perturbed by U(0.5, 1.5), box [1e-6, 10]"}
-    for name, recursive, opt, steps in (("device_optimizer", False, "device", 30), ("device_optimizer_recursive_objective", True, "device", 15),
+    for name, recursive, opt, steps in (("device_optimizer", False, "device", 100), ("device_optimizer_recursive_objective", True, "device", 30),
                                         ("host_optimizer", False, "L-BFGS-B", 3)):
         proc = nhp.synthetic.s_metric_process(N, M, T, "exponential", 1.0)
         guess = np.clip(proc.params() * np.random.default_rng(9).uniform(0.5, 1.5, len(proc.params())), 1e-6, 10.0)
