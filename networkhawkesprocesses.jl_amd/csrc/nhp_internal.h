@@ -219,6 +219,7 @@ struct nhp_disc_dataset {
     int32_t N = 0, B = 0, L = 0;
     int64_t T = 0;
     double *d_dataT = nullptr;          // [T*N] counts as f64, t fastest (GEMM operand)
+    uint8_t *d_data8 = nullptr;         // [T*N] the same counts in one byte each (when none exceeds 255): what the convolution reads
     double *d_conv = nullptr;           // [T*N*B] t fastest
     double *d_colsum = nullptr;         // [2N] Σ_t data[n,t], then Σ_t loggamma(data[n,t]+1)
     double lgamma_sum = 0.0;            // Σ_{n,t} loggamma(data[n,t]+1): the data-only term of the Poisson ll
