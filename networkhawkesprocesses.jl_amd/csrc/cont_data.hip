@@ -5,6 +5,8 @@
 // (first parent of every event's Δtmax window, using the reference's own fp64 test
 // `events[j] > t - Δtmax`, src/continuous.jl:291), the node bucketing of child events and
 // the partition of buckets into workgroup-sized items.
+#include <chrono>
+#include <thread>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -74,6 +76,16 @@ extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double
         if (i > 0 && events[i] < events[i - 1]) { nhp_set_error(ctx, "events must be sorted (event %lld)", (long long)(i + 1)); return NHP_EINVAL; }
     }
     NHP_HIP(ctx, hipSetDevice(ctx->device));
+    // NHP_TIMING=1: where the host side of a dataset's creation spends its time (stderr)
+    static const bool timing = getenv("NHP_TIMING") && atoi(getenv("NHP_TIMING")) != 0;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[nhp dataset] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    lap("validation");
 
     nhp_cont_dataset *ds = new nhp_cont_dataset();
     static std::atomic<uint64_t> next_uid{1};
@@ -94,24 +106,16 @@ extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double
         pairs += i - f;
     }
     ds->pairs = pairs;
-    if (M > 1 && events[M - 1] > events[0]) {
-        const double span = events[M - 1] - events[0];
-        for (double L = span / (double)M; L < span; L *= 2.0) {
-            int64_t best = 1, lo = 0;
-            for (int64_t i = 0; i < M; ++i) {
-                while (events[i] - events[lo] > L) ++lo;
-                best = std::max<int64_t>(best, i - lo + 1);
-            }
-            ds->h_slab_len.push_back(L);
-            ds->h_slab_max.push_back(best);
-        }
-    }
+    lap("windows");
+    // (the crowding statistics of the recursion's truncated-window bound are made at its first use: nhp_dataset_slab_stats)
     for (int64_t i = 0; i < M && events[i] == 0.0; ++i) ds->n_zero_time = i + 1;
+    lap("zero-time events");
     for (int64_t i = 0; i < M; ++i) ds->max_window = std::max<int32_t>(ds->max_window, (int32_t)(i - first[i]));
     ds->h_pair_off.assign((size_t)N + 1, 0);
     for (int64_t i = 0; i < M; ++i) ds->h_pair_off[node32[i] + 1] += i - first[i];
     for (int32_t c = 0; c < N; ++c) ds->h_pair_off[c + 1] += ds->h_pair_off[c];
     ds->group = nhp_pick_group(M > 0 ? (double)pairs / (double)M : 0.0);
+    lap("pair offsets per node");
 
     // stable counting sort of children by node
     ds->h_boff.assign((size_t)N + 1, 0);
@@ -185,6 +189,7 @@ extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double
     }
     ds->n_items = (int32_t)items.size();
     for (const nhp_item &it : items) ds->max_item = std::max(ds->max_item, it.kend - it.kbeg);
+    lap("bucketing + items");
     // Windowed kernels: children of an item are visited in rounds of (256/G)*U.  Measured orderings
     // (tools/sortcmp.sh, K=8): 2 = whole item by window length (lanes of a wave run equal pair-loop
     // trips; fastest, 43.4 us, FETCH_SIZE 99.9 MB raw), 1 = rounds in time order, window-sorted inside
@@ -199,11 +204,23 @@ extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double
         const char *flat = getenv("NHP_SORT");
         const int mode = flat ? atoi(flat) : 2;
         auto longer = [&](int32_t x, int32_t y) { return (child[x].idx - child[x].first) > (child[y].idx - child[y].first); };
-        for (const nhp_item &it : items) {
-            if (mode == 2) std::stable_sort(wpos.begin() + it.kbeg, wpos.begin() + it.kend, longer);
-            else if (mode == 1)
-                for (int k = it.kbeg; k < it.kend; k += round)
-                    std::stable_sort(wpos.begin() + k, wpos.begin() + std::min(k + round, it.kend), longer);
+        // items are disjoint ranges of wpos: sorted by a few host threads (37 ms of a 230 ms creation on one)
+        auto sort_items = [&](size_t b, size_t e) {
+            for (size_t q = b; q < e; ++q) {
+                const nhp_item &it = items[q];
+                if (mode == 2) std::stable_sort(wpos.begin() + it.kbeg, wpos.begin() + it.kend, longer);
+                else if (mode == 1)
+                    for (int k = it.kbeg; k < it.kend; k += round)
+                        std::stable_sort(wpos.begin() + k, wpos.begin() + std::min(k + round, it.kend), longer);
+            }
+        };
+        const size_t nthreads = std::max<size_t>(1, std::min<size_t>(8, std::min<size_t>(std::thread::hardware_concurrency(), items.size() / 64)));
+        if (nthreads <= 1 || M < 100000) sort_items(0, items.size());
+        else {
+            std::vector<std::thread> pool;
+            for (size_t w = 0; w < nthreads; ++w)
+                pool.emplace_back(sort_items, items.size() * w / nthreads, items.size() * (w + 1) / nthreads);
+            for (std::thread &th : pool) th.join();
         }
         for (int64_t k = 0; k < M; ++k) child_w[(size_t)k] = child[(size_t)wpos[(size_t)k]];
     }
@@ -217,6 +234,7 @@ extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double
         poff[(size_t)M] = run;
     }
     std::vector<nhp_event> ev((size_t)M);
+    lap("window sort + child_w + poff");
     for (int64_t i = 0; i < M; ++i) { ev[i].t = events[i]; ev[i].node = node32[i]; ev[i].pad = 0; }
     // 8-byte records (nhp_internal.h): only where a node fits 16 bits and the span is a finite positive number
     std::vector<uint64_t> ev8;
@@ -236,6 +254,7 @@ extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double
         }
     }
 
+    lap("event records");
     nhp_status s;
     if ((s = upload(ctx, &ds->d_times, events, (size_t)M)) != NHP_OK ||
         (s = upload(ctx, &ds->d_nodes, node32.data(), (size_t)M)) != NHP_OK ||
@@ -258,7 +277,48 @@ extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double
     }
     hipError_t e = hipStreamSynchronize(ctx->stream);   // host vectors go out of scope below
     if (e != hipSuccess) { nhp_set_error(ctx, "upload failed: %s", hipGetErrorString(e)); nhp_cont_dataset_destroy(ds); return NHP_EHIP; }
+    lap("uploads");
     *out = ds;
+    return NHP_OK;
+}
+
+// Crowding of the data for the recursion's truncated-window bound (cont_recursive.hip): h_slab_max[k] = most events inside any
+// closed time window of length h_slab_len[k], lengths doubling from the mean gap up to the span.  Data only; made at the
+// first call that needs it (it was 164 ms of a 230 ms dataset creation that most callers never use).
+nhp_status nhp_dataset_slab_stats(nhp_ctx *ctx, const nhp_cont_dataset *cds)
+{
+    nhp_cont_dataset *ds = const_cast<nhp_cont_dataset *>(cds);
+    if (ds->slab_done) return NHP_OK;
+    ds->slab_done = true;
+    const int64_t M = ds->M;
+    if (M <= 1) return NHP_OK;
+    std::vector<double> events((size_t)M);
+    NHP_HIP(ctx, hipMemcpyAsync(events.data(), ds->d_times, sizeof(double) * (size_t)M, hipMemcpyDeviceToHost, ctx->stream));
+    NHP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!(events[M - 1] > events[0])) return NHP_OK;
+    const double span = events[M - 1] - events[0];
+    std::vector<double> lens;
+    for (double L = span / (double)M; L < span; L *= 2.0) lens.push_back(L);
+    std::vector<int64_t> best(lens.size(), 1);
+    auto scan = [&](size_t q) {
+        const double L = lens[q];
+        int64_t b = 1, lo = 0;
+        for (int64_t i = 0; i < M; ++i) {
+            while (events[i] - events[lo] > L) ++lo;
+            b = std::max<int64_t>(b, i - lo + 1);
+        }
+        best[q] = b;
+    };
+    const size_t nthreads = std::max<size_t>(1, std::min<size_t>(8, std::thread::hardware_concurrency()));
+    if (nthreads <= 1 || M < 100000) { for (size_t q = 0; q < lens.size(); ++q) scan(q); }
+    else {
+        std::vector<std::thread> pool;
+        for (size_t w = 0; w < nthreads; ++w)
+            pool.emplace_back([&, w]() { for (size_t q = w; q < lens.size(); q += nthreads) scan(q); });
+        for (std::thread &th : pool) th.join();
+    }
+    ds->h_slab_len = lens;
+    ds->h_slab_max = best;
     return NHP_OK;
 }
 

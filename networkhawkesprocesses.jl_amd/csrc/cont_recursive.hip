@@ -407,6 +407,7 @@ static nhp_status rec_cut_for(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
     // the bound uses the dataset's slab statistics as well as the parameters: key it on both (a dataset id, not its size --
     // two datasets of equal length have different crowding)
     if (m->rec_version == m->version && m->rec_ds == ds->uid) { *cut = m->rec_cut; return NHP_OK; }
+    NHP_TRY(nhp_dataset_slab_stats(ctx, ds));               // the data's crowding statistics, made once
     const int blocks = 64;
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 3 * (size_t)blocks));
     nhp_cont_args a = nhp_make_args(ds, m);

@@ -141,6 +141,7 @@ struct nhp_cont_dataset {
     // formulation (cont_recursive.hip): events older than `cut` arrive at most h_slab_max per slab.
     std::vector<double> h_slab_len;
     std::vector<int64_t> h_slab_max;
+    bool slab_done = false;             // the two vectors above have been made (nhp_dataset_slab_stats: at the recursion's first bound)
     std::vector<int64_t> h_pair_off;    // [N+1] prefix of window pairs per child node (adjacency sweep scratch)
 };
 
@@ -266,6 +267,7 @@ void nhp_set_error(nhp_ctx *ctx, const char *fmt, ...);
     } while (0)
 
 nhp_status nhp_ctx_reserve_partials(nhp_ctx *ctx, size_t n_doubles);
+nhp_status nhp_dataset_slab_stats(nhp_ctx *ctx, const nhp_cont_dataset *ds);      // cont_data.hip
 int nhp_pick_group(double mean_window);
 // recursion_cost: what the caller's O(M·N) kernel costs relative to its windowed route, in units of the log-likelihood's
 // ratio (1 for the log-likelihood; the gradient's recursion is 3.5x the log-likelihood's, its windowed route 2.9x)
