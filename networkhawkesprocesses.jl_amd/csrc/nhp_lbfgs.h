@@ -59,17 +59,21 @@ __global__ __launch_bounds__(256) void k_mle_multidot(const double *__restrict__
     }
 }
 
-// out[k] = Σ_blk part[blk][k] in block order (k < NACC); out[NACC] = the evaluation's log-likelihood (riding along: one download)
-__global__ __launch_bounds__(64) void k_mle_multidot_final(const double *__restrict__ part, int nblk, const double *__restrict__ ll,
+// out[k] = Σ_blk part[blk][k] (k = blockIdx.x < NACC), the RBLK partials of one product summed by one workgroup in a fixed
+// order; out[NACC] = the evaluation's log-likelihood (riding along: one download).  (One 64-thread workgroup walking all
+// RBLK x NACC partials took 117 us a call -- a third of an optimizer step.)
+__global__ __launch_bounds__(256) void k_mle_multidot_final(const double *__restrict__ part, int nblk, const double *__restrict__ ll,
                                                            double *__restrict__ out)
 {
-    const int k = threadIdx.x;
-    if (k < NACC) {
-        double t = 0.0;
-        for (int b = 0; b < nblk; ++b) t += part[(size_t)b * NACC + k];
+    __shared__ double red[NHP_WAVES];
+    const int k = blockIdx.x;
+    double t = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) t += part[(size_t)b * NACC + k];
+    t = nhp_block_sum_n<NHP_WAVES>(t, red);
+    if (threadIdx.x == 0) {
         out[k] = t;
+        if (k == 0) out[NACC] = ll ? *ll : 0.0;
     }
-    if (k == 0) out[NACC] = ll ? *ll : 0.0;
 }
 
 // q = g on the free variables, 0 on those held at a bound
@@ -136,7 +140,7 @@ nhp_status multidot(mle_state &s, const double *u, const double *v, bool with_ll
 {
     hipStream_t st = s.ctx->stream;
     hipLaunchKernelGGL(k_mle_multidot, dim3(RBLK), dim3(256), 0, st, u, v, (const double *)s.d_base, s.P, s.d_part);
-    hipLaunchKernelGGL(k_mle_multidot_final, dim3(1), dim3(64), 0, st, (const double *)s.d_part, RBLK,
+    hipLaunchKernelGGL(k_mle_multidot_final, dim3(NACC), dim3(256), 0, st, (const double *)s.d_part, RBLK,
                        with_ll ? (const double *)s.ctx->d_results : (const double *)nullptr, s.d_scal);
     NHP_HIP(s.ctx, hipGetLastError());
     NHP_HIP(s.ctx, hipMemcpyAsync(s.h_scal, s.d_scal, 8 * (NACC + 1), hipMemcpyDeviceToHost, st));
