@@ -357,3 +357,32 @@ def _with_params(orc, om, proc, lgcp):
     if hasattr(proc.impulses, "θ"):
         return orc.ContModel(lam0, proc.weights.W, theta=proc.impulses.θ, dt_max=proc.impulses.Δtmax, grid_x=gx)
     return orc.ContModel(lam0, proc.weights.W, mu=proc.impulses.μ, tau=proc.impulses.τ, dt_max=proc.impulses.Δtmax, grid_x=gx)
+
+
+def test_device_mle_error_behaviour(nhp):
+    # the reference's mle! is defined for the standard process only (src/continuous.jl:144); a wrong-length guess is the
+    # reference's "Parameter vector length does not match model parameter length." (src/continuous.jl:121-129)
+    import ctypes as C
+    from nhp_amd import _lib
+    c = random_case(4, 1500, 120.0, "exponential", 1.0, network=True, seed=3, nhp=nhp)
+    with pytest.raises(TypeError):
+        nhp.mle_(c["proc"], c["data"], optimizer="device")
+    s = random_case(4, 1500, 120.0, "exponential", 1.0, seed=3, nhp=nhp)
+    ctx = nhp.default_context()
+    ds, model = nhp.device_dataset(s["proc"], s["data"], ctx), s["proc"].device_model(ctx)
+    x = np.full(7, 0.5)
+    out = (C.c_double(), C.c_int32(), C.c_int32(), C.c_int32())
+    rc = _lib.lib().nhp_cont_mle_run(ctx.h, None, ds.h, model.h, 0, 1e-6, 10.0, 1e-6, 10, _lib.dptr(x), len(x), C.byref(out[0]),
+                                     C.byref(out[1]), C.byref(out[2]), C.byref(out[3]))
+    assert rc == 3 and b"Parameter vector length" in _lib.lib().nhp_last_error(ctx.h)        # NHP_ESHAPE
+    net_model = c["proc"].device_model(ctx)
+    xn = np.full(4 + 2 * 16, 0.5)
+    rc = _lib.lib().nhp_cont_mle_run(ctx.h, None, nhp.device_dataset(c["proc"], c["data"], ctx).h, net_model.h, 0, 1e-6, 10.0, 1e-6, 10,
+                                     _lib.dptr(xn), len(xn), C.byref(out[0]), C.byref(out[1]), C.byref(out[2]), C.byref(out[3]))
+    assert rc != 0 and b"ContinuousStandardHawkesProcess" in _lib.lib().nhp_last_error(ctx.h)
+    with pytest.raises(NotImplementedError):
+        nhp.mle_(s["proc"], s["data"], optimizer="device", regularize=True)
+    # max_steps = 0: the clamped guess comes back, with its log-likelihood
+    g = np.random.default_rng(2).uniform(0.2, 0.8, len(s["proc"].params()))
+    r = nhp.mle_(s["proc"], s["data"], guess=g, optimizer="device", max_steps=0)
+    assert r.steps == 0 and np.array_equal(r.maximizer, g) and r.maximum == pytest.approx(nhp.loglikelihood(s["proc"], s["data"]), rel=1e-12)
