@@ -233,8 +233,37 @@ extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double
         for (int64_t k = 0; k < M; ++k) { poff[(size_t)k] = run; run += (uint32_t)(child_w[(size_t)k].idx - child_w[(size_t)k].first); }
         poff[(size_t)M] = run;
     }
+    // child slices (nhp_cont_dataset::d_sl_*): rows per slice = its longest window
+    std::vector<uint32_t> sl_row;
+    std::vector<int32_t> sl_item0;
+    if (!poff.empty() && N <= 65534 && !(getenv("NHP_SLICES") && atoi(getenv("NHP_SLICES")) == 0)) {
+        sl_item0.resize(items.size() + 1);
+        uint64_t rows = 0;
+        for (size_t q = 0; q < items.size(); ++q) {
+            sl_item0[q] = (int32_t)sl_row.size();
+            for (int32_t k0 = items[q].kbeg; k0 < items[q].kend; k0 += 64) {
+                int32_t longest = 0;
+                for (int32_t k = k0; k < std::min(k0 + 64, items[q].kend); ++k)
+                    longest = std::max(longest, child_w[(size_t)k].idx - child_w[(size_t)k].first);
+                sl_row.push_back((uint32_t)rows);
+                rows += (uint64_t)longest;
+                ds->sl_max_rows = std::max(ds->sl_max_rows, longest);
+            }
+        }
+        sl_item0[items.size()] = (int32_t)sl_row.size();
+        sl_row.push_back((uint32_t)rows);
+        // padding must stay a small share (it is read like pairs) and the row index has to fit 32 bits with 64 records a row
+        if (rows >= ((uint64_t)1 << 25) || rows * 64 > (uint64_t)pairs * 2 + 4096) { sl_row.clear(); sl_item0.clear(); ds->sl_max_rows = 0; }
+        else {
+            ds->sl_rows = (int64_t)rows;
+            ds->n_slices = (int32_t)sl_row.size() - 1;
+            int nb = 0;
+            while (((int64_t)1 << nb) <= N) ++nb;                  // bit length of N: the padding records sit on node N
+            ds->sl_nb = nb;
+        }
+    }
     std::vector<nhp_event> ev((size_t)M);
-    lap("window sort + child_w + poff");
+    lap("window sort + child_w + poff + slices");
     for (int64_t i = 0; i < M; ++i) { ev[i].t = events[i]; ev[i].node = node32[i]; ev[i].pad = 0; }
     // 8-byte records (nhp_internal.h): only where a node fits 16 bits and the span is a finite positive number
     std::vector<uint64_t> ev8;
@@ -261,6 +290,8 @@ extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double
         (s = upload(ctx, &ds->d_ev, ev.data(), (size_t)M)) != NHP_OK ||
         (!ev8.empty() && (s = upload(ctx, &ds->d_ev8, ev8.data(), (size_t)M)) != NHP_OK) ||
         (!poff.empty() && (s = upload(ctx, &ds->d_poff, poff.data(), (size_t)M + 1)) != NHP_OK) ||
+        (!sl_row.empty() && (s = upload(ctx, &ds->d_sl_row, sl_row.data(), sl_row.size())) != NHP_OK) ||
+        (!sl_item0.empty() && (s = upload(ctx, &ds->d_sl_item0, sl_item0.data(), sl_item0.size())) != NHP_OK) ||
         (s = upload(ctx, &ds->d_child, child.data(), (size_t)M)) != NHP_OK ||
         (s = upload(ctx, &ds->d_child_w, child_w.data(), (size_t)M)) != NHP_OK ||
         (s = upload(ctx, &ds->d_wpos, wpos.data(), (size_t)M)) != NHP_OK ||
@@ -328,6 +359,7 @@ extern "C" void nhp_cont_dataset_destroy(nhp_cont_dataset *ds)
     (void)hipSetDevice(ds->ctx->device);
     (void)hipStreamSynchronize(ds->ctx->stream);
     (void)hipFree(ds->d_times); (void)hipFree(ds->d_nodes); (void)hipFree(ds->d_child); (void)hipFree(ds->d_child_w); (void)hipFree(ds->d_wpos); (void)hipFree(ds->d_ev); (void)hipFree(ds->d_ev8); (void)hipFree(ds->d_poff); (void)hipFree(ds->d_plist); (void)hipFree(ds->d_plq); (void)hipFree(ds->d_pnode);
+    (void)hipFree(ds->d_sl_row); (void)hipFree(ds->d_sl_item0); (void)hipFree(ds->d_sl_lo); (void)hipFree(ds->d_sl_hi);
     (void)hipFree(ds->d_boff); (void)hipFree(ds->d_items); (void)hipFree(ds->d_cnt); (void)hipFree(ds->d_pn);
     (void)hipFree(ds->d_adj_k); (void)hipFree(ds->d_adj_p); (void)hipFree(ds->d_adj_dt); (void)hipFree(ds->d_adj_lq); (void)hipFree(ds->d_adj_start); (void)hipFree(ds->d_adj_off); (void)hipFree(ds->d_adj_group); (void)hipFree(ds->d_child_cut);
     (void)hipFree(ds->d_rec_ev); (void)hipFree(ds->d_rec_poff); (void)hipFree(ds->d_rec_rank);

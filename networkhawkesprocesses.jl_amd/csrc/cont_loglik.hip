@@ -1108,6 +1108,12 @@ static nhp_status run_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const n
     // the dataset's own short windows: through the cached pair list (k_windowed_pairs)
     const bool plist_off = getenv("NHP_PLIST") && atoi(getenv("NHP_PLIST")) == 0;       // (read per call: the tests switch it)
     const bool expo_p = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
+    // ... one lane per child over the child slices (cont_slices.hip) when there is no λ output: 6-byte records
+    if (!child_w && !d_lambda && d_out && expo_p && !plist_off) {
+        bool launched = false;
+        NHP_TRY(nhp_launch_windowed_slices(ctx, ds, m, mask_integral, d_out, &launched));
+        if (launched) return NHP_OK;
+    }
     if (!child_w && ds->d_poff && !plist_off && G <= 16 && (expo_p || nhp_ensure_pair_cache(ctx, ds, &a) == NHP_OK)) {
         if (expo_p && !ds->d_plist) {                              // first use: build the list (data only)
             nhp_cont_dataset *mds = const_cast<nhp_cont_dataset *>(ds);

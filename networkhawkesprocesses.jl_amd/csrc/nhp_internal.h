@@ -100,6 +100,21 @@ struct nhp_cont_dataset {
     // bits -- and the parent's node; built at the first logit-normal sweep
     double2 *d_plq = nullptr;           // [pairs]
     uint16_t *d_pnode = nullptr;        // [pairs]
+    // Child slices (cont_slices.hip): the same short-window pairs, laid out for one LANE per child.  A slice is
+    // 64 consecutive children of one item in child_w order = one wavefront's work; its pairs are stored row by row, row r
+    // = the r-th most recent parent of each of the 64 children (64 records, one per lane: a wave-wide coalesced load), as
+    // many rows as the slice's longest window (children are sorted by window length, so a slice's windows are nearly
+    // equal; shorter ones are padded with zero-weight records on node N).  A record is 6 bytes in two planes: lo = low 32
+    // bits of the delay, hi = node << (16 - nb) | high bits of the delay; the delay is round(Δt/Δtmax · 2^(48 - nb)),
+    // nb = bit length of N.  d_sl_row / d_sl_item0 are host-made with the dataset; the planes are filled on the device at
+    // the first evaluation that uses them.
+    uint32_t *d_sl_row = nullptr;       // [n_slices + 1] first row of each slice
+    int32_t *d_sl_item0 = nullptr;      // [n_items + 1] first slice of each item
+    uint32_t *d_sl_lo = nullptr;        // [(sl_rows + 8) * 64]
+    uint16_t *d_sl_hi = nullptr;        // [(sl_rows + 8) * 64]
+    int64_t sl_rows = 0;
+    int32_t n_slices = 0, sl_nb = 0;    // node bits
+    int32_t sl_max_rows = 0;            // most rows of one slice
     // device arrays
     double *d_times = nullptr;          // [M] time order
     int32_t *d_nodes = nullptr;         // [M] 0-based
@@ -280,6 +295,10 @@ nhp_status nhp_launch_windowed_as(nhp_ctx *ctx, const nhp_cont_dataset *ds, cons
                                   int group, int mask_integral, double *d_out);
 nhp_status nhp_ctx_reserve_scratch(nhp_ctx *ctx, size_t bytes);
 nhp_status nhp_ensure_pair_cache(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_args *a);   // cont_sampler.hip
+// cont_slices.hip: the exponential log-likelihood of the dataset's own short windows, one lane per child over the child
+// slices.  *launched = false (and NHP_OK) when the dataset has no slices or the model is not covered.
+nhp_status nhp_launch_windowed_slices(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, int mask_integral,
+                                      double *d_out, bool *launched);
 nhp_cont_args nhp_make_args(const nhp_cont_dataset *ds, const nhp_cont_model *m);
 nhp_status nhp_check_pair(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m);
 // Device -> caller memory through the context's pinned staging buffer: DMA at link speed into pinned memory, then one

@@ -326,8 +326,9 @@ def test_pair_list_and_packed_records_agree_with_the_exact_records(nhp, orc, net
     data = (t, c["nodes"], c["T"])
     want = orc.loglik(c["om"], t, c["nodes"], c["T"], recursive=False)
     got = {}
-    for name, env in (("pairs", {}), ("ev8", {"NHP_PLIST": "0"}), ("exact", {"NHP_PLIST": "0", "NHP_EV8": "0"})):
-        for k in ("NHP_PLIST", "NHP_EV8"):
+    for name, env in (("slices", {}), ("pairs", {"NHP_SLICES": "0"}), ("ev8", {"NHP_PLIST": "0"}),
+                      ("exact", {"NHP_PLIST": "0", "NHP_EV8": "0"})):
+        for k in ("NHP_PLIST", "NHP_EV8", "NHP_SLICES"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -335,12 +336,21 @@ def test_pair_list_and_packed_records_agree_with_the_exact_records(nhp, orc, net
         got[name] = nhp.loglikelihood(c["proc"], data, recursive=False)
         assert rel(got[name], want) < TOL, name
     assert rel(got["pairs"], got["exact"]) < 1e-13 and rel(got["ev8"], got["exact"]) < 1e-13
-    monkeypatch.delenv("NHP_PLIST", raising=False)
-    monkeypatch.delenv("NHP_EV8", raising=False)
+    assert rel(got["slices"], got["exact"]) < 1e-12                  # one lane per child: 6-byte records (cont_slices.hip)
+    for k in ("NHP_PLIST", "NHP_EV8", "NHP_SLICES"):
+        monkeypatch.delenv(k, raising=False)
+    nhp.invalidate_device_datasets()
+    for cfg in ("64,2", "64,4", "128,2", "128,4", "256,2", "256,4", "512,2", "512,4", "1024,2", "1024,4"):   # (waves per item, rows per request)
+        monkeypatch.setenv("NHP_SLICES_CFG", cfg)
+        assert rel(nhp.loglikelihood(c["proc"], data, recursive=False), want) < TOL, cfg
+    monkeypatch.delenv("NHP_SLICES_CFG", raising=False)
+    monkeypatch.setenv("NHP_SLICES", "0")
+    nhp.invalidate_device_datasets()
     for cfg in ("1,1,256", "2,4,256", "4,2,512", "8,4,512", "4,1,1024", "8,2,1024", "2,2,512"):
         monkeypatch.setenv("NHP_PAIRS_CFG", cfg)
         assert rel(nhp.loglikelihood(c["proc"], data, recursive=False), want) < TOL, cfg
     monkeypatch.delenv("NHP_PAIRS_CFG", raising=False)
+    monkeypatch.delenv("NHP_SLICES", raising=False)
     # logit-normal impulses: the pair kernel reads {logit(x), 1/(x(1-x))} made once per dataset -- the same operations, so
     # the same bits per term as the kernel that evaluates the whole pdf
     cl = random_case(12, 6000, 500.0, "logitnormal", 1.0, network=network, lgcp=lgcp, seed=11, nhp=nhp, orc=orc)
@@ -361,8 +371,32 @@ def test_pair_list_and_packed_records_agree_with_the_exact_records(nhp, orc, net
         assert rel(nhp.loglikelihood(cl["proc"], (t, cl["nodes"], cl["T"]), recursive=False), wantl) < TOL, cfg
 
 
+def test_child_slices_at_a_thousand_nodes(nhp, orc, monkeypatch):
+    """N = 1024 is where the 6-byte records of the child slices are tightest (11 bits of node, 37 bits of delay: 3.6e-12 of
+    Δtmax): the log-likelihood through them, through the 8-byte pair list and through the exact records against the oracle on
+    the original times, standard and network model, with a column that has no child and an item with a single one."""
+    for network in (False, True):
+        c = random_case(1024, 40000, 5000.0, "exponential", 1.0, network=network, seed=77, nhp=nhp, orc=orc)
+        n = c["nodes"].copy()
+        n[n == 5] = 6
+        n[n == 9] = 10
+        n[123] = 9
+        data = (c["times"], n, c["T"])
+        want = orc.loglik(c["om"], c["times"], n, c["T"], recursive=False)
+        for name, env in (("slices", {}), ("pairs", {"NHP_SLICES": "0"}), ("exact", {"NHP_PLIST": "0", "NHP_EV8": "0"})):
+            for k in ("NHP_PLIST", "NHP_EV8", "NHP_SLICES"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            nhp.invalidate_device_datasets()
+            assert rel(nhp.loglikelihood(c["proc"], data, recursive=False), want) < TOL, (name, network)
+    for k in ("NHP_PLIST", "NHP_EV8", "NHP_SLICES"):
+        monkeypatch.delenv(k, raising=False)
+    nhp.invalidate_device_datasets()
+
+
 def test_derived_layouts_agree_on_awkward_data(nhp, monkeypatch):
-    """The pair list and the 8-byte records are derived from the data once per dataset: time origins far from zero,
+    """The child slices, the pair list and the 8-byte records are derived from the data once per dataset: time origins far from zero,
     ties, a node without events, one node with all of them, tiny and huge Δtmax, N = 1 -- each evaluated through the pair
     list, the 8-byte records and the exact 16-byte records (the three agree to 1e-12; the exact path is the one the oracle tests
     pin), for exponential and logit-normal impulses."""
@@ -387,17 +421,19 @@ def test_derived_layouts_agree_on_awkward_data(nhp, monkeypatch):
                 imp = nhp.LogitNormalImpulseResponse(rng.normal(0.0, 1.0, (N, N)), rng.uniform(0.5, 2.0, (N, N)), dtm)
             proc = nhp.ContinuousStandardHawkesProcess(nhp.HomogeneousProcess(lam0), imp, nhp.DenseWeightModel(W))
             got = {}
-            for name, env in (("pairs", {}), ("ev8", {"NHP_PLIST": "0"}), ("exact", {"NHP_PLIST": "0", "NHP_EV8": "0"})):
-                for k in ("NHP_PLIST", "NHP_EV8"):
+            for name, env in (("slices", {}), ("pairs", {"NHP_SLICES": "0"}), ("ev8", {"NHP_PLIST": "0"}),
+                              ("exact", {"NHP_PLIST": "0", "NHP_EV8": "0"})):
+                for k in ("NHP_PLIST", "NHP_EV8", "NHP_SLICES"):
                     monkeypatch.delenv(k, raising=False)
                 for k, v in env.items():
                     monkeypatch.setenv(k, v)
                 nhp.invalidate_device_datasets()
                 got[name] = nhp.loglikelihood(proc, (t, n, T), recursive=False)
             assert np.isfinite(got["exact"])
+            assert rel(got["slices"], got["exact"]) < 1e-12, (N, kind, dtm, got)
             assert rel(got["pairs"], got["exact"]) < 1e-12, (N, kind, dtm, got)
             assert rel(got["ev8"], got["exact"]) < 1e-12, (N, kind, dtm, got)
-    for k in ("NHP_PLIST", "NHP_EV8"):
+    for k in ("NHP_PLIST", "NHP_EV8", "NHP_SLICES"):
         monkeypatch.delenv(k, raising=False)
 
 
