@@ -145,7 +145,13 @@ extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double
     // NHP_XCD = 0 | 2 | 4 | 8 overrides.  Speed heuristic only: any placement gives the same result.
     const char *xenv = getenv("NHP_XCD");
     const double kbar = M > 0 ? (double)pairs / (double)M : 0.0;
-    const int TP = xenv ? atoi(xenv) : (kbar >= 192.0 ? 4 : (kbar >= 24.0 ? 2 : 0));
+    // Datasets whose pairs are kept as child slices (short and middle windows, below) are STREAMED by their log-likelihood and
+    // gradient kernels: no scattered window for an XCD's L2 to hold, so the second staging of every column only costs there
+    // (mean window 64: 103.8 us with two time parts, 78.8 us with none; the simulated set 54.5 -> 49.6).
+    const int64_t slices_maxk = getenv("NHP_SLICES_MAXK") ? atoi(getenv("NHP_SLICES_MAXK")) : 160;
+    const bool slices_on = !(getenv("NHP_SLICES") && atoi(getenv("NHP_SLICES")) == 0);
+    const bool sliced = slices_on && pairs > 0 && pairs <= slices_maxk * M && std::isfinite(dt_max) && dt_max > 0.0 && N <= 65534;
+    const int TP = xenv ? atoi(xenv) : (kbar >= 192.0 ? 4 : (kbar >= 24.0 && !sliced ? 2 : 0));
     if ((TP == 2 || TP == 4 || TP == 8) && N >= 8 && M >= 16 * (int64_t)N) {
         const int NG = 8 / TP;
         for (int32_t c0 = 0; c0 < N; c0 += NG)
@@ -236,7 +242,9 @@ extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double
     // child slices (nhp_cont_dataset::d_sl_*): rows per slice = its longest window
     std::vector<uint32_t> sl_row;
     std::vector<int32_t> sl_item0;
-    if (!poff.empty() && N <= 65534 && !(getenv("NHP_SLICES") && atoi(getenv("NHP_SLICES")) == 0)) {
+    // (short AND middle windows: the slices are streamed, 6 bytes a pair, where k_windowed gathers scattered windows --
+    //  mean window 64: 115 -> ~70 us; at 512 the 3 GB list would cost what the exponentials do, so not there)
+    if (sliced) {
         sl_item0.resize(items.size() + 1);
         uint64_t rows = 0;
         for (size_t q = 0; q < items.size(); ++q) {
@@ -260,6 +268,8 @@ extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double
             int nb = 0;
             while (((int64_t)1 << nb) <= N) ++nb;                  // bit length of N: the padding records sit on node N
             ds->sl_nb = nb;
+            if (timing) fprintf(stderr, "[nhp dataset] child slices: %d slices, %lld rows = %.3f records per pair\n", ds->n_slices, (long long)rows,
+                                (double)rows * 64.0 / (double)pairs);
         }
     }
     std::vector<nhp_event> ev((size_t)M);

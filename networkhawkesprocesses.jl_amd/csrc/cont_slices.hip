@@ -23,7 +23,7 @@
 struct nhp_slices {               // kernel-side view of nhp_cont_dataset::d_sl_*
     const uint32_t *row;          // [n_slices + 1]
     const int32_t *item0;         // [n_items + 1]
-    const uint32_t *lo;           // [(rows + 8) * 64]
+    const uint32_t *lo;           // [(rows + 16) * 64]
     const uint16_t *hi;
     int32_t nsh;                  // 16 - node bits: hi = node << nsh | delay >> 32
     uint32_t dmask;               // (1 << nsh) - 1
@@ -31,6 +31,17 @@ struct nhp_slices {               // kernel-side view of nhp_cont_dataset::d_sl_
 };
 
 #define NHP_SL_SHARDS 64
+
+#ifdef NHP_STAMP      // diagnostic build only (tools/dbg/slstamps.py): s_memtime at the phase boundaries of wave 0 of every workgroup
+__device__ unsigned long long g_sl_stamps[8 * 4096];
+#define NHP_SL_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_sl_stamps[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int nhp_debug_stamps_slices(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sl_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#else
+#define NHP_SL_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ double sl_baseline(const nhp_cont_args &a, int c, double t)
 {
@@ -107,16 +118,18 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_slices(nhp_cont_args a, nhp_
     double *red = reinterpret_cast<double *>(smem);                 // [2 * NW <= 32] + flag at [32]
     double2 *col = reinterpret_cast<double2 *>(smem + 320);         // [N + 1] {-θ·unit·64/ln2, a·w·θ}; [N] = {0, 0}
     double *etab = reinterpret_cast<double *>(col + a.N + 1);       // [64] 2^(j/64)
-    nhp_exp_tab_init(etab);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const double tab_v = nhp_exp2_64[lane];                         // requested first, parked in LDS with the column (one wait)
 
     const nhp_item it = a.items[blockIdx.x];
-    const int c = it.node, N = a.N, tid = threadIdx.x, lane = tid & 63;
+    const int c = it.node, N = a.N;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nchild = it.kend - it.kbeg;
     const int s0 = sl.item0[blockIdx.x], ns = sl.item0[blockIdx.x + 1] - s0;
+    NHP_SL_STAMP(0);
 
     // Rows r .. r+C-1 of the slice that starts at row `row0`: a wave-uniform base and compile-time row offsets.  Rows past the
-    // slice's last are simply the next slice's (or the 8 rows of padding behind the list): loaded, never summed.
+    // slice's last are simply the next slice's (or the 16 rows of padding behind the list): loaded, never summed.
     struct chunk { uint32_t lo[C], hi[C]; };
     auto request = [&](chunk &q, const uint32_t row0, const int r) {
         const size_t o = ((size_t)row0 + (size_t)r) * 64;
@@ -128,44 +141,79 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_slices(nhp_cont_args a, nhp_
             q.hi[u] = ph[u * 64 + lane];
         }
     };
+    // Column c of the tables: every load of (up to) UN passes over the parent nodes is requested before any is used -- one
+    // round trip instead of one per pass -- and the first rows of the wave's first slice are requested right behind them
+    // (their addresses need the slice table only), so they arrive while the column is being written to LDS.
+    constexpr int UN = BLOCK >= 512 ? 2 : 4;
+    const double unit = __builtin_ldexp(a.dt_max, -sl.dbits);      // Δtmax · 2^-dbits
     int j = w;
     uint32_t row0 = 0;
     int K = 0;
-    if (j < ns) { row0 = sl.row[s0 + j]; K = (int)(sl.row[s0 + j + 1] - row0); }
     chunk qa, qb;
-    request(qa, row0, 0);
-
-    const double unit = __builtin_ldexp(a.dt_max, -sl.dbits);      // Δtmax · 2^-dbits
     double integ = 0.0;
-    for (int p = tid; p < N; p += BLOCK) {
-        const size_t k = (size_t)p + (size_t)c * N;
-        double wv = a.W[k], wint = wv;
-        if (a.A) {
-            wv = a.A[k] * wv;
-            if (mask_integral) wint = wv;
+    for (int p0 = 0; p0 < N || p0 == 0; p0 += UN * BLOCK) {
+        double w_[UN], th_[UN], a_[UN], cnt_[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int p = p0 + u * BLOCK + tid;
+            const size_t k = (size_t)(p < N ? p : 0) + (size_t)c * N;
+            w_[u] = a.W[k];
+            th_[u] = a.p1[k];
+            a_[u] = a.A ? a.A[k] : 1.0;
+            cnt_[u] = it.first ? a.cnt[p < N ? p : 0] : 0.0;
         }
-        const double th = a.p1[k];
-        col[p] = make_double2(-((th * unit) * 92.33248261689366), wv * th);   // term = (a·w·θ)·exp(-(θ·unit)·q), the rate times 64/ln 2
-        if (it.first) integ += a.cnt[p] * wint;
+        if (p0 == 0) {
+            if (j < ns) { row0 = sl.row[s0 + j]; K = (int)(sl.row[s0 + j + 1] - row0); }
+            asm volatile("" ::: "memory");
+            request(qa, row0, 0);
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int p = p0 + u * BLOCK + tid;
+            if (p < N) {
+                double wv = w_[u], wint = wv;
+                if (a.A) {
+                    wv = a_[u] * wv;
+                    if (mask_integral) wint = wv;
+                }
+                col[p] = make_double2(-((th_[u] * unit) * 92.33248261689366), wv * th_[u]);   // term = (a·w·θ)·exp(-(θ·unit)·q), the rate times 64/ln 2
+                integ += cnt_[u] * wint;
+            }
+        }
     }
+    if (tid < 64) etab[tid] = tab_v;
     if (tid == 0) col[N] = make_double2(0.0, 0.0);
     if (out && it.first) integ += sl_baseline_integral_col(a, c);
     __syncthreads();
+    NHP_SL_STAMP(1);
 
     const double lam0 = FLAT ? a.lambda0[c] : 0.0;
     const uint32_t dmask = sl.dmask;
     const int nsh = sl.nsh;
+    auto term = [&](const uint32_t lo, const uint32_t h) {
+        // the high delay bits under the exponent of 2^52 (one v_bfi_b32): the double 2^52 + delay
+        uint32_t hw;
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hw) : "s"(dmask), "v"(h), "v"(0x43300000u));
+        const double v = __hiloint2double((int)hw, (int)lo) - 4503599627370496.0;
+        const double2 cw = col[h >> nsh];
+        return cw.y * nhp_exp_neg_tab_scaled(cw.x * v, etab);
+    };
+    // A request that lies wholly inside the slice is summed as C independent straight-line chains (their LDS round trips --
+    // column entry, then the 2^(j/64) entry -- overlap); the slice's last request goes row by row behind wave-uniform
+    // branches.  The sum itself is sequential in both: most recent parent first, the reference's order.
     auto sum = [&](const chunk &q, const int r, const int K, double s) {
+        if (r + C <= K) {
+            double t[C];
 #pragma unroll
-        for (int u = 0; u < C; ++u)
-            if (r + u < K) {                                        // wave-uniform
-                // the high delay bits under the exponent of 2^52 (one v_bfi_b32): the double 2^52 + delay
-                uint32_t hw;
-                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hw) : "s"(dmask), "v"(q.hi[u]), "v"(0x43300000u));
-                const double v = __hiloint2double((int)hw, (int)q.lo[u]) - 4503599627370496.0;
-                const double2 cw = col[q.hi[u] >> nsh];
-                s = __builtin_fma(cw.y, nhp_exp_neg_tab_scaled(cw.x * v, etab), s);
-            }
+            for (int u = 0; u < C; ++u) t[u] = term(q.lo[u], q.hi[u]);
+#pragma unroll
+            for (int u = 0; u < C; ++u) s += t[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < C; ++u)
+                if (r + u < K) s += term(q.lo[u], q.hi[u]);
+        }
         return s;
     };
     double prod = 1.0;
@@ -196,10 +244,12 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_slices(nhp_cont_args a, nhp_
         prod = __builtin_amdgcn_frexp_mant(prod);
         j = jn; row0 = row0n; K = Kn;
     }
+    NHP_SL_STAMP(2);
     double acc = nhp_log(prod) + (double)pexp * 6.93147180559945286e-01;
     if (prod == 0.0) acc = -__builtin_inf();
     double blk = acc, blk_int = integ;
     nhp_block_sum2_n<NW>(blk, blk_int, red);
+    NHP_SL_STAMP(3);
     if (!out) {
         if (tid == 0) {
             partials[2 * (size_t)blockIdx.x] = blk;
@@ -223,6 +273,7 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_slices(nhp_cont_args a, nhp_
         *flag = last;
     }
     __syncthreads();
+    NHP_SL_STAMP(4);
     if (!*flag) return;
     double sl_ = 0.0, si = 0.0;
     for (unsigned int i = tid; i < gridDim.x; i += BLOCK) {
@@ -250,7 +301,7 @@ static nhp_status ensure_slices(nhp_ctx *ctx, const nhp_cont_dataset *cds, const
 {
     if (cds->d_sl_lo) return NHP_OK;
     nhp_cont_dataset *ds = const_cast<nhp_cont_dataset *>(cds);
-    const size_t n = ((size_t)ds->sl_rows + 8) * 64;
+    const size_t n = ((size_t)ds->sl_rows + 16) * 64;
     if (hipMalloc((void **)&ds->d_sl_lo, 4 * n) != hipSuccess || hipMalloc((void **)&ds->d_sl_hi, 2 * n) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(ds->d_sl_lo); (void)hipFree(ds->d_sl_hi);
@@ -258,8 +309,8 @@ static nhp_status ensure_slices(nhp_ctx *ctx, const nhp_cont_dataset *cds, const
         nhp_set_error(ctx, "out of device memory (child slices)");
         return NHP_ENOMEM;
     }
-    NHP_HIP(ctx, hipMemsetAsync(ds->d_sl_lo + (size_t)ds->sl_rows * 64, 0, 4 * 8 * 64, ctx->stream));
-    NHP_HIP(ctx, hipMemsetAsync(ds->d_sl_hi + (size_t)ds->sl_rows * 64, 0, 2 * 8 * 64, ctx->stream));
+    NHP_HIP(ctx, hipMemsetAsync(ds->d_sl_lo + (size_t)ds->sl_rows * 64, 0, 4 * 16 * 64, ctx->stream));
+    NHP_HIP(ctx, hipMemsetAsync(ds->d_sl_hi + (size_t)ds->sl_rows * 64, 0, 2 * 16 * 64, ctx->stream));
     const nhp_slices sl = slices_view(ds);
     if (ds->n_items > 0)
         hipLaunchKernelGGL(k_slices_build, dim3((unsigned)ds->n_items), dim3(256), 0, ctx->stream, a, sl, ds->d_sl_lo, ds->d_sl_hi);
@@ -283,7 +334,9 @@ nhp_status nhp_launch_windowed_slices(nhp_ctx *ctx, const nhp_cont_dataset *ds, 
     // waves per workgroup from the slices an item has (one item per node at N >= 1024: ~15 slices; short items at small N);
     // rows per request from the windows' length.  NHP_SLICES_CFG = "BLOCK,C" overrides (tools/dbg/slicesweep.sh)
     const int per_item = (ds->max_item + 63) / 64;
-    int B = per_item >= 12 ? 512 : per_item >= 6 ? 256 : per_item >= 3 ? 128 : 64, C = 4;
+    // (rows in flight per wave = 2C: short slices are served by L2 / the Infinity Cache and want few, long ones stream from HBM)
+    const double mean_rows = ds->n_slices > 0 ? (double)ds->sl_rows / (double)ds->n_slices : 0.0;
+    int B = per_item >= 12 ? 512 : per_item >= 6 ? 256 : per_item >= 3 ? 128 : 64, C = mean_rows >= 48.0 ? 8 : mean_rows >= 16.0 ? 4 : 2;
     if (const char *cfg = getenv("NHP_SLICES_CFG")) sscanf(cfg, "%d,%d", &B, &C);
     dim3 grid((unsigned)ds->n_items);
     bool ok = false;
@@ -300,7 +353,7 @@ nhp_status nhp_launch_windowed_slices(nhp_ctx *ctx, const nhp_cont_dataset *ds, 
         ok = true;                                                                                                    \
         if (flat) NHP_SLAUNCH(b, cc, true); else NHP_SLAUNCH(b, cc, false);                                           \
     }
-#define NHP_SROW(b) NHP_SCASE(b, 2) NHP_SCASE(b, 4)
+#define NHP_SROW(b) NHP_SCASE(b, 2) NHP_SCASE(b, 4) NHP_SCASE(b, 8)
     NHP_SROW(64) NHP_SROW(128) NHP_SROW(256) NHP_SROW(512) NHP_SROW(1024)
     if (!ok) { B = 256; C = 4; NHP_SCASE(256, 4) }
 #undef NHP_SLAUNCH

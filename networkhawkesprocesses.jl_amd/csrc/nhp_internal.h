@@ -110,8 +110,8 @@ struct nhp_cont_dataset {
     // the first evaluation that uses them.
     uint32_t *d_sl_row = nullptr;       // [n_slices + 1] first row of each slice
     int32_t *d_sl_item0 = nullptr;      // [n_items + 1] first slice of each item
-    uint32_t *d_sl_lo = nullptr;        // [(sl_rows + 8) * 64]
-    uint16_t *d_sl_hi = nullptr;        // [(sl_rows + 8) * 64]
+    uint32_t *d_sl_lo = nullptr;        // [(sl_rows + 16) * 64]
+    uint16_t *d_sl_hi = nullptr;        // [(sl_rows + 16) * 64]
     int64_t sl_rows = 0;
     int32_t n_slices = 0, sl_nb = 0;    // node bits
     int32_t sl_max_rows = 0;            // most rows of one slice

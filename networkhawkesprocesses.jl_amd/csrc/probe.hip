@@ -132,3 +132,66 @@ extern "C" nhp_status nhp_probe_gather(nhp_ctx *ctx, int32_t n_windows, int32_t 
     return NHP_OK;
 }
 
+
+// Streaming-read calibration for the child-slice kernels: every workgroup sweeps its own contiguous share of a
+// `bytes`-byte buffer, one wave-wide row at a time, `ahead` rows in flight per wave -- mode 0: 16 bytes per lane (the copy
+// kernels' shape), mode 1: the slices' own shape, a 4-byte plane and a 2-byte plane (256 + 128 bytes a row).  Launched back
+// to back, so a buffer below 256 MB is served by the Infinity Cache like the log-likelihood's own repeated evaluations.
+template <int MODE>
+__global__ __launch_bounds__(512) void k_probe_stream(const uint32_t *__restrict__ a32, const uint16_t *__restrict__ a16, size_t rows_per_wave,
+                                                      double *__restrict__ sink)
+{
+    const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    uint32_t acc = 0;
+    if (MODE == 0) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(a32) + wave * rows_per_wave * 64 + lane;
+        for (size_t r = 0; r < rows_per_wave; r += 4) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = p[(r + u) * 64];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+        }
+    } else {
+        const uint32_t *p = a32 + wave * rows_per_wave * 64 + lane;
+        const uint16_t *q = a16 + wave * rows_per_wave * 64 + lane;
+        for (size_t r = 0; r < rows_per_wave; r += 8) {
+            uint32_t v[8], h[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { v[u] = p[(r + u) * 64]; h[u] = q[(r + u) * 64]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u] ^ h[u];
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = 1.0;
+}
+
+extern "C" nhp_status nhp_probe_stream(nhp_ctx *ctx, int32_t mode, int64_t bytes, int32_t blocks, int32_t threads, double *us_per_launch)
+{
+    if (!ctx || !us_per_launch || bytes < 1 || blocks < 1 || (threads != 256 && threads != 512) || (mode != 0 && mode != 1)) return NHP_EINVAL;
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t waves = (size_t)blocks * (size_t)(threads / 64);
+    const size_t row_bytes = mode == 0 ? 1024 : 384;
+    size_t rows_per_wave = (size_t)bytes / row_bytes / waves;
+    rows_per_wave -= rows_per_wave % (mode == 0 ? 4 : 8);
+    if (rows_per_wave < 4) { nhp_set_error(ctx, "probe_stream: buffer too small for the grid"); return NHP_EINVAL; }
+    const size_t n32 = waves * rows_per_wave * 64 * (mode == 0 ? 4 : 1), n16 = mode == 0 ? 0 : waves * rows_per_wave * 64;
+    NHP_TRY(nhp_ctx_reserve_scratch(ctx, 4 * n32 + 2 * n16 + 64));
+    uint32_t *a32 = (uint32_t *)ctx->d_scratch;
+    uint16_t *a16 = (uint16_t *)(a32 + n32);
+    double *sink = (double *)((char *)ctx->d_scratch + ((4 * n32 + 2 * n16 + 7) & ~(size_t)7));
+    NHP_HIP(ctx, hipMemsetAsync(a32, 0, 4 * n32 + 2 * n16, ctx->stream));
+    const int reps = 20;
+    for (int r = 0; r <= reps; ++r) {
+        if (r == 1) NHP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        if (mode == 0) hipLaunchKernelGGL(k_probe_stream<0>, dim3((unsigned)blocks), dim3((unsigned)threads), 0, ctx->stream, a32, a16, rows_per_wave, sink);
+        else hipLaunchKernelGGL(k_probe_stream<1>, dim3((unsigned)blocks), dim3((unsigned)threads), 0, ctx->stream, a32, a16, rows_per_wave, sink);
+    }
+    NHP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    NHP_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    NHP_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *us_per_launch = 1e3 * (double)ms / reps;
+    return NHP_OK;
+}

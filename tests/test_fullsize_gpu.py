@@ -266,3 +266,45 @@ def test_default_dispatch_routes_agree_at_the_metric_size(nhp, orc):
     assert rel(ll_sub, orc.loglik_recursive(om, *sub)) < 1e-11
     assert rel(ll_sub, wll) < 1e-11
     assert np.max(np.abs(g_sub - wg) / np.maximum(1.0, np.abs(wg))) < 1e-9
+
+
+# ------------------------------------------------------------ the other workloads bench.py times, at their real sizes
+@pytest.mark.parametrize("workload", ["windowed_k64", "windowed_k512", "simulated_k32"])
+def test_bench_workloads_at_full_size(nhp, orc, workload):
+    """`bench.py` times the exponential log-likelihood at N = 1024, M = 1e6 for mean windows of 64 and 512 parents and on
+    events drawn from the model itself (`simulated_k32`, burstier windows), each through its own kernel route (child slices
+    up to the middle windows, 8- / 16-byte event records beyond).  The same data the bench builds, checked like the metric
+    size: per-event intensities of three 1000-event slices against the oracle (src/continuous.jl:286-300), the
+    log-likelihood = integral + Σ log λ of the returned intensities (src/continuous.jl:216-237), and the parent sampler's
+    indices on one slice bit-equal to the oracle's (src/parents.jl:25-46)."""
+    import bench
+    w = bench.WORKLOADS[workload]
+    N, M = 1024, 1_000_000
+    times, nodes, T = nhp.synthetic.s_metric_data(N, M, kbar=w["kbar"])
+    proc = nhp.synthetic.s_metric_process(N, M, T, w["kind"], 1.0)
+    if w.get("simulated"):
+        times, nodes, T = nhp.synthetic.simulated_data(proc, T, seed=0)
+        M = len(times)
+    data = (times, nodes, T)
+    lam0, W = proc.baseline.λ, proc.weights.W
+    om = orc.ContModel(lam0, W, theta=proc.impulses.θ, dt_max=1.0)
+    lam = nhp.total_intensity(proc, data)
+    starts = (0, M // 3 + 17, M - 1000)
+    for i0 in starts:
+        want = orc.total_intensity(om, times, nodes, i0, i0 + 1000)
+        assert np.max(np.abs(lam[i0:i0 + 1000] - want) / want) < 1e-12
+    integral = -(lam0 * T).sum() - (np.bincount(nodes - 1, minlength=N) @ W.sum(axis=1))
+    ll = nhp.loglikelihood(proc, data, recursive=False)
+    assert rel(ll, integral + np.log(lam).sum()) < 1e-6             # contractual tolerance (BASELINE.json north_star)
+    assert rel(ll, integral + np.log(lam).sum()) < 1e-11
+    # parent sampler: one slice with its look-back prefix (the oracle sees events [a, i1))
+    seed, step = 5, 2
+    p, pn = nhp.resample_parents(proc, data, seed=seed, step=step)
+    u = orc.uniform_stream(seed, step, M)
+    i0 = starts[1]
+    i1 = i0 + 1000
+    a = max(int(np.searchsorted(times, times[i0] - 1.0, side="right")) - 1, 0)
+    wp, wpn = orc.resample_parents(om, times[a:i1], nodes[a:i1], u[a:i1], flags=orc.MATH_DET)
+    wp = np.where(wp > 0, wp + a, 0)[i0 - a:]
+    assert np.array_equal(p[i0:i1], wp)                             # bit-exact indices (north_star)
+    assert np.array_equal(pn[i0:i1], wpn[i0 - a:])
