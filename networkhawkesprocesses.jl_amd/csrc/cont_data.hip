@@ -193,6 +193,15 @@ extern "C" nhp_status nhp_cont_dataset_create_columns(nhp_ctx *ctx, const double
             if (it.node >= col_begin && it.node < col_end) own.push_back(it);
         items.swap(own);
     }
+    {   // bit 1 of `first`: the node's only item
+        std::vector<int32_t> per_node((size_t)N, 0);
+        for (const nhp_item &it : items) per_node[(size_t)it.node]++;
+        ds->all_sole = !items.empty();
+        for (nhp_item &it : items) {
+            if (per_node[(size_t)it.node] == 1) it.first |= 2;
+            else ds->all_sole = false;
+        }
+    }
     ds->n_items = (int32_t)items.size();
     for (const nhp_item &it : items) ds->max_item = std::max(ds->max_item, it.kend - it.kbeg);
     lap("bucketing + items");
@@ -370,6 +379,7 @@ extern "C" void nhp_cont_dataset_destroy(nhp_cont_dataset *ds)
     (void)hipStreamSynchronize(ds->ctx->stream);
     (void)hipFree(ds->d_times); (void)hipFree(ds->d_nodes); (void)hipFree(ds->d_child); (void)hipFree(ds->d_child_w); (void)hipFree(ds->d_wpos); (void)hipFree(ds->d_ev); (void)hipFree(ds->d_ev8); (void)hipFree(ds->d_poff); (void)hipFree(ds->d_plist); (void)hipFree(ds->d_plq); (void)hipFree(ds->d_pnode);
     (void)hipFree(ds->d_sl_row); (void)hipFree(ds->d_sl_item0); (void)hipFree(ds->d_sl_lo); (void)hipFree(ds->d_sl_hi);
+    (void)hipFree(ds->d_ps_row); (void)hipFree(ds->d_ps_perm); (void)hipFree(ds->d_ps_lo); (void)hipFree(ds->d_ps_hi);
     (void)hipFree(ds->d_boff); (void)hipFree(ds->d_items); (void)hipFree(ds->d_cnt); (void)hipFree(ds->d_pn);
     (void)hipFree(ds->d_adj_k); (void)hipFree(ds->d_adj_p); (void)hipFree(ds->d_adj_dt); (void)hipFree(ds->d_adj_lq); (void)hipFree(ds->d_adj_start); (void)hipFree(ds->d_adj_off); (void)hipFree(ds->d_adj_group); (void)hipFree(ds->d_child_cut);
     (void)hipFree(ds->d_rec_ev); (void)hipFree(ds->d_rec_poff); (void)hipFree(ds->d_rec_rank);

@@ -474,6 +474,18 @@ nhp_status nhp_grad_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_
     } else {
         const int mask = child_cut ? 0 : 1;
         const int G = child_cut ? cut_group : ds->group;
+        // exponential impulses on the dataset's own short / middle windows: ONE launch over the child and the parent slices
+        // (cont_slices.hip: no LDS atomics, no λ round trip through HBM; k_grad_init only where items share a column)
+        if (!child_cut && exp_imp && ds->d_sl_row && !(getenv("NHP_SLICES") && atoi(getenv("NHP_SLICES")) == 0) &&
+            !(getenv("NHP_GRAD_SLICES") && atoi(getenv("NHP_GRAD_SLICES")) == 0)) {
+            if (!nhp_grad_slices_direct(ds, m)) {
+                hipLaunchKernelGGL(k_grad_init, dim3(1024), dim3(256), 0, st, a, mask, d_grad);
+                NHP_HIP(ctx, hipGetLastError());
+            }
+            bool launched = false;
+            NHP_TRY(nhp_launch_grad_slices(ctx, ds, m, ctx->d_results, d_grad, &launched));
+            if (launched) return NHP_OK;
+        }
         if (child_cut) { a.child = child_cut; a.child_w = child_cut; }
         hipLaunchKernelGGL(k_grad_init, dim3(1024), dim3(256), 0, st, a, mask, d_grad);
         NHP_HIP(ctx, hipGetLastError());

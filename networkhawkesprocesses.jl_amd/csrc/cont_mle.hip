@@ -24,16 +24,28 @@ extern "C" nhp_status nhp_cont_mle_run(nhp_ctx *ctx, nhp_comm *comm, const nhp_c
     const size_t nb = m->baseline_kind == NHP_BASELINE_HOMOGENEOUS ? N : N * (size_t)m->grid_n;
     const size_t nimp = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL ? NN : 2 * NN;
     if ((size_t)P != nb + nimp + NN) { nhp_set_error(ctx, "Parameter vector length does not match model parameter length."); return NHP_ESHAPE; }
-    // params!(process, x) from a DEVICE vector, then the log-likelihood (-> ctx->d_results[0]) and g = -∇ll at it
-    auto eval = [&](const double *d_x, double *d_g) -> nhp_status {
+    // params!(process, x) from a DEVICE vector, then the log-likelihood (-> ctx->d_results[0]) and g = -∇ll at it.  A trial is
+    // evaluated straight from the optimizer's vector -- a view of the model whose tables point into d_x ([λ0; θ | μ; τ; W] is
+    // params! order: the blocks ARE the tables) -- so no parameter is copied per evaluation; the run's last call (commit)
+    // puts the iterate into the model's own tables.
+    auto eval = [&](const double *d_x, double *d_g, bool commit) -> nhp_status {
         hipStream_t st = ctx->stream;
         ++m->version;
-        NHP_HIP(ctx, hipMemcpyAsync(m->d_lambda0, d_x, 8 * nb, hipMemcpyDeviceToDevice, st));
-        NHP_HIP(ctx, hipMemcpyAsync(m->d_p1, d_x + nb, 8 * NN, hipMemcpyDeviceToDevice, st));
-        if (m->impulse_kind == NHP_IMPULSE_LOGITNORMAL) NHP_HIP(ctx, hipMemcpyAsync(m->d_p2, d_x + nb + NN, 8 * NN, hipMemcpyDeviceToDevice, st));
-        NHP_HIP(ctx, hipMemcpyAsync(m->d_W, d_x + nb + nimp, 8 * NN, hipMemcpyDeviceToDevice, st));
+        nhp_cont_model view = *m;
+        if (commit) {
+            NHP_HIP(ctx, hipMemcpyAsync(m->d_lambda0, d_x, 8 * nb, hipMemcpyDeviceToDevice, st));
+            NHP_HIP(ctx, hipMemcpyAsync(m->d_p1, d_x + nb, 8 * NN, hipMemcpyDeviceToDevice, st));
+            if (m->impulse_kind == NHP_IMPULSE_LOGITNORMAL) NHP_HIP(ctx, hipMemcpyAsync(m->d_p2, d_x + nb + NN, 8 * NN, hipMemcpyDeviceToDevice, st));
+            NHP_HIP(ctx, hipMemcpyAsync(m->d_W, d_x + nb + nimp, 8 * NN, hipMemcpyDeviceToDevice, st));
+        } else {
+            double *x = const_cast<double *>(d_x);                  // (read-only through the view)
+            view.d_lambda0 = x; view.d_p1 = x + nb; view.d_W = x + nb + nimp;
+            if (m->impulse_kind == NHP_IMPULSE_LOGITNORMAL) view.d_p2 = x + nb + NN;
+        }
         double *d_grad = nullptr;
-        NHP_TRY(nhp_grad_enqueue_reduced(ctx, comm, ds, m, flags, P, &d_grad));
+        const nhp_status rc = nhp_grad_enqueue_reduced(ctx, comm, ds, &view, flags, P, &d_grad);
+        m->rec_version = view.rec_version; m->rec_ds = view.rec_ds; m->rec_cut = view.rec_cut;    // (the recursive route's cached bound)
+        NHP_TRY(rc);
         hipLaunchKernelGGL(k_mle_neg, dim3((unsigned)std::min<int64_t>(2048, (P + 255) / 256)), dim3(256), 0, st, d_g, (const double *)d_grad, P);
         NHP_HIP(ctx, hipGetLastError());
         return NHP_OK;

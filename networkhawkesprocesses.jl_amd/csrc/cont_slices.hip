@@ -16,6 +16,7 @@
 //  * Σ log λ as one logarithm per lane of a running mantissa product; block sums and the fused last-workgroup reduction as
 //    in k_windowed.
 #include <algorithm>
+#include <vector>
 
 #include "nhp_internal.h"
 #include "nhp_math.h"
@@ -69,6 +70,24 @@ __device__ __forceinline__ double sl_baseline_integral_col(const nhp_cont_args &
     return I;
 }
 
+// ∂ log λ_i / ∂(grid intensities of node c) for an event at time t: g = 1/λ_i spread over the two grid neighbours with the
+// interpolation weights (src/utils/interpolation.jl:26-35); as grad_lgcp_scatter of cont_grad.hip
+__device__ __forceinline__ void sl_lgcp_scatter(const nhp_cont_args &a, int c, double t, double g, double *grad)
+{
+    const double *x = a.grid;
+    const int G = a.grid_n;
+    double *gc = grad + (size_t)c * G;
+    int lo = 0, hi = G - 1;
+    if (!(t < x[hi])) { atomicAdd(&gc[hi], g); return; }
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (t >= x[mid]) lo = mid; else hi = mid;
+    }
+    const double w = x[lo + 1] - x[lo];
+    atomicAdd(&gc[lo], g * (x[lo + 1] - t) / w);
+    atomicAdd(&gc[lo + 1], g * (t - x[lo]) / w);
+}
+
 // Fills the planes: wave = slice, lane = child, row r = the child's r-th most recent parent (src/continuous.jl:290-298 walks
 // the window in this order).  Delays are rounded to 2^-dbits of Δtmax and kept inside [1, 2^dbits - 1] (a tie Δt = 0 becomes
 // one unit: 7e-12·Δtmax at N = 1024); rows past a child's window hold {node N, delay 0}.
@@ -105,11 +124,135 @@ __global__ __launch_bounds__(256) void k_slices_build(nhp_cont_args a, nhp_slice
     }
 }
 
+struct nhp_pslices {              // kernel-side view of the parent slices (nhp_cont_dataset::d_ps_*) + where the gradient goes
+    const uint32_t *row;          // [n_items * spi + 1]
+    const uint16_t *perm;         // [n_items * spi * 64]
+    const uint32_t *lo;
+    const uint16_t *hi;
+    int32_t spi;                  // parent slices per item
+    int32_t psh;                  // 16 - slot bits: hi = slot << psh | delay >> 32
+    uint32_t dmask;
+    int32_t dbits;
+    int32_t max_item;             // the padding records' slot (its 1/λ is 0)
+    int32_t direct;               // every item is its node's only one, whole dataset, flat baseline: the gradient is stored, not added
+    double *grad;                 // [P] params! order
+};
+
+// pairs of every item by parent node: cnt[item * N + p]
+__global__ __launch_bounds__(256) void k_ps_count(nhp_cont_args a, uint32_t *__restrict__ cnt)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
+    const nhp_item it = a.items[blockIdx.x];
+    for (int p = threadIdx.x; p < a.N; p += 256) hist[p] = 0;
+    __syncthreads();
+    for (int k = it.kbeg + threadIdx.x; k < it.kend; k += 256) {
+        const nhp_child ch = a.child_w[k];
+        for (int j = ch.idx - 1; j >= ch.first; --j) atomicAdd(&hist[a.ev[j].node], 1u);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < a.N; p += 256) cnt[(size_t)blockIdx.x * a.N + p] = hist[p];
+}
+
+// the item's parent nodes by pair count (most first, ties by node): lane order of the parent slices, rows of every slice
+__global__ __launch_bounds__(256) void k_ps_rank(int N, int spi, const uint32_t *__restrict__ cnt, uint16_t *__restrict__ perm,
+                                                 uint16_t *__restrict__ rankof, uint32_t *__restrict__ rows)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *c = reinterpret_cast<uint32_t *>(smem);
+    for (int p = threadIdx.x; p < N; p += 256) c[p] = cnt[(size_t)blockIdx.x * N + p];
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * spi * 64;
+    for (int p = threadIdx.x; p < N; p += 256) {
+        const uint32_t mine = c[p];
+        int rank = 0;
+        for (int q = 0; q < N; ++q) rank += (c[q] > mine || (c[q] == mine && q < p)) ? 1 : 0;
+        perm[base + rank] = (uint16_t)p;
+        rankof[(size_t)blockIdx.x * N + p] = (uint16_t)rank;
+        if ((rank & 63) == 0) rows[(size_t)blockIdx.x * spi + (rank >> 6)] = mine;
+    }
+    for (int q = N + threadIdx.x; q < spi * 64; q += 256) perm[base + q] = 0xFFFFu;
+}
+
+// every pair into its parent's lane (position by an LDS ticket: any order), then the rest of the lane padded
+__global__ __launch_bounds__(256) void k_ps_fill(nhp_cont_args a, nhp_pslices ps, const uint32_t *__restrict__ cnt, const uint16_t *__restrict__ rankof,
+                                                 uint32_t *__restrict__ lo, uint16_t *__restrict__ hi)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *cursor = reinterpret_cast<uint32_t *>(smem);
+    const nhp_item it = a.items[blockIdx.x];
+    const int N = a.N;
+    for (int p = threadIdx.x; p < N; p += 256) cursor[p] = 0;
+    __syncthreads();
+    const double two_d = __builtin_ldexp(1.0, ps.dbits);
+    const double scale = a.inv_dtmax * two_d, qmax = two_d - 1.0;
+    const uint32_t *row = ps.row + (size_t)blockIdx.x * ps.spi;
+    for (int k = it.kbeg + threadIdx.x; k < it.kend; k += 256) {
+        const nhp_child ch = a.child_w[k];
+        const uint32_t slot = (uint32_t)(k - it.kbeg);
+        for (int j = ch.idx - 1; j >= ch.first; --j) {
+            const nhp_event e = a.ev[j];
+            const uint32_t pos = atomicAdd(&cursor[e.node], 1u);
+            const int rk = rankof[(size_t)blockIdx.x * N + e.node];
+            double q = __builtin_rint((ch.t - e.t) * scale);
+            q = q < 1.0 ? 1.0 : (q > qmax ? qmax : q);
+            const uint64_t qi = (uint64_t)q;
+            const size_t o = ((size_t)row[rk >> 6] + pos) * 64 + (size_t)(rk & 63);
+            lo[o] = (uint32_t)qi;
+            hi[o] = (uint16_t)((slot << ps.psh) | (uint32_t)(qi >> 32));
+        }
+    }
+    // lanes shorter than their slice, and the lanes behind the last node
+    for (int rk = threadIdx.x; rk < ps.spi * 64; rk += 256) {
+        const int p = ps.perm[(size_t)blockIdx.x * ps.spi * 64 + rk];
+        const uint32_t n = p == 0xFFFF ? 0u : cnt[(size_t)blockIdx.x * N + p];
+        const uint32_t r0 = row[rk >> 6], R = row[(rk >> 6) + 1] - r0;
+        for (uint32_t i = n; i < R; ++i) {
+            const size_t o = ((size_t)r0 + i) * 64 + (size_t)(rk & 63);
+            lo[o] = 0;
+            hi[o] = (uint16_t)((uint32_t)ps.max_item << ps.psh);
+        }
+    }
+}
+
+// every lane's records sorted by (slot, delay): the list is the same whatever order the tickets were drawn in
+__global__ __launch_bounds__(256) void k_ps_sort(int N, nhp_pslices ps, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ lo,
+                                                 uint16_t *__restrict__ hi)
+{
+    const uint32_t *row = ps.row + (size_t)blockIdx.x * ps.spi;
+    for (int rk = threadIdx.x; rk < ps.spi * 64; rk += 256) {
+        const int p = ps.perm[(size_t)blockIdx.x * ps.spi * 64 + rk];
+        if (p == 0xFFFF) continue;
+        const int n = (int)cnt[(size_t)blockIdx.x * N + p];
+        const size_t o0 = (size_t)row[rk >> 6] * 64 + (size_t)(rk & 63);
+        for (int i = 1; i < n; ++i) {
+            const uint32_t l = lo[o0 + (size_t)i * 64], h = hi[o0 + (size_t)i * 64];
+            const uint64_t key = ((uint64_t)h << 32) | l;
+            int j = i - 1;
+            while (j >= 0) {
+                const uint32_t lj = lo[o0 + (size_t)j * 64], hj = hi[o0 + (size_t)j * 64];
+                if ((((uint64_t)hj << 32) | lj) <= key) break;
+                lo[o0 + (size_t)(j + 1) * 64] = lj;
+                hi[o0 + (size_t)(j + 1) * 64] = (uint16_t)hj;
+                --j;
+            }
+            lo[o0 + (size_t)(j + 1) * 64] = l;
+            hi[o0 + (size_t)(j + 1) * 64] = (uint16_t)h;
+        }
+    }
+}
+
 // C rows of a slice are requested at a time into one of two register sets: the next set is in flight while this one is
 // summed, across slice boundaries too (the first rows of a wave's next slice are requested under the last rows of this one,
 // and the very first set before the column is staged: its addresses need the slice table only).
-template <int BLOCK, int C, bool FLAT>
-__global__ __launch_bounds__(BLOCK) void k_windowed_slices(nhp_cont_args a, nhp_slices sl, int mask_integral,
+// GRAD: the analytic gradient in the same launch (the objective of mle!, src/continuous.jl:144-198, differentiated by hand;
+// formulas at the top of cont_grad.hip).  Phase A is the log-likelihood itself and leaves g_k = 1/λ_k of the item's children
+// in LDS; phase B walks the item's PARENT slices -- lane = parent node p, its θ[p,c], W[p,c] in registers, row r = the node's
+// r-th pair as {child slot, delay} -- and every lane sums Σ g·e^{-θΔ} and Σ g·(1-θΔ)·e^{-θΔ} over its own pairs: no atomics,
+// no cross-lane step, the list streamed once.  An item that is its node's only one stores the column's gradient (the
+// parameter-independent terms included), others add to what k_grad_init left.
+template <int BLOCK, int C, bool FLAT, bool GRAD>
+__global__ __launch_bounds__(BLOCK) void k_windowed_slices(nhp_cont_args a, nhp_slices sl, nhp_pslices ps, int mask_integral,
                                                             double *__restrict__ partials, unsigned int *__restrict__ counter,
                                                             double *__restrict__ out)
 {
@@ -118,6 +261,7 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_slices(nhp_cont_args a, nhp_
     double *red = reinterpret_cast<double *>(smem);                 // [2 * NW <= 32] + flag at [32]
     double2 *col = reinterpret_cast<double2 *>(smem + 320);         // [N + 1] {-θ·unit·64/ln2, a·w·θ}; [N] = {0, 0}
     double *etab = reinterpret_cast<double *>(col + a.N + 1);       // [64] 2^(j/64)
+    double *ginv = etab + 64;                                       // GRAD: [max_item + 1] 1/λ of the item's children; [max_item] = 0
     const int tid = threadIdx.x, lane = tid & 63;
     const double tab_v = nhp_exp2_64[lane];                         // requested first, parked in LDS with the column (one wait)
 
@@ -131,10 +275,10 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_slices(nhp_cont_args a, nhp_
     // Rows r .. r+C-1 of the slice that starts at row `row0`: a wave-uniform base and compile-time row offsets.  Rows past the
     // slice's last are simply the next slice's (or the 16 rows of padding behind the list): loaded, never summed.
     struct chunk { uint32_t lo[C], hi[C]; };
-    auto request = [&](chunk &q, const uint32_t row0, const int r) {
+    auto request = [&](chunk &q, const uint32_t *plo, const uint16_t *phi, const uint32_t row0, const int r) {
         const size_t o = ((size_t)row0 + (size_t)r) * 64;
-        const uint32_t *pl = sl.lo + o;
-        const uint16_t *ph = sl.hi + o;
+        const uint32_t *pl = plo + o;
+        const uint16_t *ph = phi + o;
 #pragma unroll
         for (int u = 0; u < C; ++u) {
             q.lo[u] = pl[u * 64 + lane];
@@ -151,7 +295,7 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_slices(nhp_cont_args a, nhp_
     int K = 0;
     chunk qa, qb;
     double integ = 0.0;
-    for (int p0 = 0; p0 < N || p0 == 0; p0 += UN * BLOCK) {
+    for (int p0 = 0; p0 < N; p0 += UN * BLOCK) {
         double w_[UN], th_[UN], a_[UN], cnt_[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -165,7 +309,7 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_slices(nhp_cont_args a, nhp_
         if (p0 == 0) {
             if (j < ns) { row0 = sl.row[s0 + j]; K = (int)(sl.row[s0 + j + 1] - row0); }
             asm volatile("" ::: "memory");
-            request(qa, row0, 0);
+            request(qa, sl.lo, sl.hi, row0, 0);
             asm volatile("" ::: "memory");
         }
 #pragma unroll
@@ -184,6 +328,7 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_slices(nhp_cont_args a, nhp_
     }
     if (tid < 64) etab[tid] = tab_v;
     if (tid == 0) col[N] = make_double2(0.0, 0.0);
+    if (GRAD && tid == 0) ginv[ps.max_item] = 0.0;
     if (out && it.first) integ += sl_baseline_integral_col(a, c);
     __syncthreads();
     NHP_SL_STAMP(1);
@@ -191,11 +336,14 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_slices(nhp_cont_args a, nhp_
     const double lam0 = FLAT ? a.lambda0[c] : 0.0;
     const uint32_t dmask = sl.dmask;
     const int nsh = sl.nsh;
-    auto term = [&](const uint32_t lo, const uint32_t h) {
-        // the high delay bits under the exponent of 2^52 (one v_bfi_b32): the double 2^52 + delay
+    // the high delay bits under the exponent of 2^52 (one v_bfi_b32): the double 2^52 + delay, minus 2^52
+    auto delay = [&](const uint32_t lo, const uint32_t h, const uint32_t mask) {
         uint32_t hw;
-        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hw) : "s"(dmask), "v"(h), "v"(0x43300000u));
-        const double v = __hiloint2double((int)hw, (int)lo) - 4503599627370496.0;
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hw) : "s"(mask), "v"(h), "v"(0x43300000u));
+        return __hiloint2double((int)hw, (int)lo) - 4503599627370496.0;
+    };
+    auto term = [&](const uint32_t lo, const uint32_t h) {
+        const double v = delay(lo, h, dmask);
         const double2 cw = col[h >> nsh];
         return cw.y * nhp_exp_neg_tab_scaled(cw.x * v, etab);
     };
@@ -216,7 +364,7 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_slices(nhp_cont_args a, nhp_
         }
         return s;
     };
-    double prod = 1.0;
+    double prod = 1.0, gsum = 0.0;
     int pexp = 0;
     while (j < ns) {
         const int jn = j + NW;
@@ -224,31 +372,126 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_slices(nhp_cont_args a, nhp_
         int Kn = 0;
         if (jn < ns) { row0n = sl.row[s0 + jn]; Kn = (int)(sl.row[s0 + jn + 1] - row0n); }
         double s = 0.0;
-        if (K <= 0) request(qa, row0n, 0);
+        if (K <= 0) request(qa, sl.lo, sl.hi, row0n, 0);
         for (int r0 = 0; r0 < K; r0 += 2 * C) {
-            request(qb, row0, r0 + C);
+            request(qb, sl.lo, sl.hi, row0, r0 + C);
             asm volatile("" ::: "memory");
             s = sum(qa, r0, K, s);
             const bool more = r0 + 2 * C < K;
-            request(qa, more ? row0 : row0n, more ? r0 + 2 * C : 0);
+            request(qa, sl.lo, sl.hi, more ? row0 : row0n, more ? r0 + 2 * C : 0);
             asm volatile("" ::: "memory");
             s = sum(qb, r0 + C, K, s);
         }
         const int kk = 64 * j + lane;
         if (kk < nchild) {
-            const double lam = (FLAT ? lam0 : sl_baseline(a, c, a.child_w[it.kbeg + kk].t)) + s;
+            const double tk = FLAT ? 0.0 : a.child_w[it.kbeg + kk].t;
+            const double lam = (FLAT ? lam0 : sl_baseline(a, c, tk)) + s;
             prod *= lam < 0.0 ? __builtin_nan("") : __builtin_amdgcn_frexp_mant(lam);
             pexp += __builtin_amdgcn_frexp_exp(lam);
+            if (GRAD) {
+                const double g = 1.0 / lam;
+                ginv[kk] = g;
+                if (FLAT) gsum += g;
+                else sl_lgcp_scatter(a, c, tk, g, ps.grad);
+            }
         }
         pexp += __builtin_amdgcn_frexp_exp(prod);
         prod = __builtin_amdgcn_frexp_mant(prod);
         j = jn; row0 = row0n; K = Kn;
     }
     NHP_SL_STAMP(2);
+    if (GRAD) {
+        // ---- phase B: the item's pairs by parent node ----
+        const uint32_t *prow = ps.row + (size_t)blockIdx.x * ps.spi;
+        const uint16_t *pperm = ps.perm + (size_t)blockIdx.x * ps.spi * 64;
+        const double punit = __builtin_ldexp(a.dt_max, -ps.dbits);
+        const uint32_t pmask = ps.dmask;
+        const int psh = ps.psh;
+        const size_t nbase = a.baseline_kind == NHP_BASELINE_HOMOGENEOUS ? (size_t)N : (size_t)N * (size_t)a.grid_n;
+        const size_t NN = (size_t)N * (size_t)N;
+        // a lane's node and its parameters, requested a slice ahead
+        struct lanep { int p; double th, wv, av, cn; };
+        auto lane_params = [&](const int jj) {
+            lanep q;
+            q.p = jj < ps.spi ? (int)pperm[jj * 64 + lane] : 0xFFFF;
+            const size_t k = (size_t)(q.p == 0xFFFF ? 0 : q.p) + (size_t)c * N;
+            q.th = a.p1[k];
+            q.wv = a.W[k];
+            q.av = a.A ? a.A[k] : 1.0;
+            q.cn = ps.direct ? a.cnt[q.p == 0xFFFF ? 0 : q.p] : 0.0;
+            return q;
+        };
+        int jp = w;
+        uint32_t prow0 = 0;
+        int Kp = 0;
+        if (jp < ps.spi) { prow0 = prow[jp]; Kp = (int)(prow[jp + 1] - prow0); }
+        lanep cur = lane_params(jp);
+        request(qa, ps.lo, ps.hi, prow0, 0);
+        __syncthreads();                                            // every wave's g_k are in LDS
+        auto gterm = [&](const uint32_t lo, const uint32_t h, const double xs, double &accH, double &acc1) {
+            const double v = delay(lo, h, pmask);
+            const double g = ginv[h >> psh];
+            const double t = xs * v;
+            const double ge = g * nhp_exp_neg_tab_scaled(t, etab);
+            accH += ge;                                             // Σ g·e^{-θΔ}
+            acc1 = __builtin_fma(ge, __builtin_fma(t, 1.0830424696249145e-02, 1.0), acc1);   // Σ g·(1 - θΔ)·e^{-θΔ}; θΔ = -t·ln2/64
+        };
+        auto gsum_chunk = [&](const chunk &q, const int r, const int K, const double xs, double &accH, double &acc1) {
+            if (r + C <= K) {
+#pragma unroll
+                for (int u = 0; u < C; ++u) gterm(q.lo[u], q.hi[u], xs, accH, acc1);
+            } else {
+#pragma unroll
+                for (int u = 0; u < C; ++u)
+                    if (r + u < K) gterm(q.lo[u], q.hi[u], xs, accH, acc1);
+            }
+        };
+        while (jp < ps.spi) {
+            const int jn = jp + NW;
+            uint32_t row0n = 0;
+            int Kn = 0;
+            if (jn < ps.spi) { row0n = prow[jn]; Kn = (int)(prow[jn + 1] - row0n); }
+            const lanep nxt = lane_params(jn);
+            const double xs = -((cur.th * punit) * 92.33248261689366);
+            double accH = 0.0, acc1 = 0.0;
+            if (Kp <= 0) request(qa, ps.lo, ps.hi, row0n, 0);
+            for (int r0 = 0; r0 < Kp; r0 += 2 * C) {
+                request(qb, ps.lo, ps.hi, prow0, r0 + C);
+                asm volatile("" ::: "memory");
+                gsum_chunk(qa, r0, Kp, xs, accH, acc1);
+                const bool more = r0 + 2 * C < Kp;
+                request(qa, ps.lo, ps.hi, more ? prow0 : row0n, more ? r0 + 2 * C : 0);
+                asm volatile("" ::: "memory");
+                gsum_chunk(qb, r0 + C, Kp, xs, accH, acc1);
+            }
+            if (cur.p != 0xFFFF) {
+                const size_t k = (size_t)cur.p + (size_t)c * N;
+                const double gW = cur.av * (cur.th * accH);         // ∂/∂W[p,c]: a Σ g·θ e^{-θΔ}
+                const double gT = (cur.av * cur.wv) * acc1;         // ∂/∂θ[p,c]: a·w Σ g·(1 - θΔ) e^{-θΔ}
+                if (ps.direct) {
+                    const double mk = (a.A && mask_integral) ? cur.av : 1.0;
+                    ps.grad[nbase + NN + k] = gW - cur.cn * mk;
+                    ps.grad[nbase + k] = gT;
+                } else {
+                    if (gW != 0.0) atomicAdd(&ps.grad[nbase + NN + k], gW);
+                    if (gT != 0.0) atomicAdd(&ps.grad[nbase + k], gT);
+                }
+            }
+            jp = jn; prow0 = row0n; Kp = Kn; cur = nxt;
+        }
+    }
     double acc = nhp_log(prod) + (double)pexp * 6.93147180559945286e-01;
     if (prod == 0.0) acc = -__builtin_inf();
     double blk = acc, blk_int = integ;
     nhp_block_sum2_n<NW>(blk, blk_int, red);
+    if (GRAD && FLAT) {
+        const double gs = nhp_block_sum_n<NW>(gsum, red);
+        if (tid == 0) {
+            if (ps.direct) ps.grad[c] = gs - a.duration;
+            else if (gs != 0.0) atomicAdd(&ps.grad[c], gs);
+        }
+        __syncthreads();
+    }
     NHP_SL_STAMP(3);
     if (!out) {
         if (tid == 0) {
@@ -318,19 +561,100 @@ static nhp_status ensure_slices(nhp_ctx *ctx, const nhp_cont_dataset *cds, const
     return NHP_OK;
 }
 
-nhp_status nhp_launch_windowed_slices(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, int mask_integral,
-                                      double *d_out, bool *launched)
+static nhp_pslices pslices_view(const nhp_cont_dataset *ds)
+{
+    nhp_pslices ps;
+    ps.row = ds->d_ps_row; ps.perm = ds->d_ps_perm; ps.lo = ds->d_ps_lo; ps.hi = ds->d_ps_hi;
+    ps.spi = ds->ps_spi;
+    ps.psh = 16 - ds->ps_sb;
+    ps.dmask = (1u << ps.psh) - 1u;
+    ps.dbits = 32 + ps.psh;
+    ps.max_item = ds->max_item;
+    ps.direct = 0;
+    ps.grad = nullptr;
+    return ps;
+}
+
+// The parent slices, made at the first gradient that wants them (data only): pair counts by (item, parent node) -> the
+// lanes' order and every slice's rows (device) -> row offsets (host prefix sum over n_items·spi numbers: the one
+// synchronisation) -> fill through LDS tickets -> every lane sorted.
+static nhp_status ensure_parent_slices(nhp_ctx *ctx, const nhp_cont_dataset *cds, const nhp_cont_args &a)
+{
+    if (cds->d_ps_lo) return NHP_OK;
+    nhp_cont_dataset *ds = const_cast<nhp_cont_dataset *>(cds);
+    const int N = ds->N, spi = (N + 63) / 64, ni = ds->n_items;
+    int sb = 0;
+    while (((int64_t)1 << sb) <= ds->max_item) ++sb;               // bit length of max_item: the padding records' slot
+    if (sb > 16 || 4 * (size_t)N > 160 * 1024) { nhp_set_error(ctx, "parent slices: item or node count out of range"); return NHP_ENOTIMPL; }
+    uint32_t *d_cnt = nullptr, *d_rows = nullptr;
+    uint16_t *d_rankof = nullptr;
+    auto fail = [&](nhp_status st, const char *what) {
+        (void)hipGetLastError();
+        (void)hipFree(d_cnt); (void)hipFree(d_rows); (void)hipFree(d_rankof);
+        (void)hipFree(ds->d_ps_row); (void)hipFree(ds->d_ps_perm); (void)hipFree(ds->d_ps_lo); (void)hipFree(ds->d_ps_hi);
+        ds->d_ps_row = nullptr; ds->d_ps_perm = nullptr; ds->d_ps_lo = nullptr; ds->d_ps_hi = nullptr;
+        nhp_set_error(ctx, "parent slices: %s", what);
+        return st;
+    };
+    if (hipMalloc((void **)&d_cnt, 4 * (size_t)ni * N) != hipSuccess || hipMalloc((void **)&d_rows, 4 * (size_t)ni * spi) != hipSuccess ||
+        hipMalloc((void **)&d_rankof, 2 * (size_t)ni * N) != hipSuccess ||
+        hipMalloc((void **)&ds->d_ps_perm, 2 * (size_t)ni * spi * 64) != hipSuccess ||
+        hipMalloc((void **)&ds->d_ps_row, 4 * ((size_t)ni * spi + 1)) != hipSuccess)
+        return fail(NHP_ENOMEM, "out of device memory");
+    const size_t lds = 4 * (size_t)N;
+    if (lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void *)k_ps_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)k_ps_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)k_ps_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    hipLaunchKernelGGL(k_ps_count, dim3((unsigned)ni), dim3(256), lds, ctx->stream, a, d_cnt);
+    hipLaunchKernelGGL(k_ps_rank, dim3((unsigned)ni), dim3(256), lds, ctx->stream, N, spi, d_cnt, ds->d_ps_perm, d_rankof, d_rows);
+    if (hipGetLastError() != hipSuccess) return fail(NHP_EHIP, "launch failed");
+    std::vector<uint32_t> rows((size_t)ni * spi), off((size_t)ni * spi + 1);
+    if (hipMemcpyAsync(rows.data(), d_rows, 4 * rows.size(), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(NHP_EHIP, "copy failed");
+    uint64_t run = 0;
+    for (size_t q = 0; q < rows.size(); ++q) { off[q] = (uint32_t)run; run += rows[q]; }
+    off[rows.size()] = (uint32_t)run;
+    if (run >= ((uint64_t)1 << 25)) return fail(NHP_ENOTIMPL, "too many rows");
+    ds->ps_rows = (int64_t)run; ds->ps_spi = spi; ds->ps_sb = sb;
+    const size_t n = ((size_t)run + 16) * 64;
+    if (hipMalloc((void **)&ds->d_ps_lo, 4 * n) != hipSuccess || hipMalloc((void **)&ds->d_ps_hi, 2 * n) != hipSuccess)
+        return fail(NHP_ENOMEM, "out of device memory");
+    if (hipMemcpyAsync(ds->d_ps_row, off.data(), 4 * off.size(), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemsetAsync(ds->d_ps_lo + (size_t)run * 64, 0, 4 * 16 * 64, ctx->stream) != hipSuccess ||
+        hipMemsetAsync(ds->d_ps_hi + (size_t)run * 64, 0, 2 * 16 * 64, ctx->stream) != hipSuccess)
+        return fail(NHP_EHIP, "copy failed");
+    const nhp_pslices ps = pslices_view(ds);
+    hipLaunchKernelGGL(k_ps_fill, dim3((unsigned)ni), dim3(256), lds, ctx->stream, a, ps, d_cnt, d_rankof, ds->d_ps_lo, ds->d_ps_hi);
+    hipLaunchKernelGGL(k_ps_sort, dim3((unsigned)ni), dim3(256), 0, ctx->stream, N, ps, d_cnt, ds->d_ps_lo, ds->d_ps_hi);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(NHP_EHIP, "fill failed");   // (`off` and the scratch go out of scope)
+    (void)hipFree(d_cnt); (void)hipFree(d_rows); (void)hipFree(d_rankof);
+    return NHP_OK;
+}
+
+// grad != nullptr: log-likelihood AND gradient (k_windowed_slices<.., GRAD>); the gradient must have been initialised by
+// k_grad_init unless `direct`
+static nhp_status launch_slices(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, int mask_integral, double *d_out,
+                                double *d_grad, bool direct, bool *launched)
 {
     *launched = false;
     if (!ds->d_sl_row || ds->n_items <= 0 || m->impulse_kind != NHP_IMPULSE_EXPONENTIAL) return NHP_OK;
     if (getenv("NHP_SLICES") && atoi(getenv("NHP_SLICES")) == 0) return NHP_OK;          // (A/B switch, read per call: the tests flip it)
-    const size_t lds = 320 + 16 * ((size_t)ds->N + 1) + 512;
+    const size_t lds = 320 + 16 * ((size_t)ds->N + 1) + 512 + (d_grad ? 8 * ((size_t)ds->max_item + 1) : 0);
     if (lds > 160 * 1024) return NHP_OK;
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)ds->n_items));
     nhp_cont_args a = nhp_make_args(ds, m);
     NHP_TRY(ensure_slices(ctx, ds, a));
     const nhp_slices sl = slices_view(ds);
+    nhp_pslices ps{};
+    if (d_grad) {
+        NHP_TRY(ensure_parent_slices(ctx, ds, a));
+        ps = pslices_view(ds);
+        ps.grad = d_grad;
+        ps.direct = direct ? 1 : 0;
+    }
     // waves per workgroup from the slices an item has (one item per node at N >= 1024: ~15 slices; short items at small N);
     // rows per request from the windows' length.  NHP_SLICES_CFG = "BLOCK,C" overrides (tools/dbg/slicesweep.sh)
     const int per_item = (ds->max_item + 63) / 64;
@@ -341,17 +665,18 @@ nhp_status nhp_launch_windowed_slices(nhp_ctx *ctx, const nhp_cont_dataset *ds, 
     dim3 grid((unsigned)ds->n_items);
     bool ok = false;
     const bool flat = m->baseline_kind == NHP_BASELINE_HOMOGENEOUS;
-#define NHP_SLAUNCH(b, cc, f)                                                                                         \
+#define NHP_SLAUNCH(b, cc, f, g)                                                                                      \
     do {                                                                                                              \
         if (lds > 64 * 1024)                                                                                          \
-            (void)hipFuncSetAttribute((const void *)k_windowed_slices<b, cc, f>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_windowed_slices<b, cc, f>), grid, dim3(b), lds, ctx->stream, a, sl, mask_integral, ctx->d_partials, \
+            (void)hipFuncSetAttribute((const void *)k_windowed_slices<b, cc, f, g>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_windowed_slices<b, cc, f, g>), grid, dim3(b), lds, ctx->stream, a, sl, ps, mask_integral, ctx->d_partials, \
                            ctx->d_counter, d_out);                                                                    \
     } while (0)
 #define NHP_SCASE(b, cc)                                                                                              \
     if (!ok && B == b && C == cc) {                                                                                   \
         ok = true;                                                                                                    \
-        if (flat) NHP_SLAUNCH(b, cc, true); else NHP_SLAUNCH(b, cc, false);                                           \
+        if (d_grad) { if (flat) NHP_SLAUNCH(b, cc, true, true); else NHP_SLAUNCH(b, cc, false, true); }               \
+        else { if (flat) NHP_SLAUNCH(b, cc, true, false); else NHP_SLAUNCH(b, cc, false, false); }                    \
     }
 #define NHP_SROW(b) NHP_SCASE(b, 2) NHP_SCASE(b, 4) NHP_SCASE(b, 8)
     NHP_SROW(64) NHP_SROW(128) NHP_SROW(256) NHP_SROW(512) NHP_SROW(1024)
@@ -362,4 +687,39 @@ nhp_status nhp_launch_windowed_slices(nhp_ctx *ctx, const nhp_cont_dataset *ds, 
     NHP_HIP(ctx, hipGetLastError());
     *launched = true;
     return NHP_OK;
+}
+
+nhp_status nhp_launch_windowed_slices(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, int mask_integral,
+                                      double *d_out, bool *launched)
+{
+    return launch_slices(ctx, ds, m, mask_integral, d_out, nullptr, false, launched);
+}
+
+// Log-likelihood -> *d_out and gradient -> d_grad [P] of the dataset's own windows (mask_integral = 1: the windowed route's
+// masked integral).  When every item is its node's only one, the dataset is whole and the baseline flat, the kernel stores
+// every entry of the gradient itself; otherwise k_grad_init (cont_grad.hip) must have run on d_grad (*needs_init).
+nhp_status nhp_launch_grad_slices(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_out, double *d_grad,
+                                  bool *launched)
+{
+    *launched = false;
+    if (getenv("NHP_GRAD_SLICES") && atoi(getenv("NHP_GRAD_SLICES")) == 0) return NHP_OK;   // (A/B switch: the two-pass route of cont_grad.hip)
+    const bool direct = ds->all_sole && !nhp_is_column_shard(ds) && m->baseline_kind == NHP_BASELINE_HOMOGENEOUS;
+    return launch_slices(ctx, ds, m, 1, d_out, d_grad, direct, launched);
+}
+
+bool nhp_grad_slices_direct(const nhp_cont_dataset *ds, const nhp_cont_model *m)
+{
+    return ds->all_sole && !nhp_is_column_shard(ds) && m->baseline_kind == NHP_BASELINE_HOMOGENEOUS;
+}
+
+// diagnostics (tools/dbg): the parent-slice planes as they sit on the device; returns the number of records (rows * 64), or -1
+extern "C" int64_t nhp_debug_parent_slices(const nhp_cont_dataset *ds, uint32_t *lo, uint16_t *hi, int64_t cap)
+{
+    if (!ds || !ds->d_ps_lo) return -1;
+    const int64_t n = ds->ps_rows * 64;
+    if (lo && hi && cap >= n) {
+        if (hipMemcpy(lo, ds->d_ps_lo, 4 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+        if (hipMemcpy(hi, ds->d_ps_hi, 2 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    }
+    return n;
 }

@@ -1211,7 +1211,7 @@ extern "C" nhp_status nhp_disc_mle_run(nhp_ctx *ctx, const nhp_disc_dataset *ds,
     if ((size_t)P != q.nbase + q.NN * q.B) { nhp_set_error(ctx, "Parameter vector length does not match model parameter length."); return NHP_ESHAPE; }
     // scratch: E | base | the evaluation's buffers (nhp_disc_stage_bump's layout without its host-side copies)
     NHP_TRY(nhp_ctx_reserve_scratch(ctx, 8 * (q.K * q.N + q.N + q.extra())));
-    auto eval = [&](const double *d_x, double *d_g) -> nhp_status {
+    auto eval = [&](const double *d_x, double *d_g, bool /*commit*/) -> nhp_status {
         hipStream_t st = ctx->stream;
         double *E = (double *)ctx->d_scratch, *base = E + q.K * q.N, *xs = base + q.N, *dgrad = nullptr;
         hipLaunchKernelGGL(k_disc_bump_from_x, dim3((unsigned)((q.NN + 255) / 256)), dim3(256), 0, st, (int)q.N, (int)q.B, dt, d_x, E, base);

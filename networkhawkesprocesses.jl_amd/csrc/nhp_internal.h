@@ -54,7 +54,7 @@ struct nhp_item {
     int32_t node;      // child node c (0-based)
     int32_t kbeg;      // first child slot in bucket order
     int32_t kend;      // one past the last
-    int32_t first;     // 1 if this is the first item of its node (owns the column's integral term)
+    int32_t first;     // bit 0: the first item of its node (owns the column's integral term); bit 1: its only item
 };
 
 // A child event in node-bucketed order: everything a wave needs to walk its window.
@@ -115,6 +115,19 @@ struct nhp_cont_dataset {
     int64_t sl_rows = 0;
     int32_t n_slices = 0, sl_nb = 0;    // node bits
     int32_t sl_max_rows = 0;            // most rows of one slice
+    // Parent slices (cont_slices.hip, the gradient's second phase): the same pairs of every item grouped by PARENT node --
+    // lane = parent node (the item's parent nodes sorted by their number of pairs, 64 to a slice, every node present),
+    // row r = the node's r-th pair as {child slot inside the item, delay}; a record is again 6 bytes: lo = low 32 bits of
+    // the delay, hi = slot << (16 - sb) | high bits, sb = bit length of max_item; padding records point at slot max_item
+    // (whose 1/λ is 0).  Built on the device at the first gradient that uses them; every lane's records are sorted by
+    // (slot, delay), so the list -- and with it the order of every gradient sum -- is the same for every build.
+    uint32_t *d_ps_row = nullptr;       // [n_items * ps_spi + 1] first row of each parent slice
+    uint16_t *d_ps_perm = nullptr;      // [n_items * ps_spi * 64] parent node of each lane (0xFFFF: none)
+    uint32_t *d_ps_lo = nullptr;        // [(ps_rows + 16) * 64]
+    uint16_t *d_ps_hi = nullptr;
+    int64_t ps_rows = 0;
+    int32_t ps_spi = 0, ps_sb = 0;      // parent slices per item = ceil(N / 64); slot bits
+    bool all_sole = false;              // every item is the only item of its node (the gradient then stores, never adds)
     // device arrays
     double *d_times = nullptr;          // [M] time order
     int32_t *d_nodes = nullptr;         // [M] 0-based
@@ -299,6 +312,12 @@ nhp_status nhp_ensure_pair_cache(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_c
 // slices.  *launched = false (and NHP_OK) when the dataset has no slices or the model is not covered.
 nhp_status nhp_launch_windowed_slices(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, int mask_integral,
                                       double *d_out, bool *launched);
+// the same with the analytic gradient (params! order, P doubles at d_grad) from one fused launch over the child and the
+// parent slices; *launched = false when the pair is not covered
+nhp_status nhp_launch_grad_slices(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_out, double *d_grad,
+                                  bool *launched);
+// true: that launch stores every entry of the gradient itself; false: it adds to what k_grad_init left
+bool nhp_grad_slices_direct(const nhp_cont_dataset *ds, const nhp_cont_model *m);
 nhp_cont_args nhp_make_args(const nhp_cont_dataset *ds, const nhp_cont_model *m);
 nhp_status nhp_check_pair(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m);
 // Device -> caller memory through the context's pinned staging buffer: DMA at link speed into pinned memory, then one

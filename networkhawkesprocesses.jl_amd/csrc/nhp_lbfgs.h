@@ -5,12 +5,15 @@
 // back onto the box and accepted by the Armijo rule along the projected path (backtracking by halves; the first trial is the
 // unit step).  The two-loop recursion runs in COEFFICIENT space ("vector-free" L-BFGS): the direction is a combination of the
 // 2·HIST + 1 vectors {s_i, y_i, q}, whose coefficients follow from their dot products alone -- the products among stored pairs
-// are kept on the host and only the 2·HIST + 1 products of the new q (one fused pass) and, after a step, of the new pair (one
-// more) are computed; the direction is then assembled in a single pass.  Stopping rule: the reference's mle! callback,
+// are kept on the host; after an accepted step ONE pass over the stored vectors takes the products of the new pair AND of the
+// next masked gradient with them (k_mle_multidot3; slots never written since the last reset are not read), and the direction
+// is then assembled in a single pass.  A line-search trial reads back one scalar pair: the objective and g·(x_new - x).
+// Per step: two passes over the history, one evaluation, two synchronisations.  Stopping rule: the reference's mle! callback,
 // |f_k - f_{k-1}| < f_abstol (src/continuous.jl:168-181, src/discrete.jl:247-258), or a zero projected gradient.
 //
-// The objective is given as `eval(d_x, d_g)`: enqueue on ctx->stream the evaluation at the DEVICE vector d_x, leaving the
-// log-likelihood in ctx->d_results[0] and g = -∇ll in d_g (f = -ll is minimised); asynchronous.
+// The objective is given as `eval(d_x, d_g, commit)`: enqueue on ctx->stream the evaluation at the DEVICE vector d_x, leaving
+// the log-likelihood in ctx->d_results[0] and g = -∇ll in d_g (f = -ll is minimised); asynchronous.  `commit` marks the
+// run's last call -- the iterate the caller's model has to hold afterwards (a trial may be evaluated straight from d_x).
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -21,7 +24,7 @@ namespace {
 
 constexpr int HIST = 8;               // limited-memory pairs
 constexpr int NB = 2 * HIST;          // stored vectors: s_0..s_{HIST-1}, y_0..y_{HIST-1} (contiguous)
-constexpr int NACC = 2 * NB + 3;      // u·b_j (NB), u·u, v·b_j (NB), v·v, u·v
+constexpr int NACC = 3 * NB + 6;      // u·b_j, v·b_j, w·b_j (NB each), then u·u, v·v, w·w, u·v, u·w, v·w
 constexpr int RBLK = 512;             // workgroups of a reduction
 
 __device__ __forceinline__ bool held_at(double xi, double gi, double lo, double hi)
@@ -29,51 +32,66 @@ __device__ __forceinline__ bool held_at(double xi, double gi, double lo, double 
     return (xi <= lo && gi > 0.0) || (xi >= hi && gi < 0.0);       // g = ∇f, f minimised
 }
 
-// part[blk][k]: this block's share of u·b_j (k = j), u·u (NB), and -- with v -- v·b_j (NB + 1 + j), v·v, u·v; b_j = base + j·n
-__global__ __launch_bounds__(256) void k_mle_multidot(const double *__restrict__ u, const double *__restrict__ v,
-                                                      const double *__restrict__ base, int64_t n, double *__restrict__ part)
+// part[blk][k]: this block's share of the products of u, v, w (null = a zero vector) with the stored vectors b_j = base + j·n
+// of the slots j < na (both halves: s_j and y_j; the other slots hold zeros and are not read) and with each other
+__global__ __launch_bounds__(256) void k_mle_multidot3(const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ w,
+                                                       const double *__restrict__ base, int na, int64_t n, double *__restrict__ part)
 {
     __shared__ double red[NHP_WAVES][NACC];
     double acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const double ui = u[i], vi = v ? v[i] : 0.0;
+        const double ui = u ? u[i] : 0.0, vi = v ? v[i] : 0.0, wi = w[i];
         double b[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) b[j] = base[(size_t)j * n + i];
+        for (int j = 0; j < HIST; ++j) {
+            b[j] = j < na ? base[(size_t)j * n + i] : 0.0;
+            b[HIST + j] = j < na ? base[(size_t)(HIST + j) * n + i] : 0.0;
+        }
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { acc[j] += ui * b[j]; acc[NB + 1 + j] += vi * b[j]; }
-        acc[NB] += ui * ui; acc[2 * NB + 1] += vi * vi; acc[2 * NB + 2] += ui * vi;
+        for (int j = 0; j < NB; ++j) { acc[j] += ui * b[j]; acc[NB + j] += vi * b[j]; acc[2 * NB + j] += wi * b[j]; }
+        acc[3 * NB] += ui * ui; acc[3 * NB + 1] += vi * vi; acc[3 * NB + 2] += wi * wi;
+        acc[3 * NB + 3] += ui * vi; acc[3 * NB + 4] += ui * wi; acc[3 * NB + 5] += vi * wi;
     }
 #pragma unroll
     for (int k = 0; k < NACC; ++k) {
-        const double w = nhp_wave_sum(acc[k]);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = w;
+        const double ws = nhp_wave_sum(acc[k]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = ws;
     }
     __syncthreads();
     if (threadIdx.x < NACC) {
         double t = 0.0;
-        for (int w = 0; w < NHP_WAVES; ++w) t += red[w][threadIdx.x];
+        for (int q = 0; q < NHP_WAVES; ++q) t += red[q][threadIdx.x];
         part[(size_t)blockIdx.x * NACC + threadIdx.x] = t;
     }
 }
 
-// out[k] = Σ_blk part[blk][k] (k = blockIdx.x < NACC), the RBLK partials of one product summed by one workgroup in a fixed
-// order; out[NACC] = the evaluation's log-likelihood (riding along: one download).  (One 64-thread workgroup walking all
-// RBLK x NACC partials took 117 us a call -- a third of an optimizer step.)
-__global__ __launch_bounds__(256) void k_mle_multidot_final(const double *__restrict__ part, int nblk, const double *__restrict__ ll,
+// out[k] = Σ_blk part[blk][k] (k = blockIdx.x < nacc), the partials of one product summed by one workgroup in a fixed order;
+// out[nacc] = the evaluation's log-likelihood (riding along: one download).  (One 64-thread workgroup walking all RBLK x NACC
+// partials took 117 us a call -- a third of an optimizer step.)
+__global__ __launch_bounds__(256) void k_mle_multidot_final(const double *__restrict__ part, int nblk, int nacc, const double *__restrict__ ll,
                                                            double *__restrict__ out)
 {
     __shared__ double red[NHP_WAVES];
     const int k = blockIdx.x;
     double t = 0.0;
-    for (int b = threadIdx.x; b < nblk; b += 256) t += part[(size_t)b * NACC + k];
+    for (int b = threadIdx.x; b < nblk; b += 256) t += part[(size_t)b * nacc + k];
     t = nhp_block_sum_n<NHP_WAVES>(t, red);
     if (threadIdx.x == 0) {
         out[k] = t;
-        if (k == 0) out[NACC] = ll ? *ll : 0.0;
+        if (k == 0) out[nacc] = ll ? *ll : 0.0;
     }
+}
+
+// part[blk] = this block's share of u·v (the Armijo slope term of a trial: two vectors, not the whole history)
+__global__ __launch_bounds__(256) void k_mle_dot(const double *__restrict__ u, const double *__restrict__ v, int64_t n, double *__restrict__ part)
+{
+    __shared__ double red[NHP_WAVES];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += u[i] * v[i];
+    acc = nhp_block_sum_n<NHP_WAVES>(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 
 // q = g on the free variables, 0 on those held at a bound
@@ -86,15 +104,16 @@ __global__ __launch_bounds__(256) void k_mle_masked(double *__restrict__ q, cons
 
 struct mle_coef { double q, b[NB]; };
 
-// d = (coef.q·q + Σ_j coef.b[j]·b_j) on the free variables, 0 on the held ones
+// d = (coef.q·q + Σ_j coef.b[j]·b_j) on the free variables, 0 on the held ones; only the first `na` slots are read
 __global__ __launch_bounds__(256) void k_mle_combine(double *__restrict__ d, const double *__restrict__ q, const double *__restrict__ base,
-                                                     mle_coef c, const double *__restrict__ g, const double *__restrict__ x,
+                                                     mle_coef c, int na, const double *__restrict__ g, const double *__restrict__ x,
                                                      double lo, double hi, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         double v = c.q * q[i];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) v += c.b[j] * base[(size_t)j * n + i];
+        for (int j = 0; j < HIST; ++j)
+            if (j < na) v += c.b[j] * base[(size_t)j * n + i] + c.b[HIST + j] * base[(size_t)(HIST + j) * n + i];   // (the other slots hold zeros)
         d[i] = held_at(x[i], g[i], lo, hi) ? 0.0 : v;
     }
 }
@@ -117,12 +136,17 @@ __global__ __launch_bounds__(256) void k_mle_neg(double *__restrict__ out, const
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = -in[i];
 }
 
-// y = g_new - g on the variables that were free at (x, g), 0 on the held ones
-__global__ __launch_bounds__(256) void k_mle_ydiff(double *__restrict__ y, const double *__restrict__ gn, const double *__restrict__ g,
-                                                   const double *__restrict__ x, double lo, double hi, int64_t n)
+// after an accepted step: y = g_new - g on the variables that were free at (x, g), 0 on the held ones, and the NEXT masked
+// gradient q = g_new on the variables free at (x_new, g_new) -- one pass over the five vectors
+__global__ __launch_bounds__(256) void k_mle_ydiff_masked(double *__restrict__ y, double *__restrict__ qn, const double *__restrict__ gn,
+                                                          const double *__restrict__ g, const double *__restrict__ x,
+                                                          const double *__restrict__ xn, double lo, double hi, int64_t n)
 {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        y[i] = held_at(x[i], g[i], lo, hi) ? 0.0 : gn[i] - g[i];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double gni = gn[i], gi = g[i];
+        y[i] = held_at(x[i], gi, lo, hi) ? 0.0 : gni - gi;
+        qn[i] = held_at(xn[i], gni, lo, hi) ? 0.0 : gni;
+    }
 }
 
 struct mle_state {
@@ -134,18 +158,30 @@ struct mle_state {
     dim3 grid;
 };
 
-// the products of u (and v) with the stored vectors -> host, together with the log-likelihood of the evaluation enqueued
-// before (with_ll): ONE synchronisation
-nhp_status multidot(mle_state &s, const double *u, const double *v, bool with_ll, double *out /* [NACC + 1] */)
+// the products of u, v (nullable) and w with the stored vectors of the first `na` slots and with each other -> host: ONE
+// synchronisation
+nhp_status multidot3(mle_state &s, const double *u, const double *v, const double *w, int na, double *out /* [NACC + 1] */)
 {
     hipStream_t st = s.ctx->stream;
-    hipLaunchKernelGGL(k_mle_multidot, dim3(RBLK), dim3(256), 0, st, u, v, (const double *)s.d_base, s.P, s.d_part);
-    hipLaunchKernelGGL(k_mle_multidot_final, dim3(NACC), dim3(256), 0, st, (const double *)s.d_part, RBLK,
-                       with_ll ? (const double *)s.ctx->d_results : (const double *)nullptr, s.d_scal);
+    hipLaunchKernelGGL(k_mle_multidot3, dim3(RBLK), dim3(256), 0, st, u, v, w, (const double *)s.d_base, na, s.P, s.d_part);
+    hipLaunchKernelGGL(k_mle_multidot_final, dim3(NACC), dim3(256), 0, st, (const double *)s.d_part, RBLK, NACC, (const double *)nullptr, s.d_scal);
     NHP_HIP(s.ctx, hipGetLastError());
     NHP_HIP(s.ctx, hipMemcpyAsync(s.h_scal, s.d_scal, 8 * (NACC + 1), hipMemcpyDeviceToHost, st));
     NHP_HIP(s.ctx, hipStreamSynchronize(st));
     for (int k = 0; k <= NACC; ++k) out[k] = s.h_scal[k];
+    return NHP_OK;
+}
+
+// u·v and the log-likelihood of the evaluation enqueued before -> host: the one readback of a line-search trial
+nhp_status dot_with_ll(mle_state &s, const double *u, const double *v, double *uv, double *ll)
+{
+    hipStream_t st = s.ctx->stream;
+    hipLaunchKernelGGL(k_mle_dot, dim3(RBLK), dim3(256), 0, st, u, v, s.P, s.d_part);
+    hipLaunchKernelGGL(k_mle_multidot_final, dim3(1), dim3(256), 0, st, (const double *)s.d_part, RBLK, 1, (const double *)s.ctx->d_results, s.d_scal);
+    NHP_HIP(s.ctx, hipGetLastError());
+    NHP_HIP(s.ctx, hipMemcpyAsync(s.h_scal, s.d_scal, 8 * 2, hipMemcpyDeviceToHost, st));
+    NHP_HIP(s.ctx, hipStreamSynchronize(st));
+    *uv = s.h_scal[0]; *ll = s.h_scal[1];
     return NHP_OK;
 }
 
@@ -186,7 +222,7 @@ nhp_status nhp_lbfgs_box(nhp_ctx *ctx, int64_t P, double lower, double upper, do
     int evals = 0, steps = 0, nhist = 0, head = 0;        // active slots [head - nhist, head) modulo HIST, newest last
     bool converged = false;
 
-    NHP_TRY(eval(d_x, d_g)); ++evals;
+    NHP_TRY(eval(d_x, d_g, false)); ++evals;
     {
         double ll = 0.0;
         NHP_TRY(nhp_ctx_fetch(ctx, 0, 1, &ll));
@@ -194,14 +230,23 @@ nhp_status nhp_lbfgs_box(nhp_ctx *ctx, int64_t P, double lower, double upper, do
     }
     if (!std::isfinite(f)) { nhp_set_error(ctx, "mle!: the objective is not finite at the starting point"); return NHP_EDOMAIN; }
 
+    // the masked gradient at the start and its products (no pair stored yet: nothing but q·q is read)
+    int filled = 0;                                            // slots written since the last reset (the others hold zeros)
+    double qq = 0.0, qs[HIST] = {}, qy[HIST] = {};             // q·q, q·s_j, q·y_j by slot
+    hipLaunchKernelGGL(k_mle_masked, s.grid, dim3(256), 0, st, d_q, (const double *)d_g, (const double *)d_x, lower, upper, P);
+    NHP_TRY(multidot3(s, nullptr, nullptr, d_q, 0, sc));
+    qq = sc[3 * NB + 2];
+    auto drop_history = [&]() -> nhp_status {
+        NHP_HIP(ctx, hipMemsetAsync(d_S, 0, 8 * (size_t)NB * P, st));
+        for (int i = 0; i < HIST; ++i) {
+            qs[i] = qy[i] = 0.0;
+            for (int j = 0; j < HIST; ++j) ss[i][j] = sy[i][j] = yy[i][j] = 0.0;
+        }
+        nhist = 0; head = 0; filled = 0;
+        return NHP_OK;
+    };
     for (int it = 0; it < max_steps; ++it) {
-        // ---- the masked gradient and its products with the stored vectors (one pass, one synchronisation)
-        hipLaunchKernelGGL(k_mle_masked, s.grid, dim3(256), 0, st, d_q, (const double *)d_g, (const double *)d_x, lower, upper, P);
-        NHP_TRY(multidot(s, d_q, nullptr, false, sc));
-        const double qq = sc[NB];
         if (!(qq > 0.0)) { converged = true; break; }          // projected gradient is zero: a stationary point of the box problem
-        double qs[HIST], qy[HIST];                             // q·s_j, q·y_j by slot
-        for (int j = 0; j < HIST; ++j) { qs[j] = sc[j]; qy[j] = sc[HIST + j]; }
         // ---- two-loop recursion on coefficients: p = cq·q + Σ cs[j]·s_j + Σ cy[j]·y_j, starting from p = -q
         mle_coef c{};
         double *cs = c.b, *cy = c.b + HIST;
@@ -240,44 +285,53 @@ nhp_status nhp_lbfgs_box(nhp_ctx *ctx, int64_t P, double lower, double upper, do
         double t = 1.0;
         if (!(gd < 0.0) || !std::isfinite(gd)) {               // not a descent direction: steepest descent, history dropped
             c = mle_coef{}; c.q = -1.0;
-            nhist = 0; gd = -qq;
-            NHP_HIP(ctx, hipMemsetAsync(d_S, 0, 8 * (size_t)NB * P, st));
-            for (int i = 0; i < HIST; ++i) for (int j = 0; j < HIST; ++j) ss[i][j] = sy[i][j] = yy[i][j] = 0.0;
+            gd = -qq;
+            NHP_TRY(drop_history());
         }
         if (nhist == 0) t = std::min(1.0, 1.0 / std::sqrt(qq));
-        hipLaunchKernelGGL(k_mle_combine, s.grid, dim3(256), 0, st, d_d, (const double *)d_q, (const double *)s.d_base, c,
+        hipLaunchKernelGGL(k_mle_combine, s.grid, dim3(256), 0, st, d_d, (const double *)d_q, (const double *)s.d_base, c, filled,
                            (const double *)d_g, (const double *)d_x, lower, upper, P);
-        // ---- backtracking along the projected path; a trial = one fused (log-likelihood, gradient) evaluation, after which
-        //      the candidate step's products ride down with the objective value
+        // ---- backtracking along the projected path; a trial = one fused (log-likelihood, gradient) evaluation and one readback
+        //      of two scalars: the objective and the Armijo slope term g·(x_new - x) = q·s_new (s is zero on the held variables).
+        //      A trial is accepted only on a path that descends to first order (dec < 0: once the projection has clipped the
+        //      descent components of a quasi-Newton step, what is left may point uphill) -- never with f_new > f.
         double *s_new = d_S + (size_t)head * P, *y_new = d_Y + (size_t)head * P;
         bool accepted = false;
         double fn = 0.0;
         for (int ls = 0; ls < 60; ++ls) {
             hipLaunchKernelGGL(k_mle_step, s.grid, dim3(256), 0, st, d_xn, s_new, (const double *)d_x, (const double *)d_d, t, lower, upper, P);
             NHP_HIP(ctx, hipGetLastError());
-            NHP_TRY(eval(d_xn, d_gn)); ++evals;
-            // u = s_new, v = q: u·v = g·(x_new - x) (s is zero on the held variables) = the Armijo slope term
-            NHP_TRY(multidot(s, s_new, d_q, true, sc));
-            fn = -sc[NACC];
-            const double dec = sc[2 * NB + 2];
-            if (std::isfinite(fn) && fn <= f + 1e-4 * dec) { accepted = true; break; }
+            NHP_TRY(eval(d_xn, d_gn, false)); ++evals;
+            double dec = 0.0, ll = 0.0;
+            NHP_TRY(dot_with_ll(s, s_new, d_q, &dec, &ll));
+            fn = -ll;
+            if (std::isfinite(fn) && dec < 0.0 && fn <= f + 1e-4 * dec) { accepted = true; break; }
+            if (std::isfinite(fn) && !(dec < 0.0) && nhist > 0) break;     // clipped into an ascent path: not this direction
             t *= std::isfinite(fn) ? 0.5 : 0.1;
         }
-        if (!accepted) {                                       // no decrease along the path: where we are is the answer
-            NHP_HIP(ctx, hipMemsetAsync(s_new, 0, 8 * (size_t)P, st));
-            break;
+        if (!accepted) {
+            NHP_HIP(ctx, hipMemsetAsync(s_new, 0, 8 * (size_t)P, st));     // the slot multiplies as zeros again
+            if (nhist > 0) {                                   // a quasi-Newton direction failed: the projected gradient's own path next
+                NHP_TRY(drop_history());
+                continue;
+            }
+            break;                                             // no decrease along the projected gradient: where we are is the answer
         }
-        // ---- the new pair's products with everything stored (slot `head` holds it already: its own entries come out right
-        //      once y is there too, so the s-row is taken again together with the y-row)
-        hipLaunchKernelGGL(k_mle_ydiff, s.grid, dim3(256), 0, st, y_new, (const double *)d_gn, (const double *)d_g, (const double *)d_x, lower, upper, P);
-        NHP_TRY(multidot(s, s_new, y_new, false, sc));
-        const double s_y = sc[2 * NB + 2], y_y = sc[2 * NB + 1], s_s = sc[NB];
+        // ---- the new pair and the next masked gradient, then ONE pass over the stored vectors for the products of all three
+        //      (slot `head` holds the pair already, so its own entries come out with the rest)
+        hipLaunchKernelGGL(k_mle_ydiff_masked, s.grid, dim3(256), 0, st, y_new, d_q, (const double *)d_gn, (const double *)d_g, (const double *)d_x,
+                           (const double *)d_xn, lower, upper, P);
+        filled = std::max(filled, head + 1);
+        NHP_TRY(multidot3(s, s_new, y_new, d_q, filled, sc));
+        const double s_s = sc[3 * NB], y_y = sc[3 * NB + 1], s_y = sc[3 * NB + 3];
+        qq = sc[3 * NB + 2];
+        for (int j = 0; j < HIST; ++j) { qs[j] = sc[2 * NB + j]; qy[j] = sc[2 * NB + HIST + j]; }
         if (s_y > 1e-300 && y_y > 0.0 && std::isfinite(s_y) && std::isfinite(y_y) && s_y > 1e-12 * y_y) {
             for (int j = 0; j < HIST; ++j) {
                 ss[head][j] = ss[j][head] = sc[j];                     // s_new·s_j
                 sy[head][j] = sc[HIST + j];                            // s_new·y_j
-                sy[j][head] = sc[NB + 1 + j];                          // y_new·s_j
-                yy[head][j] = yy[j][head] = sc[NB + 1 + HIST + j];     // y_new·y_j
+                sy[j][head] = sc[NB + j];                              // y_new·s_j
+                yy[head][j] = yy[j][head] = sc[NB + HIST + j];         // y_new·y_j
             }
             ss[head][head] = s_s; sy[head][head] = s_y; yy[head][head] = y_y;
             head = (head + 1) % HIST; nhist = std::min(nhist + 1, HIST);
@@ -286,6 +340,7 @@ nhp_status nhp_lbfgs_box(nhp_ctx *ctx, int64_t P, double lower, double upper, do
             NHP_HIP(ctx, hipMemsetAsync(s_new, 0, 8 * (size_t)P, st));
             NHP_HIP(ctx, hipMemsetAsync(y_new, 0, 8 * (size_t)P, st));
             for (int j = 0; j < HIST; ++j) ss[head][j] = ss[j][head] = sy[head][j] = sy[j][head] = yy[head][j] = yy[j][head] = 0.0;
+            qs[head] = qy[head] = 0.0;
             if (nhist == HIST) nhist = HIST - 1;
         }
         std::swap(d_x, d_xn); std::swap(d_g, d_gn);
@@ -294,7 +349,7 @@ nhp_status nhp_lbfgs_box(nhp_ctx *ctx, int64_t P, double lower, double upper, do
         minloss = f;
     }
     // the model holds the last TRIAL; make it the iterate
-    NHP_TRY(eval(d_x, d_gn));
+    NHP_TRY(eval(d_x, d_gn, true));
     {
         double ll = 0.0;
         NHP_TRY(nhp_ctx_fetch(ctx, 0, 1, &ll));

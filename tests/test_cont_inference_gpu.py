@@ -40,6 +40,81 @@ def test_gradient_matches_oracle(nhp, orc, kind, recursive, network):
     assert np.max(np.abs(g - wg) / np.maximum(1.0, np.abs(wg))) < 1e-9
 
 
+@pytest.mark.parametrize("network,lgcp", [(False, False), (True, False), (False, True)])
+def test_gradient_over_the_slices_equals_the_two_pass_route(nhp, orc, network, lgcp, monkeypatch):
+    """Exponential impulses on the dataset's own windows: log-likelihood and gradient come from ONE launch over the child
+    slices (λ_k, 1/λ_k in LDS) and the parent slices (lane = parent node: no atomics) -- cont_slices.hip.  Against the oracle
+    and against the two-pass route (NHP_GRAD_SLICES=0), with columns cut into several items (the kernel adds to k_grad_init's
+    terms), ties and a burst in the data, and every (workgroup, rows per request) shape."""
+    c = random_case(7, 5000, 300.0, "exponential", 1.0, network=network, lgcp=lgcp, seed=23, nhp=nhp, orc=orc)
+    t = c["times"].copy()
+    t[700:730:2] = t[701:731:2]
+    t[2000:2090] = np.sort(np.random.default_rng(5).uniform(t[2000], t[2000] + 0.6, 90))
+    t = np.sort(t)
+    data = (t, c["nodes"], c["T"])
+    wll, wg = orc.loglik_grad(c["om"], t, c["nodes"], c["T"], recursive=False)
+
+    def run():
+        nhp.invalidate_device_datasets()
+        if network:
+            return _grad_network(nhp, dict(c, data=data), False)
+        return nhp.loglikelihood_gradient(c["proc"], data, recursive=False)
+
+    got = {}
+    for name, env in (("slices", {}), ("two-pass", {"NHP_GRAD_SLICES": "0"})):
+        for k in ("NHP_GRAD_SLICES", "NHP_SLICES_CFG"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ll, g = run()
+        assert rel(ll, wll) < 1e-11, name
+        assert np.max(np.abs(g - wg) / np.maximum(1.0, np.abs(wg))) < 1e-9, name
+        got[name] = g
+    assert np.max(np.abs(got["slices"] - got["two-pass"]) / np.maximum(1.0, np.abs(wg))) < 1e-10
+    monkeypatch.delenv("NHP_GRAD_SLICES", raising=False)
+    for cfg in ("64,2", "128,4", "256,8", "512,2", "1024,4"):
+        monkeypatch.setenv("NHP_SLICES_CFG", cfg)
+        ll, g = run()
+        assert rel(ll, wll) < 1e-11, cfg
+        assert np.max(np.abs(g - wg) / np.maximum(1.0, np.abs(wg))) < 1e-9, cfg
+    monkeypatch.delenv("NHP_SLICES_CFG", raising=False)
+
+
+def test_gradient_over_the_slices_one_item_per_node(nhp, orc, monkeypatch):
+    """At N >= 1024 every node is one item: the slice kernel then STORES every entry of the gradient (the parameter-
+    independent terms -T, -cnt[p] included) and k_grad_init does not run.  A node without events and one with a single
+    event are in the data."""
+    N, M = 1040, 60000
+    monkeypatch.setenv("NHP_CHUNK", "4096")                         # (58 events a node: the 1.3 x mean item bound would cut some nodes in two)
+    c = random_case(N, M, 4000.0, "exponential", 1.0, seed=31, nhp=nhp, orc=orc)
+    n = c["nodes"].copy()
+    n[n == 7] = 8
+    n[n == 11] = 12
+    n[4321] = 11
+    data = (c["times"], n, c["T"])
+    wll, wg = orc.loglik_grad(c["om"], c["times"], n, c["T"], recursive=False)
+    for env in ({}, {"NHP_GRAD_SLICES": "0"}):
+        monkeypatch.delenv("NHP_GRAD_SLICES", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        nhp.invalidate_device_datasets()
+        g0 = np.full(len(wg), np.nan)                               # (the call fills every entry)
+        ll, g = nhp.loglikelihood_gradient(c["proc"], data, recursive=False)
+        assert rel(ll, wll) < 1e-11
+        assert np.all(np.isfinite(g)) and g.shape == g0.shape
+        assert np.max(np.abs(g - wg) / np.maximum(1.0, np.abs(wg))) < 1e-9
+    monkeypatch.delenv("NHP_GRAD_SLICES", raising=False)
+    # no atomics on this path and the parent slices are sorted lane by lane after the ticketed fill: two builds of the
+    # dataset give the same bits
+    nhp.invalidate_device_datasets()
+    ll1, g1 = nhp.loglikelihood_gradient(c["proc"], data, recursive=False)
+    nhp.invalidate_device_datasets()
+    ll2, g2 = nhp.loglikelihood_gradient(c["proc"], data, recursive=False)
+    assert ll1 == ll2 and np.array_equal(g1, g2)
+    monkeypatch.delenv("NHP_CHUNK", raising=False)
+    nhp.invalidate_device_datasets()
+
+
 def _grad_network(nhp, c, recursive):
     # the network process has no params!/mle! in the reference (src/continuous.jl:325-333), but the
     # kernels differentiate it all the same; P is the standard process's [λ0; θ|μ;τ; W]
