@@ -536,10 +536,12 @@ def chains_leg(nhp, ctx, rank, steps, sync):
     wall = time.perf_counter() - t0
     # the two parts that exchange are guarded separately (-1 = failed, reported as null): the chains' own rate above stands
     t_gather = -1.0
+    lib_world, lib_rank = 0, -1                     # what the LIBRARY's communicator says (0 / -1: none, the gloo rehearsal)
     try:
         comm = _lib.comm_for(ctx)                   # RCCL communicator of this rank ("nccl" groups); None in the gloo rehearsal
         t_gather = 0.0
         if comm is not None:
+            lib_world, lib_rank = int(lib.nhp_comm_world(comm.h)), int(lib.nhp_comm_rank(comm.h))
             L = inference.moments_length(proc)
             s, q = np.empty((comm.world, L)), np.empty((comm.world, L))
             counts, rho = np.empty(comm.world, dtype=np.int64), np.empty((comm.world, 3))
@@ -567,7 +569,31 @@ def chains_leg(nhp, ctx, rank, steps, sync):
         t_one = time.perf_counter() - t0
     except Exception as exc:
         print(f"[rank {rank}] one chain over all ranks failed: {exc!r}", file=sys.stderr, flush=True)
-    return wall, t_one, t_gather
+    return wall, t_one, t_gather, float(lib_world), float(lib_rank)
+
+
+def find_errors(obj, path=""):
+    """Paths of every "error" key inside the line: a leg that raised is recorded where it belongs AND named at the top."""
+    found = []
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            if k == "error":
+                found.append(path or "/")
+            else:
+                found += find_errors(v, f"{path}/{k}")
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            found += find_errors(v, f"{path}[{i}]")
+    return found
+
+
+def finish_line(out):
+    """`status`: "ok", or "partial" with the paths of the legs that failed (the headline itself is always measured)."""
+    bad = find_errors(out)
+    out["status"] = "partial" if bad else "ok"
+    if bad:
+        out["failed_legs"] = bad
+    return json.dumps(out)
 
 
 def headline(args, r, world, wall_s, lls):
@@ -587,8 +613,9 @@ def headline(args, r, world, wall_s, lls):
                    "pairs_per_eval": r["pairs"], "independent_streams": world,
                    "dataset_setup_ms_once": r["dataset_ms"], "first_evaluation_ms_incl_layout_build": r["first_ms"],
                    "data_layout": "per dataset, made once from the events (data only, no parameter in it): children bucketed by node, "
-                                  "parent-child pairs as a list of node | delay; every evaluation computes every pair term "
-                                  "from the parameters it is given (see parameters_changing_every_evaluation)"},
+                                  "parent-child pairs as child slices (64 children a wavefront, one lane per child, 6-byte records "
+                                  "node | delay, row r = every lane's r-th most recent parent); every evaluation computes every pair "
+                                  "term from the parameters it is given (see parameters_changing_every_evaluation)"},
         "roofline": {"bound": "hbm", "achieved": B / (ms_kernel * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": B / (ms_kernel * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": measured_traffic(args.workload)[0], "traffic_measured_at_commit": measured_traffic(args.workload)[1],
@@ -669,30 +696,39 @@ def main():
     # exception is recorded in the line, and a leg that does not return (a rank stuck in a collective) is cut short by a
     # watchdog thread that prints the line as it stands and ends the process (ctypes and torch collectives release the GIL).
     watchdog = None
-    state = {"printed": False}
+    state = {"printed": False, "partial": False}
     if world > 1:
         deadline = float(os.environ.get("NHP_BENCH_EXTRAS_DEADLINE_S", "300"))
 
         def give_up():
+            # the line as it stands, marked partial, then a NON-ZERO exit: a leg that hangs must not read as a clean run
             if rank == 0 and not state["printed"]:
                 out["multi_gpu_legs"] = {"error": f"not finished within {deadline:.0f} s: cut short, headline unaffected"}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+                print(finish_line(out), flush=True)
+            sys.stdout.flush()
+            os._exit(3)
         watchdog = threading.Timer(deadline + (0.0 if rank == 0 else 10.0), give_up)
         watchdog.daemon = True
         watchdog.start()
     def rest():
         chain_wall = None
         if world > 1 and args.chain_steps > 0:
-            tw = torch.zeros(4, dtype=torch.float64, device=tdev)
+            # per rank: [own chain wall, one chain over all ranks, gather, library communicator world, its rank, raised]
+            mine = torch.zeros(6, dtype=torch.float64, device=tdev)
             try:
-                tw[:3] = torch.tensor(list(chains_leg(nhp, ctx, rank, args.chain_steps, sync)), dtype=torch.float64, device=tdev)
+                mine[:5] = torch.tensor(list(chains_leg(nhp, ctx, rank, args.chain_steps, sync)), dtype=torch.float64, device=tdev)
             except Exception as exc:                # recorded below; the other ranks see the flag
-                tw[3] = 1.0
+                mine[5] = 1.0
                 print(f"[rank {rank}] config-5 leg failed: {exc!r}", file=sys.stderr, flush=True)
-            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-            if float(tw[3].item()) == 0.0:
-                chain_wall, one_chain_wall, gather_wall = float(tw[0].item()), float(tw[1].item()), float(tw[2].item())
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            per_rank = torch.stack(every).cpu()
+            if float(per_rank[:, 5].max().item()) == 0.0:
+                chain_wall, one_chain_wall, gather_wall = (float(per_rank[:, k].max().item()) for k in (0, 1, 2))
+                gather_wall = -1.0 if float(per_rank[:, 2].min().item()) < 0.0 else gather_wall
+                one_chain_wall = -1.0 if float(per_rank[:, 1].min().item()) < 0.0 else one_chain_wall
+                chain_ranks = [{"torch_rank": q, "library_comm_world": int(per_rank[q, 3].item()), "library_comm_rank": int(per_rank[q, 4].item()),
+                                "mcmc_steps_per_sec": args.chain_steps / float(per_rank[q, 0].item())} for q in range(world)]
             elif rank == 0:
                 out["config5_independent_chains"] = {"error": "a rank raised in the chains leg (stderr has the message)"}
         sharded = None
@@ -706,9 +742,17 @@ def main():
                 out["config5_independent_chains"] = {
                     "workload": "c3 model (N=1024, M=1e6, logit-normal network), one mcmc! chain per rank, device-side sweep",
                     "chains": world, "steps_per_chain": args.chain_steps,
+                    # what the library's OWN communicator saw on every rank (world 0 = no RCCL clique: the gloo rehearsal)
+                    "ranks": chain_ranks,
+                    "rccl_clique_of_the_library": all(q["library_comm_world"] == world for q in chain_ranks)
+                                                  and sorted(q["library_comm_rank"] for q in chain_ranks) == list(range(world)),
                     "mcmc_steps_per_sec": world * args.chain_steps / chain_wall, "ms_per_step": 1e3 * chain_wall / args.chain_steps,
                     "rccl_gather_of_the_chains_posterior_moments_ms": 1e3 * gather_wall if gather_wall >= 0.0 else None,
                     "one_chain_over_all_ranks_ms_per_step": 1e3 * one_chain_wall / args.chain_steps if one_chain_wall >= 0.0 else None}
+                if gather_wall < 0.0:
+                    out["config5_independent_chains"]["gather"] = {"error": "the gather of the chains' moments failed on a rank (stderr has the message)"}
+                if one_chain_wall < 0.0:
+                    out["config5_independent_chains"]["one_chain_over_all_ranks"] = {"error": "failed on a rank (stderr has the message)"}
             if sharded is not None:
                 out["one_evaluation_over_all_ranks"] = sharded
             if world == 1 and args.two_streams and not r["recursive"]:
@@ -759,13 +803,15 @@ def main():
                 out["other_workloads"] = others
             if world == 1 and args.configs:
                 out["configs"] = config_workloads(nhp, ctx, args.configs.split(","))
-            print(json.dumps(out), flush=True)
+            print(finish_line(out), flush=True)
             state["printed"] = True
+            state["partial"] = out["status"] != "ok"
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
 
-    # past the headline nothing may cost the line or the exit status: rank 0 prints what it has, every rank leaves with 0
+    # past the headline nothing may cost the LINE: rank 0 prints what it has, marked "status": "partial" with the failed legs
+    # named -- and then the process leaves NON-ZERO (3), so that a leg that raised or hung never reads as a clean run
     try:
         rest()
     except BaseException as exc:
@@ -774,11 +820,14 @@ def main():
         print(f"[rank {rank}] after the headline: {exc!r}", file=sys.stderr, flush=True)
         if rank == 0 and not state["printed"]:
             out["multi_gpu_legs"] = {"error": repr(exc)}
-            print(json.dumps(out), flush=True)
+            print(finish_line(out), flush=True)
         sys.stdout.flush()
-        os._exit(0)
+        os._exit(3)
     if watchdog is not None:
         watchdog.cancel()
+    if world > 1 and state.get("partial"):          # a leg recorded an error inside the (printed) line
+        sys.stdout.flush()
+        os._exit(3)
 
 
 if __name__ == "__main__":

@@ -266,7 +266,8 @@ nhp_status nhp_probe_gather(nhp_ctx *ctx, int32_t n_windows, int32_t recs, int64
 /* streaming-read calibration: `blocks` workgroups of `threads` (256 | 512) sweep contiguous shares of a `bytes`-byte buffer,
  * mode 0 = 16 bytes per lane, mode 1 = the child slices' two planes (4 + 2 bytes per lane) -- microseconds per launch
  * (launched back to back: below 256 MB the Infinity Cache serves it, as it does the repeated log-likelihood) */
-nhp_status nhp_probe_stream(nhp_ctx *ctx, int32_t mode, int64_t bytes, int32_t blocks, int32_t threads, double *us_per_launch);
+nhp_status nhp_probe_stream(nhp_ctx *ctx, int32_t mode, int64_t bytes, int32_t blocks, int32_t threads, double *us_per_launch,
+                            int64_t *bytes_read /* nullable: what a launch really reads (whole rows per wave) */);
 
 /* ---- discrete data: N x T counts  src/discrete.jl:18,80 -------------------------------- */
 nhp_status nhp_disc_dataset_create(nhp_ctx *ctx, const int64_t *data, int32_t n_nodes, int64_t n_bins,

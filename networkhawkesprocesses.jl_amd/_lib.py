@@ -120,7 +120,7 @@ def _declare(lib):
     f("nhp_probe_draws", i32, _vp, i32, u64, u64, i64, _dp, _dp, _dp)
     f("nhp_probe_rate", i32, _vp, i32, i32, i32, _dp)
     f("nhp_probe_gather", i32, _vp, i32, i32, i64, i32, _dp)
-    f("nhp_probe_stream", i32, _vp, i32, i64, i32, i32, _dp)
+    f("nhp_probe_stream", i32, _vp, i32, i64, i32, i32, _dp, C.POINTER(C.c_int64))
     for name, args in (
         ("nhp_cont_loglik_grad", (_vp, _vp, _vp, i32, _dp, _dp, i64)),
         ("nhp_cont_intensity", (_vp, _vp, _vp, _dp, i64, _dp)),

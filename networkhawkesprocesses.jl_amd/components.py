@@ -263,7 +263,7 @@ class ExponentialImpulseResponse(ImpulseResponse):
         if len(x) != self.θ.size:
             raise ValueError("Parameter vector length does not match model parameter length.")
         n = self.size()
-        self.θ = np.asarray(x, dtype=np.float64).reshape((n, n), order="F").copy()
+        self.θ = np.asarray(x, dtype=np.float64).reshape((n, n), order="F").copy(order="F")   # (column-major like the vector: a plain copy)
 
     def resample_(self, Mnm, Xnm, rng):
         """resample!: θ ~ Gamma(α + Mnm, 1/(β + Mnm·Xnm)) -- src/impulses.jl:68-73"""
@@ -297,8 +297,8 @@ class LogitNormalImpulseResponse(ImpulseResponse):
             raise ValueError("Parameter vector length does not match model parameter length.")
         n = self.size()
         x = np.asarray(x, dtype=np.float64)
-        self.μ = x[: n * n].reshape((n, n), order="F").copy()
-        self.τ = x[n * n:].reshape((n, n), order="F").copy()
+        self.μ = x[: n * n].reshape((n, n), order="F").copy(order="F")
+        self.τ = x[n * n:].reshape((n, n), order="F").copy(order="F")
 
     def resample_(self, Mnm, Xnm, Vnm, rng):
         """resample!: normal-gamma conjugate draw -- src/impulses.jl:204-214"""
@@ -337,7 +337,7 @@ class DenseWeightModel(Weights):
         """params!: src/weights.jl:9-15"""
         if len(x) != self.W.size:
             raise ValueError("Parameter vector length does not match model parameter length.")
-        self.W = np.asarray(x, dtype=np.float64).reshape(self.W.shape, order="F").copy()
+        self.W = np.asarray(x, dtype=np.float64).reshape(self.W.shape, order="F").copy(order="F")
 
     def resample_(self, Mn, Mnm, rng):
         """resample!: W ~ Gamma(κ + Mnm, 1/(ν + Mn[p])) -- src/weights.jl:59-64"""

@@ -110,6 +110,8 @@ extern "C" void nhp_ctx_destroy(nhp_ctx *ctx)
     if (ctx->ev_err) (void)hipEventDestroy(ctx->ev_err);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_mle) (void)hipFree(ctx->d_mle);
+    if (ctx->h_mle_scal) (void)hipHostFree(ctx->h_mle_scal);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

@@ -46,6 +46,11 @@ struct nhp_ctx {
     size_t partials2_cap = 0;
     unsigned int *d_counter2 = nullptr;
     int cu_count = 256;
+    // the device optimizer's state (nhp_lbfgs.h): kept between mle! runs -- allocating and freeing ~400 MB per run cost
+    // several ms of a 30 ms run
+    void *d_mle = nullptr;
+    size_t mle_cap = 0;
+    double *h_mle_scal = nullptr;       // pinned scalars of its readbacks
     std::string err;
 };
 

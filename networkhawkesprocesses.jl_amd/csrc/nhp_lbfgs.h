@@ -16,6 +16,7 @@
 // run's last call -- the iterate the caller's model has to hold afterwards (a trial may be evaluated straight from d_x).
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 #include "nhp_internal.h"
@@ -193,19 +194,39 @@ nhp_status nhp_lbfgs_box(nhp_ctx *ctx, int64_t P, double lower, double upper, do
 {
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    // NHP_TIMING=1: where a run spends its wall time outside the steps (stderr)
+    static const bool timing = getenv("NHP_TIMING") && atoi(getenv("NHP_TIMING")) != 0;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(st);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[nhp mle] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     mle_state s{ctx, P};
     s.grid = dim3((unsigned)std::min<int64_t>(2048, (P + 255) / 256));
 
     // x, x_new, g, g_new, q, d + HIST pairs (s_i, y_i): (6 + 2·HIST)·P doubles (370 MB at N = 1024)
-    double *buf = nullptr;
     const size_t nvec = 6 + NB;
-    if (hipMalloc((void **)&buf, 8 * (nvec * (size_t)P + (size_t)RBLK * NACC + NACC + 1)) != hipSuccess) {
-        nhp_set_error(ctx, "out of device memory (mle! state)");
+    const size_t need = 8 * (nvec * (size_t)P + (size_t)RBLK * NACC + NACC + 1);
+    if (ctx->mle_cap < need) {                                  // (kept by the context between runs)
+        (void)hipFree(ctx->d_mle);
+        ctx->d_mle = nullptr; ctx->mle_cap = 0;
+        if (hipMalloc(&ctx->d_mle, need) != hipSuccess) {
+            (void)hipGetLastError();
+            nhp_set_error(ctx, "out of device memory (mle! state)");
+            return NHP_ENOMEM;
+        }
+        ctx->mle_cap = need;
+    }
+    if (!ctx->h_mle_scal && hipHostMalloc((void **)&ctx->h_mle_scal, 8 * (NACC + 1)) != hipSuccess) {
+        ctx->h_mle_scal = nullptr;
+        nhp_set_error(ctx, "out of pinned memory");
         return NHP_ENOMEM;
     }
-    struct guard { double *b; double *h; ~guard() { (void)hipFree(b); if (h) (void)hipHostFree(h); } } g_{buf, nullptr};
-    if (hipHostMalloc((void **)&s.h_scal, 8 * (NACC + 1)) != hipSuccess) { nhp_set_error(ctx, "out of pinned memory"); return NHP_ENOMEM; }
-    g_.h = s.h_scal;
+    double *buf = (double *)ctx->d_mle;
+    s.h_scal = ctx->h_mle_scal;
     double *d_x = buf, *d_xn = d_x + P, *d_g = d_xn + P, *d_gn = d_g + P, *d_q = d_gn + P, *d_d = d_q + P;
     double *d_S = d_d + P, *d_Y = d_S + (size_t)HIST * P;
     s.d_base = d_S; s.d_part = d_Y + (size_t)HIST * P; s.d_scal = s.d_part + (size_t)RBLK * NACC;
@@ -222,6 +243,7 @@ nhp_status nhp_lbfgs_box(nhp_ctx *ctx, int64_t P, double lower, double upper, do
     int evals = 0, steps = 0, nhist = 0, head = 0;        // active slots [head - nhist, head) modulo HIST, newest last
     bool converged = false;
 
+    lap("state + start uploaded");
     NHP_TRY(eval(d_x, d_g, false)); ++evals;
     {
         double ll = 0.0;
@@ -230,6 +252,7 @@ nhp_status nhp_lbfgs_box(nhp_ctx *ctx, int64_t P, double lower, double upper, do
     }
     if (!std::isfinite(f)) { nhp_set_error(ctx, "mle!: the objective is not finite at the starting point"); return NHP_EDOMAIN; }
 
+    lap("first evaluation");
     // the masked gradient at the start and its products (no pair stored yet: nothing but q·q is read)
     int filled = 0;                                            // slots written since the last reset (the others hold zeros)
     double qq = 0.0, qs[HIST] = {}, qy[HIST] = {};             // q·q, q·s_j, q·y_j by slot
@@ -348,6 +371,7 @@ nhp_status nhp_lbfgs_box(nhp_ctx *ctx, int64_t P, double lower, double upper, do
         if (std::fabs(f - minloss) < f_abstol) { converged = true; break; }     // the reference's callback rule
         minloss = f;
     }
+    lap("steps");
     // the model holds the last TRIAL; make it the iterate
     NHP_TRY(eval(d_x, d_gn, true));
     {
@@ -356,6 +380,7 @@ nhp_status nhp_lbfgs_box(nhp_ctx *ctx, int64_t P, double lower, double upper, do
         f = -ll;
     }
     NHP_TRY(nhp_download(ctx, x, d_x, 8 * (size_t)P));
+    lap("last evaluation + download");
     *loss = f; *steps_out = steps; *converged_out = converged ? 1 : 0;
     if (evals_out) *evals_out = evals;
     return NHP_OK;

@@ -167,7 +167,8 @@ __global__ __launch_bounds__(512) void k_probe_stream(const uint32_t *__restrict
     if (acc == 0x12345678u) sink[0] = 1.0;
 }
 
-extern "C" nhp_status nhp_probe_stream(nhp_ctx *ctx, int32_t mode, int64_t bytes, int32_t blocks, int32_t threads, double *us_per_launch)
+extern "C" nhp_status nhp_probe_stream(nhp_ctx *ctx, int32_t mode, int64_t bytes, int32_t blocks, int32_t threads, double *us_per_launch,
+                                        int64_t *bytes_read)
 {
     if (!ctx || !us_per_launch || bytes < 1 || blocks < 1 || (threads != 256 && threads != 512) || (mode != 0 && mode != 1)) return NHP_EINVAL;
     NHP_HIP(ctx, hipSetDevice(ctx->device));
@@ -193,5 +194,6 @@ extern "C" nhp_status nhp_probe_stream(nhp_ctx *ctx, int32_t mode, int64_t bytes
     float ms = 0.f;
     NHP_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *us_per_launch = 1e3 * (double)ms / reps;
+    if (bytes_read) *bytes_read = (int64_t)(waves * rows_per_wave * row_bytes);        // (the request rounded down to whole rows per wave)
     return NHP_OK;
 }

@@ -94,7 +94,7 @@ def mle_(process, data, optimizer="L-BFGS-B", verbose=False, f_abstol=1e-6, regu
     ctx = (shard.ctx if shard else ctx) or _lib.default_context()
     ds = shard.local if shard else device_dataset(process, data, ctx)
     rng = np.random.default_rng(seed)
-    x0 = _rand_init_(process, rng) if guess is None else np.array(guess, dtype=np.float64)
+    x0 = _rand_init_(process, rng) if guess is None else np.asarray(guess, dtype=np.float64)
     if shard is not None and shard.world > 1:                        # rank 0's start everywhere
         x0 = _all_reduce_sum(x0 if shard.rank == 0 else np.zeros_like(x0), ctx)
     lower, upper = 1e-6, 1e1
@@ -103,7 +103,6 @@ def mle_(process, data, optimizer="L-BFGS-B", verbose=False, f_abstol=1e-6, regu
 
     import ctypes as C
     from .continuous import _check_recursive
-    model = process.device_model(ctx)
     flags = _check_recursive(process, recursive)
     P = len(x0)
     comm = _lib.comm_for(ctx) if shard is not None else None
@@ -115,7 +114,12 @@ def mle_(process, data, optimizer="L-BFGS-B", verbose=False, f_abstol=1e-6, regu
             raise NotImplementedError("optimizer='device' minimises -loglikelihood only; use the host optimizer with regularize=True")
         if shard is not None and shard.world > 1 and comm is None:
             raise NotImplementedError("optimizer='device' on a sharded dataset needs an RCCL clique (one GPU per rank)")
-        x = np.ascontiguousarray(np.clip(x0, lower, upper), dtype=np.float64)
+        x = np.clip(x0, lower, upper)                               # (a new float64 vector: the caller's guess is not written to)
+        # mle! overwrites the process anyway: taking the start into it first leaves its tables column-major like the
+        # vector, so lowering them to the device model is a plain copy (a fresh process holds row-major numpy arrays, whose
+        # lowering transposes 16 MB at N = 1024); a wrong-length guess raises the reference's error here
+        process.params_(x)
+        model = process.device_model(ctx)
         loss, steps, conv, evals = C.c_double(), C.c_int32(), C.c_int32(), C.c_int32()
         _lib.check(_lib.lib().nhp_cont_mle_run(ctx.h, comm.h if comm is not None else None, ds.h, model.h, flags, lower, upper,
                                                float(f_abstol), int(max_steps), _lib.dptr(x), P, C.byref(loss), C.byref(steps),
@@ -123,10 +127,12 @@ def mle_(process, data, optimizer="L-BFGS-B", verbose=False, f_abstol=1e-6, regu
         if verbose:
             print(f" > steps: {steps.value}, objective evaluations: {evals.value}, loss: {loss.value}, elapsed: {time.time() - start}")
         process.params_(x)
-        res = MaximumLikelihood(x.copy(), -float(loss.value), int(steps.value), time.time() - start,
+        res = MaximumLikelihood(x, -float(loss.value), int(steps.value), time.time() - start,
                                 "success" if conv.value else "failure")
         res.evaluations = int(evals.value)
         return res
+
+    model = process.device_model(ctx)
 
     def fg(x):
         # params!(process, x) straight into the device-resident model: x already is the reference's

@@ -9,6 +9,10 @@ run() {   # run <tag> <counters...> -- <cmd...>
   tag=$1; shift; ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
   rocprofv3 --kernel-trace --pmc "${ctr[@]}" --output-format csv -d $R/gpurun_out/pmc_traffic/$tag -- "$@" > /dev/null 2>&1
 }
+# calibration of FETCH_SIZE on the child slices' own access shape (4 + 2 bytes per lane; the guide's factor 2 is for 16 bytes per
+# lane): nhp_probe_stream mode 1 reads a known number of bytes per launch
+STREAM_ONE=1,512,1024,512 run cal_fetch FETCH_SIZE -- python3 $R/tools/dbg/streambw.py
+STREAM_ONE=1,512,1024,512 python3 $R/tools/dbg/streambw.py > $R/gpurun_out/pmc_traffic/cal_bytes.txt 2>/dev/null
 run k8_fetch FETCH_SIZE -- python3 $R/tools/kbench.py windowed_k8 10
 run k8_write WRITE_SIZE -- python3 $R/tools/kbench.py windowed_k8 10
 run k8_tcc TCC_HIT_sum TCC_MISS_sum -- python3 $R/tools/kbench.py windowed_k8 10
@@ -23,15 +27,27 @@ def mean(tag, kern, name):
          for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"] and r["Counter_Name"] == name]
     return sum(v) / len(v) if v else None
 out = {}
-for key, pre, kern, label in (("windowed_k8", "k8", "k_windowed_pairs<", "k_windowed_pairs<0,4,1,512>"), ("batch_8_sets", "b8", "k_windowed_batch", "k_windowed_batch<0,8,1024>")):
+# bytes per FETCH_SIZE KB on the slices' access shape: the probe's known bytes per launch over its counter value
+cal = None
+try:
+    known = int(open(f"{R}/gpurun_out/pmc_traffic/cal_bytes.txt").read().split("bytes=")[1].split()[0])
+    cf = mean("cal_fetch", "k_probe_stream", "FETCH_SIZE")
+    cal = known / (cf * 1024.0)
+except Exception as exc:
+    print("calibration pass failed:", exc)
+for key, pre, kern, label, factor in (("windowed_k8", "k8", "k_windowed_slices<", "k_windowed_slices<512,2,true,false>", cal),
+                                      ("batch_8_sets", "b8", "k_windowed_batch", "k_windowed_batch<0,8,1024>", 2.0)):
     f, w = mean(pre + "_fetch", kern, "FETCH_SIZE"), mean(pre + "_write", kern, "WRITE_SIZE")
     h, m = mean(pre + "_tcc", kern, "TCC_HIT_sum"), mean(pre + "_tcc", kern, "TCC_MISS_sum")
-    if f is None: continue
+    if f is None or factor is None: continue
     out[key] = {"kernel": label, "commit": os.environ.get("NHP_HEAD", "unknown"),
                 "source": f"gpurun_out/pmc_traffic/{pre}_{{fetch,write,tcc}} (separate rocprofv3 --pmc passes; tools/traffic.sh)",
-                "FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB_raw": w,
-                "correction": "MI355X_MICROARCH.md HBM: FETCH_SIZE counts 128-B requests at 64 B on gfx950 -> doubled; WRITE_SIZE exact; unit KB",
-                "traffic_bytes_per_launch": int(2 * f * 1024 + (w or 0) * 1024), "tcc_hit_rate": h / (h + m) if h is not None else None}
+                "FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB_raw": w, "fetch_factor": factor,
+                "correction": ("FETCH_SIZE calibrated on this kernel's own access shape (nhp_probe_stream mode 1: 4 + 2 bytes per lane, known bytes per launch; "
+                               "MI355X_MICROARCH.md HBM: other widths than 16 B per lane are uncalibrated): factor = known bytes / counter"
+                               if key == "windowed_k8" else
+                               "MI355X_MICROARCH.md HBM: FETCH_SIZE counts 128-B requests at 64 B on gfx950 -> doubled") + "; WRITE_SIZE exact; unit KB",
+                "traffic_bytes_per_launch": int(factor * f * 1024 + (w or 0) * 1024), "tcc_hit_rate": h / (h + m) if h is not None else None}
 json.dump(out, open(f"{R}/gpurun_out/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
