@@ -22,6 +22,7 @@ struct rccl_api {
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    std::string why;            // why not, captured once: dlerror() hands its message out a single time
 };
 
 rccl_api &rccl()
@@ -29,8 +30,11 @@ rccl_api &rccl()
     static rccl_api api = [] {
         rccl_api a;
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *n : names)
+        for (const char *n : names) {
             if ((a.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
+            const char *e = dlerror();
+            a.why = e ? e : "dlopen(librccl.so.1) failed";
+        }
         if (!a.handle) return a;
         a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.handle, "ncclGetUniqueId");
         a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.handle, "ncclCommInitRank");
@@ -39,6 +43,11 @@ rccl_api &rccl()
         a.AllGather = (decltype(a.AllGather))dlsym(a.handle, "ncclAllGather");
         a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
         a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.AllGather && a.GetErrorString;
+        if (!a.ok) {                                            // an RCCL without a symbol this library calls: say so, keep nothing open
+            a.why = "librccl lacks a required symbol";
+            (void)dlclose(a.handle);
+            a.handle = nullptr;
+        }
         return a;
     }();
     return api;
@@ -47,7 +56,7 @@ rccl_api &rccl()
 nhp_status need_rccl(nhp_ctx *ctx)
 {
     if (rccl().ok) return NHP_OK;
-    nhp_set_error(ctx, "RCCL is not available: %s", rccl().handle ? "librccl lacks a required symbol" : dlerror());
+    nhp_set_error(ctx, "RCCL is not available: %s", rccl().why.c_str());
     return NHP_ERCCL;
 }
 }   // namespace

@@ -695,7 +695,7 @@ extern "C" nhp_status nhp_cont_network_step(nhp_ctx *ctx, nhp_comm *comm, const 
     NHP_TRY(nhp_adj_enqueue(ctx, ds, m, nullptr, 0.5, m->d_rho, nullptr, seed, step, &d_links));
     hipLaunchKernelGGL(k_links_total, dim3(1), dim3(256), 0, ctx->stream, d_links, ds->N, m->d_rho);
     NHP_HIP(ctx, hipGetLastError());
-    if (comm && comm->world > 1) NHP_TRY(nhp_comm_allreduce_dev(ctx, comm, m->d_rho + 3, 1));      // the shards' link counts
+    if (comm) NHP_TRY(nhp_comm_allreduce_dev(ctx, comm, m->d_rho + 3, 1));      // the shards' link counts (a one-rank clique runs the same call)
     const double nn = (double)ds->N * (double)ds->N;
     if (!fixed) {
         hipLaunchKernelGGL(k_rho_draw, dim3(1), dim3(64), 0, ctx->stream, m->d_rho, alpha, beta, nn, seed, step);

@@ -21,8 +21,6 @@
 // running sum with the bin's ascending thresholds u_(1) < u_(2) < ... (order statistics generated one
 // at a time from Philox, so n events cost one walk).  One lane owns a bin's running sum, in the
 // reference's category order with separate multiply and add: counts equal the oracle's, bit for bit.
-#define RP_TT 64
-#define RP_CT 128
 #define RP_KC 16
 #define RP_KEY 0xD15C0DE5EEDC0FFEull
 
@@ -36,20 +34,24 @@ __device__ __attribute__((noinline)) double rp_next_u(double u_prev, int remaini
 }
 
 // RP_SLOTS = occupied bins a thread carries through one pair of walks: the host picks the smallest of 1, 2, 4 whose
-// 256·RP_SLOTS slots hold a tile's occupied bins (an empty slot costs the walk as much as a full one: at config 4 a
+// RP_TH·RP_SLOTS slots hold a tile's occupied bins (an empty slot costs the walk as much as a full one: at config 4 a
 // 64 x 128 tile holds ~400, and two slots per thread take 14.7 ms where four took 20.9).
-template <int RP_SLOTS>
-__global__ __launch_bounds__(256, 3) void k_disc_resample_parents(const double *__restrict__ dataT, const double *__restrict__ conv,
+// RP_TT x RP_CT = the tile (bins x child nodes), RP_TH threads.  What a launch moves is the staging traffic: per chunk of RP_KC
+// categories a tile fetches (RP_TT + RP_CT)·RP_KC doubles for RP_TT·RP_CT·rate occupied bins -- 78 GB per sweep at config 4 with
+// 64 x 128 tiles (5.6 TB/s out of L2 / the Infinity Cache: the bound of the 14 ms launch), half of that with 128 x 256.
+template <int RP_SLOTS, int RP_TT, int RP_CT, int RP_TH>
+__global__ __launch_bounds__(RP_TH) void k_disc_resample_parents(const double *__restrict__ dataT, const double *__restrict__ conv,
                                                                const double *__restrict__ E2, const double *__restrict__ base,
                                                                const double *__restrict__ baseT, int64_t T, int N, int B,
                                                                unsigned b_magic, uint64_t seed, uint64_t step,
                                                                int *__restrict__ counts, int *__restrict__ base_counts)
 {
 #pragma clang fp contract(off)
-    __shared__ unsigned short list[RP_TT * RP_CT];
-    __shared__ double Gt[RP_KC][RP_TT];
-    __shared__ double Et[RP_KC][RP_CT + 1];
-    __shared__ int nb, wcnt[4];
+    extern __shared__ __align__(16) unsigned char rp_smem[];
+    double (*Gt)[RP_TT] = reinterpret_cast<double (*)[RP_TT]>(rp_smem);                                   // [RP_KC][RP_TT]
+    double (*Et)[RP_CT + 1] = reinterpret_cast<double (*)[RP_CT + 1]>(rp_smem + 8 * RP_KC * RP_TT);      // [RP_KC][RP_CT + 1]
+    unsigned short *list = reinterpret_cast<unsigned short *>(rp_smem + 8 * RP_KC * (RP_TT + RP_CT + 1)); // [RP_TT * RP_CT]
+    __shared__ int nb, wcnt[RP_TH / 64];
     const int tid = threadIdx.x, K = N * B;
     const int64_t t0 = (int64_t)blockIdx.x * RP_TT;
     const int c0 = blockIdx.y * RP_CT;
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256, 3) void k_disc_resample_parents(const double *
     // bin row, so a wave's reads of a G row collapse to a few broadcast addresses and its reads of an E
     // row hit distinct banks.  Flags are gathered with coalesced loads (t fastest), then compacted in order.
     unsigned char *occ = reinterpret_cast<unsigned char *>(&Et[0][0]);       // [RP_TT][RP_CT], before Et is used
-    for (int i = tid; i < RP_TT * RP_CT; i += 256) {
+    for (int i = tid; i < RP_TT * RP_CT; i += RP_TH) {
         const int tl_ = i % RP_TT, cl_ = i / RP_TT;
         const int64_t t = t0 + tl_;
         const int c = c0 + cl_;
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256, 3) void k_disc_resample_parents(const double *
     __syncthreads();
     {
         const int lane = tid & 63, wave = tid >> 6;
-        constexpr int PER_WAVE = RP_TT * RP_CT / 4;
+        constexpr int PER_WAVE = RP_TT * RP_CT / (RP_TH / 64);
         int cnt = 0;
         for (int i = wave * PER_WAVE + lane; i < (wave + 1) * PER_WAVE; i += 64) cnt += __popcll(__ballot(occ[i] != 0));
         if (lane == 0) wcnt[wave] = cnt;
@@ -79,18 +81,19 @@ __global__ __launch_bounds__(256, 3) void k_disc_resample_parents(const double *
             if (f) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
             off += __popcll(m);
         }
-        if (tid == 255) nb = off;
+        if (tid == RP_TH - 1) nb = off;
     }
     __syncthreads();
     const int nbins = nb;
 
     // A chunk of RP_KC categories is fetched into registers one chunk ahead (under the previous chunk's
     // arithmetic) and written to LDS between two barriers.
-    constexpr int GN = RP_KC * RP_TT / 256, EN = RP_KC * RP_CT / 256;
-    static_assert(256 % RP_TT == 0 && 256 % RP_KC == 0, "staging coordinates below assume these");
+    constexpr int GN = RP_KC * RP_TT / RP_TH, EN = RP_KC * RP_CT / RP_TH;
+    static_assert(GN >= 1 && EN >= 1 && RP_TT * RP_CT <= 65536 && RP_TT * RP_CT <= 8 * RP_KC * (RP_CT + 1), "tile shape");
+    static_assert(RP_TH % RP_TT == 0 && RP_TH % RP_KC == 0, "staging coordinates below assume these");
     double rg[GN], re[EN];
-    // staging coordinates are fixed per thread: G element r is (category row tid/RP_TT + (256/RP_TT)·r,
-    // bin tid % RP_TT), E element r is (category tid % RP_KC, node tid/RP_KC + (256/RP_KC)·r).
+    // staging coordinates are fixed per thread: G element r is (category row tid/RP_TT + (RP_TH/RP_TT)·r,
+    // bin tid % RP_TT), E element r is (category tid % RP_KC, node tid/RP_KC + (RP_TH/RP_KC)·r).
     // Category q = p·B + b reads Ŝ[t, p, b]; q / B is a multiply-high by the host-made reciprocal.
     const int g_tt = tid % RP_TT, g_k0 = tid / RP_TT, e_kk = tid % RP_KC, e_c0 = tid / RP_KC;
     const bool g_ok = t0 + g_tt < T;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256, 3) void k_disc_resample_parents(const double *
         gmask = 0; emask = 0;
 #pragma unroll
         for (int r = 0; r < GN; ++r) {
-            const int qr = q0 + g_k0 + (256 / RP_TT) * r;
+            const int qr = q0 + g_k0 + (RP_TH / RP_TT) * r;
             const unsigned q = (unsigned)(qr < K ? qr : K - 1);
             const unsigned pq = B == 1 ? q : __umulhi(q, b_magic), bq = q - pq * (unsigned)B;
             rg[r] = g_base[(size_t)T32 * (size_t)(pq + (unsigned)N * bq)];
@@ -111,24 +114,24 @@ __global__ __launch_bounds__(256, 3) void k_disc_resample_parents(const double *
         }
 #pragma unroll
         for (int r = 0; r < EN; ++r) {
-            const int cr = c0 + e_c0 + (256 / RP_KC) * r, qr = q0 + e_kk;
+            const int cr = c0 + e_c0 + (RP_TH / RP_KC) * r, qr = q0 + e_kk;
             re[r] = E2[(size_t)(qr < K ? qr : K - 1) + (size_t)(cr < N ? cr : N - 1) * K];
             emask |= (qr < K && cr < N ? 1u : 0u) << r;
         }
     };
     auto stage = [&]() {
 #pragma unroll
-        for (int r = 0; r < GN; ++r) { const int e = tid + 256 * r; Gt[e / RP_TT][e % RP_TT] = (gmask >> r) & 1u ? rg[r] : 0.0; }
+        for (int r = 0; r < GN; ++r) { const int e = tid + RP_TH * r; Gt[e / RP_TT][e % RP_TT] = (gmask >> r) & 1u ? rg[r] : 0.0; }
 #pragma unroll
-        for (int r = 0; r < EN; ++r) { const int e = tid + 256 * r; Et[e % RP_KC][e / RP_KC] = (emask >> r) & 1u ? re[r] : 0.0; }
+        for (int r = 0; r < EN; ++r) { const int e = tid + RP_TH * r; Et[e % RP_KC][e / RP_KC] = (emask >> r) & 1u ? re[r] : 0.0; }
     };
 
-    for (int b0 = 0; b0 < nbins; b0 += 256 * RP_SLOTS) {
+    for (int b0 = 0; b0 < nbins; b0 += RP_TH * RP_SLOTS) {
         int tl[RP_SLOTS], cl[RP_SLOTS], n[RP_SLOTS], j[RP_SLOTS];
         double cum[RP_SLOTS], total[RP_SLOTS], thr[RP_SLOTS], u[RP_SLOTS];
 #pragma unroll
         for (int s = 0; s < RP_SLOTS; ++s) {
-            const int idx = b0 + tid + 256 * s;
+            const int idx = b0 + tid + RP_TH * s;
             const int e = idx < nbins ? list[idx] : 0;
             tl[s] = e / RP_CT; cl[s] = e % RP_CT;
             n[s] = idx < nbins ? (int)dataT[(size_t)(t0 + tl[s]) + (size_t)T * (c0 + cl[s])] : 0;
@@ -211,19 +214,33 @@ static nhp_status disc_parent_counts(nhp_ctx *ctx, const nhp_disc_dataset *ds, c
     int *d_counts = reinterpret_cast<int *>(extra);
     hipStream_t st = ctx->stream;
     NHP_HIP(ctx, hipMemsetAsync(d_counts, 0, sizeof(int) * NC, st));
-    dim3 grid((unsigned)((ds->T + RP_TT - 1) / RP_TT), (unsigned)((N + RP_CT - 1) / RP_CT));
     if (ds->T >= ((int64_t)1 << 31) || K >= ((size_t)1 << 24)) { nhp_set_error(ctx, "resample_parents: T or N*B too large"); return NHP_ENOTIMPL; }
     // q / B for q < 2^24 as a multiply-high: exact with magic = floor(2^32 / B) + 1 while q·B < 2^32
     const unsigned b_magic = (unsigned)((((uint64_t)1 << 32) / (uint64_t)ds->B + 1) & 0xFFFFFFFFu);   // unused for B = 1
     if (ds->d_base_counts) NHP_HIP(ctx, hipMemsetAsync(ds->d_base_counts, 0, sizeof(int) * (size_t)ds->T * N, st));
-    // occupied bins of a 64 x 128 tile: the mean plus three standard deviations (a tile that overflows its slots walks twice)
-    const double mean = (double)ds->nocc * (double)(RP_TT * RP_CT) / ((double)ds->T * (double)std::max<size_t>(N, RP_CT));
+    // tile (bins x nodes, threads): the larger one halves the staging traffic per occupied bin where the problem fills it;
+    // NHP_RP_TILE = "TT,CT,THREADS" overrides (64,128,256 | 128,128,512 | 128,256,1024), NHP_RP_SLOTS the slots per thread
+    int TT = 64, CT = 128, TH = 256;
+    if (N >= 256 && ds->T >= 128 * 256) { TT = 128; CT = 256; TH = 1024; }
+    if (const char *ts = getenv("NHP_RP_TILE")) sscanf(ts, "%d,%d,%d", &TT, &CT, &TH);
+    if (!((TT == 64 && CT == 128 && TH == 256) || (TT == 128 && CT == 128 && TH == 512) || (TT == 128 && CT == 256 && TH == 1024))) { TT = 64; CT = 128; TH = 256; }
+    dim3 grid((unsigned)((ds->T + TT - 1) / TT), (unsigned)((N + CT - 1) / CT));
+    // occupied bins of a tile: the mean plus three standard deviations (a tile that overflows its slots walks twice)
+    const double mean = (double)ds->nocc * (double)(TT * CT) / ((double)ds->T * (double)std::max<size_t>(N, (size_t)CT));
     const double need = mean + 3.0 * sqrt(mean);
     const char *fs = getenv("NHP_RP_SLOTS");
-    const int slots = fs ? atoi(fs) : (need <= 256.0 ? 1 : need <= 512.0 ? 2 : 4);
-#define RP_LAUNCH(S) hipLaunchKernelGGL(k_disc_resample_parents<S>, grid, dim3(256), 0, st, ds->d_dataT, ds->d_conv, E2, base, \
-                       lambda0 ? nullptr : ds->d_baseT, ds->T, ds->N, ds->B, b_magic, seed, step, d_counts, ds->d_base_counts)
-    if (slots == 1) RP_LAUNCH(1); else if (slots == 2) RP_LAUNCH(2); else RP_LAUNCH(4);
+    const int slots = fs ? atoi(fs) : (need <= 1.0 * TH ? 1 : need <= 2.0 * TH ? 2 : 4);
+    const size_t lds = 8 * (size_t)RP_KC * (size_t)(TT + CT + 1) + 2 * (size_t)TT * CT;
+#define RP_LAUNCH(S, tt, ct, th)                                                                                                  \
+    do {                                                                                                                          \
+        if (lds > 64 * 1024)                                                                                                      \
+            (void)hipFuncSetAttribute((const void *)k_disc_resample_parents<S, tt, ct, th>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_disc_resample_parents<S, tt, ct, th>), grid, dim3(th), lds, st, ds->d_dataT, ds->d_conv, E2, base,  \
+                           lambda0 ? nullptr : ds->d_baseT, ds->T, ds->N, ds->B, b_magic, seed, step, d_counts, ds->d_base_counts); \
+    } while (0)
+#define RP_TILE(tt, ct, th) do { if (slots == 1) RP_LAUNCH(1, tt, ct, th); else if (slots == 2) RP_LAUNCH(2, tt, ct, th); else RP_LAUNCH(4, tt, ct, th); } while (0)
+    if (TT == 64) RP_TILE(64, 128, 256); else if (CT == 128) RP_TILE(128, 128, 512); else RP_TILE(128, 256, 1024);
+#undef RP_TILE
 #undef RP_LAUNCH
     if (ds->d_base_counts) const_cast<nhp_disc_dataset *>(ds)->base_counts_valid = true;
     NHP_HIP(ctx, hipGetLastError());

@@ -361,10 +361,15 @@ function pull!(p::NHP.ContinuousHawkesProcess, ctx, m)     # device-resident mod
     end
 end
 
+# moments=true: the chain's posterior sums over the steps >= burn are kept on the device (nhp_cont_model_moments_*, what
+# `gather_moments` exchanges between chains) and come back as the second value: (res, (sum, sumsq, count, rho)) -- fetched
+# before the device model is released.  Without it no sum is accumulated (burn = -1 to the library).
 function mcmc!(p::NHP.ContinuousHawkesProcess, data; nsteps=1000, log_freq=100, verbose=false, seed::UInt64=UInt64(0),
-               keep_samples=true, ctx=context(), comm=nothing, ds=Dataset(ctx, data, NHP.ndims(p), p.impulses.Δtmax))
+               keep_samples=true, moments=false, burn::Integer=0, ctx=context(), comm=nothing,
+               ds=Dataset(ctx, data, NHP.ndims(p), p.impulses.Δtmax))
     p.baseline isa NHP.HomogeneousProcess || error("mcmc! on the device draws the homogeneous baseline; use the package's mcmc! with an LGCP baseline")
     res = NHP.MarkovChainMonteCarlo(p)
+    mom = nothing
     start_time = time()
     network = p isa NHP.ContinuousNetworkHawkesProcess
     bern = network && p.network isa NHP.BernoulliNetworkModel
@@ -372,11 +377,12 @@ function mcmc!(p::NHP.ContinuousHawkesProcess, data; nsteps=1000, log_freq=100, 
     pr = Ref(priors(p))
     with_model(ctx, p) do m
         network && check(ccall((:nhp_cont_model_set_rho, libnhp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Float64), ctx.h, m, bern ? p.network.ρ : 1.0), ctx.h)
+        moments && check(ccall((:nhp_cont_model_moments_reset, libnhp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.h, m), ctx.h)
         while res.steps < nsteps
             n = keep_samples ? 1 : min(nsteps - res.steps, verbose ? log_freq : nsteps)
             check(ccall((:nhp_cont_mcmc_run, libnhp), Int32,
                         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Priors}, Float64, Float64, UInt64, UInt64, Int64, Int64),
-                        ctx.h, commptr(comm), ds.h, m, pr, na, nb, seed, UInt64(res.steps), n, keep_samples ? -1 : 0), ctx.h)
+                        ctx.h, commptr(comm), ds.h, m, pr, na, nb, seed, UInt64(res.steps), n, moments ? Int64(burn) : Int64(-1)), ctx.h)
             res.steps += n
             if keep_samples || res.steps == nsteps
                 pull!(p, ctx, m)
@@ -387,9 +393,18 @@ function mcmc!(p::NHP.ContinuousHawkesProcess, data; nsteps=1000, log_freq=100, 
                 println(" > step: $(res.steps), elapsed: $(res.elapsed)")
             end
         end
+        if moments                                          # while the model is alive
+            N = NHP.ndims(p)
+            len = N + N * N * (p.impulses isa NHP.ExponentialImpulseResponse ? 1 : 2) + N * N + (network ? N * N : 0)
+            s, q, cnt, rho = Vector{Float64}(undef, len), Vector{Float64}(undef, len), Ref{Int64}(0), zeros(3)
+            check(ccall((:nhp_cont_model_moments_fetch, libnhp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{Int64}),
+                        ctx.h, m, s, q, len, cnt), ctx.h)
+            network && check(ccall((:nhp_cont_model_get_rho, libnhp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}), ctx.h, m, rho), ctx.h)
+            mom = (s, q, cnt[], rho)
+        end
     end
     res.elapsed = time() - start_time
-    return res
+    return moments ? (res, mom) : res
 end
 
 # BASELINE config 5: after every rank ran its own chain with keep_samples=false, the per-chain posterior sums (still on
