@@ -112,6 +112,9 @@ def two_streams(nhp, base_ctx, r, steps, local):
     `value`, because a launch that shares the GPU takes longer (the per-launch roofline is the single-stream one)."""
     from nhp_amd import _lib
     lib = _lib.lib()
+    # the leg's launches take another instantiation of the slice kernel (4 rows per request instead of 2: +0.3 us alone), so
+    # that rocprofv3's per-symbol average of the headline kernel holds the headline's launches only
+    os.environ["NHP_SLICES_CFG"] = "512,4"
     ctxs = [base_ctx, nhp.Context(local)]
     dss, models, keep = [], [], []
     for ctx in ctxs:
@@ -131,7 +134,10 @@ def two_streams(nhp, base_ctx, r, steps, local):
     go(steps)
     dt = time.perf_counter() - t0
     lls = [float(c.fetch(0, 1)[0]) for c in ctxs]
+    os.environ.pop("NHP_SLICES_CFG", None)
+    B = algorithmic_bytes(r["N"], r["M"], r["kind"])
     return {"streams": 2, "value": 2 * steps / dt, "unit": "log-likelihood evals/sec", "us_per_evaluation": 1e6 * dt / (2 * steps),
+            "aggregate_hbm_frac_on_algorithmic_bytes": 2 * steps * B / dt / 1e9 / HBM_PEAK_GBS, "kernel": "k_windowed_slices<512,4,true,false>",
             "loglik": lls}
 
 
@@ -247,13 +253,16 @@ def _eight_models(nhp, ctx, r):
 def batch_leg(nhp, ctx, r, args, sync):
     """nhp_cont_loglik_batch: S DISTINCT parameter sets against the headline dataset per call -- what the metric's real
     callers issue (the 2P objective calls of a finite-difference gradient inside mle!, src/continuous.jl:190; restarts;
-    chain populations).  Eight sets share one pass over the data (k_windowed_batch).  Roofline on the batch's OWN
-    algorithmic bytes: the data once, every parameter set once: 16·M + S·8·P."""
+    chain populations).  Four sets share one pass over the dataset's child slices (k_slices_batch: every pair record
+    fetched and decoded once for the four).  Roofline on the batch's OWN algorithmic bytes: the data once per pass, every
+    parameter set once: (16·M + 4·8·P) per pass of 4."""
     import ctypes as C
     import numpy as np
     from nhp_amd import _lib
     procs, ds, models = _eight_models(nhp, ctx, r)
     P = r["N"] + 2 * r["N"] * r["N"]
+    SETS = 4                                                   # parameter sets per launch (cont_slices.hip)
+    t_launch, t_commit = measured_traffic("batch_4_sets")      # bytes per LAUNCH (one pass of 4 sets), from the committed PMC passes
     res = {}
     for nb in (8, 32, 64):
         arr = (C.c_void_p * nb)(*[models[q % 8].h for q in range(nb)])
@@ -266,15 +275,18 @@ def batch_leg(nhp, ctx, r, args, sync):
             _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, ds.h, arr, nb, 0, _lib.dptr(outb)), ctx.h)
         sync()
         tb = (time.perf_counter() - t0) / reps
-        B = (nb // 8) * (16 * r["M"] + 8 * 8 * P)             # per call: nb/8 passes of 8 sets
+        B = (nb // SETS) * (16 * r["M"] + SETS * 8 * P)        # per call: nb/4 passes of 4 sets
         res[f"sets_{nb}"] = {"value": nb / tb, "unit": "log-likelihood evals/sec", "us_per_evaluation": 1e6 * tb / nb,
                              "calls": reps, "loglik_first_last": [float(outb[0]), float(outb[-1])],
                              "roofline": {"bound": "hbm", "achieved": B / tb / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": B / tb / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": B, "traffic": None},
+                                          "frac": B / tb / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": B,
+                                          "traffic": None if t_launch is None else (nb // SETS) * t_launch,
+                                          "traffic_measured_at_commit": t_commit},
                              "exp_terms_per_s": nb * r["pairs"] / tb,
                              "frac_of_measured_exp_term_ceiling": nb * r["pairs"] / tb / EXP_TERM_CEILING}
-    res["note"] = ("wall time per call incl. one result fetch; 8 sets per pass (k_windowed_batch: one lane per (child, set), "
-                   "windows gathered once per child for all 8)")
+    res["note"] = ("wall time per call incl. one result fetch; 4 sets per pass (k_slices_batch: one lane per child, the four "
+                   "models' columns in LDS, every pair record fetched once for the four); launches alternate between the "
+                   "context's two streams")
     return res
 
 
@@ -642,9 +654,8 @@ def main():
                     help="comma list of workloads whose single evaluation is also column-sharded over the ranks (N>1 only); '' to skip")
     ap.add_argument("--chain-steps", type=int, default=int(os.environ.get("NHP_BENCH_CHAIN_STEPS", "50")),
                     help="mcmc! steps per rank of the config-5 leg (N>1 only); 0 to skip")
-    ap.add_argument("--two-streams", action="store_true",
-                    help="also time two independent evaluation streams sharing the GPU (N=1).  Off by default: its launches "
-                         "of the headline kernel would enter the rocprofv3 per-symbol average of the default command")
+    ap.add_argument("--no-two-streams", dest="two_streams", action="store_false",
+                    help="skip the leg with two independent evaluation streams sharing the GPU (N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-default-dispatch", action="store_true", help="skip the recursive=true legs (the reference's default call)")
     ap.add_argument("--no-batch", action="store_true", help="skip the batch / changing-parameter legs")

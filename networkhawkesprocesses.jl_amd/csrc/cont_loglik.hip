@@ -1291,6 +1291,19 @@ extern "C" nhp_status nhp_cont_loglik_batch(nhp_ctx *ctx, const nhp_cont_dataset
                 lane.flip();
             }
             for (int q = 1; q < take; ++q) NHP_TRY(nhp_check_pair(ctx, ds, ms[q]));
+            // exponential models on a dataset with child slices: four (or two) at a time through ONE pass over the slices
+            // (cont_slices.hip: every pair record fetched and decoded once for all of them)
+            if (windowed && take >= 2 && ds->d_sl_row) {
+                const int S = take >= 4 ? 4 : 2;
+                bool launched = false;
+                NHP_TRY(nhp_launch_slices_batch(ctx, ds, ms, S, k, &launched));
+                if (launched) {
+                    if (second) lane.flip();
+                    ++launches;
+                    k += S;
+                    continue;
+                }
+            }
             if (take == 8) NHP_TRY(enqueue_batch<8>(ctx, ds, ms, k));
             else if (take == 4 && lane_kernel) NHP_TRY(enqueue_batch<4>(ctx, ds, ms, k));
             else if (take == 2 && lane_kernel) NHP_TRY(enqueue_batch<2>(ctx, ds, ms, k));

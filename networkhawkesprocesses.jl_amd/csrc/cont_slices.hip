@@ -33,9 +33,9 @@ struct nhp_slices {               // kernel-side view of nhp_cont_dataset::d_sl_
 
 #define NHP_SL_SHARDS 64
 
-#ifdef NHP_STAMP      // diagnostic build only (tools/dbg/slstamps.py): s_memtime at the phase boundaries of wave 0 of every workgroup
+#ifdef NHP_STAMP      // diagnostic build only (tools/dbg/slstamps.py): s_memrealtime (100 MHz, one clock for all XCDs) at the phase boundaries of wave 0 of every workgroup
 __device__ unsigned long long g_sl_stamps[8 * 4096];
-#define NHP_SL_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_sl_stamps[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define NHP_SL_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_sl_stamps[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int nhp_debug_stamps_slices(unsigned long long *out, int n)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sl_stamps), sizeof(unsigned long long) * (size_t)n);
@@ -529,6 +529,174 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_slices(nhp_cont_args a, nhp_
         __hip_atomic_store(&counter[32 * i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- S parameter sets per pass --------------------------------------------------------------------------
+// The callers of "log-likelihood evaluations per second" come in batches (the 2P objective calls of a finite-difference
+// gradient inside the reference's mle!, src/continuous.jl:190; restarts :200; chain populations).  For S models on one dataset
+// a slice's rows are fetched and decoded ONCE; a lane (= child) keeps S running sums, one per model, each term from that
+// model's column in LDS (S planes of N + 1 entries).  What a pass then costs is its exponentials: ~18 instructions per pair
+// and model + 4 per pair.
+#define NHP_SETS_MAX 4
+struct nhp_sets {
+    const double *p1[NHP_SETS_MAX], *W[NHP_SETS_MAX], *A[NHP_SETS_MAX], *lambda0[NHP_SETS_MAX];
+    double *out[NHP_SETS_MAX];
+};
+
+template <int BLOCK, int C, int S>
+__global__ __launch_bounds__(BLOCK) void k_slices_batch(nhp_cont_args a, nhp_slices sl, nhp_sets st, double *__restrict__ partials,
+                                                         unsigned int *__restrict__ counter)
+{
+    constexpr int NW = BLOCK / 64;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *red = reinterpret_cast<double *>(smem);                 // [2 * NW <= 32] + flag at [32]
+    double2 *col = reinterpret_cast<double2 *>(smem + 320);         // [S][N + 1]
+    double *etab = reinterpret_cast<double *>(col + (size_t)S * (a.N + 1));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const double tab_v = nhp_exp2_64[lane];
+    const nhp_item it = a.items[blockIdx.x];
+    const int c = it.node, N = a.N;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchild = it.kend - it.kbeg;
+    const int s0 = sl.item0[blockIdx.x], ns = sl.item0[blockIdx.x + 1] - s0;
+
+    struct chunk { uint32_t lo[C], hi[C]; };
+    auto request = [&](chunk &q, const uint32_t row0, const int r) {
+        const size_t o = ((size_t)row0 + (size_t)r) * 64;
+        const uint32_t *pl = sl.lo + o;
+        const uint16_t *ph = sl.hi + o;
+#pragma unroll
+        for (int u = 0; u < C; ++u) {
+            q.lo[u] = pl[u * 64 + lane];
+            q.hi[u] = ph[u * 64 + lane];
+        }
+    };
+    int j = w;
+    uint32_t row0 = 0;
+    int K = 0;
+    if (j < ns) { row0 = sl.row[s0 + j]; K = (int)(sl.row[s0 + j + 1] - row0); }
+    chunk qa, qb;
+    request(qa, row0, 0);
+
+    const double unit = __builtin_ldexp(a.dt_max, -sl.dbits);
+    double integ[S];
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+        integ[m] = 0.0;
+        for (int p = tid; p < N; p += BLOCK) {
+            const size_t k = (size_t)p + (size_t)c * N;
+            double wv = st.W[m][k];
+            if (st.A[m]) wv = st.A[m][k] * wv;                      // windowed route: the integral is masked too
+            const double th = st.p1[m][k];
+            col[(size_t)m * (N + 1) + p] = make_double2(-((th * unit) * 92.33248261689366), wv * th);
+            if (it.first) integ[m] += a.cnt[p] * wv;
+        }
+        if (tid == 0) col[(size_t)m * (N + 1) + N] = make_double2(0.0, 0.0);
+        if (it.first && tid == 0) integ[m] += st.lambda0[m][c] * a.duration;
+    }
+    if (tid < 64) etab[tid] = tab_v;
+    __syncthreads();
+
+    const uint32_t dmask = sl.dmask;
+    const int nsh = sl.nsh;
+    const uint32_t plane = (uint32_t)(N + 1) * 16u;                 // bytes between the models' columns
+    auto terms = [&](const uint32_t lo, const uint32_t h, double (&acc)[S]) {
+        uint32_t hw;
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hw) : "s"(dmask), "v"(h), "v"(0x43300000u));
+        const double v = __hiloint2double((int)hw, (int)lo) - 4503599627370496.0;
+        const unsigned char *base = reinterpret_cast<const unsigned char *>(col) + ((h >> nsh) << 4);
+#pragma unroll
+        for (int m = 0; m < S; ++m) {
+            const double2 cw = *reinterpret_cast<const double2 *>(base + m * plane);
+            acc[m] = __builtin_fma(cw.y, nhp_exp_neg_tab_scaled(cw.x * v, etab), acc[m]);
+        }
+    };
+    auto sum = [&](const chunk &q, const int r, const int K, double (&acc)[S]) {
+        if (r + C <= K) {
+#pragma unroll
+            for (int u = 0; u < C; ++u) terms(q.lo[u], q.hi[u], acc);
+        } else {
+#pragma unroll
+            for (int u = 0; u < C; ++u)
+                if (r + u < K) terms(q.lo[u], q.hi[u], acc);
+        }
+    };
+    double lam0[S], prod[S];
+    int pexp[S];
+#pragma unroll
+    for (int m = 0; m < S; ++m) { lam0[m] = st.lambda0[m][c]; prod[m] = 1.0; pexp[m] = 0; }
+    while (j < ns) {
+        const int jn = j + NW;
+        uint32_t row0n = 0;
+        int Kn = 0;
+        if (jn < ns) { row0n = sl.row[s0 + jn]; Kn = (int)(sl.row[s0 + jn + 1] - row0n); }
+        double acc[S];
+#pragma unroll
+        for (int m = 0; m < S; ++m) acc[m] = 0.0;
+        if (K <= 0) request(qa, row0n, 0);
+        for (int r0 = 0; r0 < K; r0 += 2 * C) {
+            request(qb, row0, r0 + C);
+            asm volatile("" ::: "memory");
+            sum(qa, r0, K, acc);
+            const bool more = r0 + 2 * C < K;
+            request(qa, more ? row0 : row0n, more ? r0 + 2 * C : 0);
+            asm volatile("" ::: "memory");
+            sum(qb, r0 + C, K, acc);
+        }
+        const int kk = 64 * j + lane;
+        if (kk < nchild) {
+#pragma unroll
+            for (int m = 0; m < S; ++m) {
+                const double lam = lam0[m] + acc[m];
+                prod[m] *= lam < 0.0 ? __builtin_nan("") : __builtin_amdgcn_frexp_mant(lam);
+                pexp[m] += __builtin_amdgcn_frexp_exp(lam);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < S; ++m) {
+            pexp[m] += __builtin_amdgcn_frexp_exp(prod[m]);
+            prod[m] = __builtin_amdgcn_frexp_mant(prod[m]);
+        }
+        j = jn; row0 = row0n; K = Kn;
+    }
+    int *flag = reinterpret_cast<int *>(red + 32);
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+        double blk = nhp_log(prod[m]) + (double)pexp[m] * 6.93147180559945286e-01;
+        if (prod[m] == 0.0) blk = -__builtin_inf();
+        double blk_int = integ[m];
+        nhp_block_sum2_n<NW>(blk, blk_int, red);
+        if (tid == 0) {
+            __hip_atomic_store(&partials[(2 * (size_t)blockIdx.x) * S + 2 * m], blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&partials[(2 * (size_t)blockIdx.x) * S + 2 * m + 1], blk_int, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int nb = gridDim.x, sh = blockIdx.x % NHP_SL_SHARDS;
+        const unsigned int pop = (nb - sh + NHP_SL_SHARDS - 1) / NHP_SL_SHARDS;
+        const unsigned int used = nb < NHP_SL_SHARDS ? nb : NHP_SL_SHARDS;
+        int last = 0;
+        if (__hip_atomic_fetch_add(&counter[32 * (1 + sh)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pop - 1)
+            last = __hip_atomic_fetch_add(&counter[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == used - 1;
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+        double sl_ = 0.0, si = 0.0;
+        for (unsigned int i = tid; i < gridDim.x; i += BLOCK) {
+            sl_ += __hip_atomic_load(&partials[(2 * (size_t)i) * S + 2 * m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            si += __hip_atomic_load(&partials[(2 * (size_t)i) * S + 2 * m + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        nhp_block_sum2_n<NW>(sl_, si, red);
+        if (tid == 0) *st.out[m] = (0.0 - si) + sl_;
+        __syncthreads();
+    }
+    for (int i = tid; i <= NHP_SL_SHARDS; i += BLOCK)
+        __hip_atomic_store(&counter[32 * i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 static nhp_slices slices_view(const nhp_cont_dataset *ds)
 {
     nhp_slices sl;
@@ -722,4 +890,52 @@ extern "C" int64_t nhp_debug_parent_slices(const nhp_cont_dataset *ds, uint32_t 
         if (hipMemcpy(hi, ds->d_ps_hi, 2 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -2;
     }
     return n;
+}
+
+template <int S>
+static nhp_status launch_sets(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *const *ms, int32_t slot0, size_t lds)
+{
+    NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)ds->n_items * S));
+    nhp_cont_args a = nhp_make_args(ds, ms[0]);
+    NHP_TRY(ensure_slices(ctx, ds, a));
+    const nhp_slices sl = slices_view(ds);
+    nhp_sets st;
+    for (int k = 0; k < NHP_SETS_MAX; ++k) {
+        const nhp_cont_model *m = ms[k < S ? k : 0];
+        st.p1[k] = m->d_p1; st.W[k] = m->d_W; st.A[k] = m->has_A ? m->d_A : nullptr; st.lambda0[k] = m->d_lambda0;
+        st.out[k] = ctx->d_results + slot0 + (k < S ? k : 0);
+    }
+    const double mean_rows = ds->n_slices > 0 ? (double)ds->sl_rows / (double)ds->n_slices : 0.0;
+    dim3 grid((unsigned)ds->n_items);
+    // (the columns of S models leave room for two workgroups of 512 per CU at N = 1024, S = 4; NHP_SETS_CFG = "BLOCK,C" overrides)
+    int B = (ds->max_item + 63) / 64 >= 6 ? 512 : 256, C = mean_rows >= 16.0 ? 4 : 2;
+    if (const char *cfg = getenv("NHP_SETS_CFG")) sscanf(cfg, "%d,%d", &B, &C);
+#define NHP_BL(b, cc)                                                                                                  \
+    do {                                                                                                               \
+        if (lds > 64 * 1024)                                                                                           \
+            (void)hipFuncSetAttribute((const void *)k_slices_batch<b, cc, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_slices_batch<b, cc, S>), grid, dim3(b), lds, ctx->stream, a, sl, st, ctx->d_partials, ctx->d_counter); \
+    } while (0)
+    if (B == 256 && C == 2) NHP_BL(256, 2); else if (B == 256) NHP_BL(256, 4);
+    else if (B == 1024 && C == 2) NHP_BL(1024, 2); else if (B == 1024) NHP_BL(1024, 4);
+    else if (C == 2) NHP_BL(512, 2); else NHP_BL(512, 4);
+#undef NHP_BL
+    NHP_HIP(ctx, hipGetLastError());
+    return NHP_OK;
+}
+
+nhp_status nhp_launch_slices_batch(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *const *ms, int S, int32_t slot0,
+                                   bool *launched)
+{
+    *launched = false;
+    if (!ds->d_sl_row || ds->n_items <= 0 || (S != 2 && S != 4)) return NHP_OK;
+    if ((getenv("NHP_SLICES") && atoi(getenv("NHP_SLICES")) == 0) || (getenv("NHP_BATCH_SLICES") && atoi(getenv("NHP_BATCH_SLICES")) == 0)) return NHP_OK;
+    for (int k = 0; k < S; ++k)
+        if (!ms[k] || ms[k]->impulse_kind != NHP_IMPULSE_EXPONENTIAL || ms[k]->baseline_kind != NHP_BASELINE_HOMOGENEOUS) return NHP_OK;
+    const size_t lds = 320 + 16 * ((size_t)ds->N + 1) * (size_t)S + 512;
+    if (lds > 160 * 1024) return NHP_OK;
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    if (S == 4) NHP_TRY(launch_sets<4>(ctx, ds, ms, slot0, lds)); else NHP_TRY(launch_sets<2>(ctx, ds, ms, slot0, lds));
+    *launched = true;
+    return NHP_OK;
 }

@@ -323,6 +323,11 @@ nhp_status nhp_launch_grad_slices(nhp_ctx *ctx, const nhp_cont_dataset *ds, cons
                                   bool *launched);
 // true: that launch stores every entry of the gradient itself; false: it adds to what k_grad_init left
 bool nhp_grad_slices_direct(const nhp_cont_dataset *ds, const nhp_cont_model *m);
+// S = 2 or 4 exponential models with homogeneous baselines on one dataset in ONE pass over its child slices (every record is
+// fetched and decoded once, S columns sit in LDS): results -> ctx->d_results[slot0 .. slot0 + S).  *launched = false when the
+// models are not covered (the caller falls back to its other kernels).
+nhp_status nhp_launch_slices_batch(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *const *ms, int S, int32_t slot0,
+                                   bool *launched);
 nhp_cont_args nhp_make_args(const nhp_cont_dataset *ds, const nhp_cont_model *m);
 nhp_status nhp_check_pair(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m);
 // Device -> caller memory through the context's pinned staging buffer: DMA at link speed into pinned memory, then one

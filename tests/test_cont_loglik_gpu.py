@@ -279,6 +279,19 @@ def test_batches_of_eight_share_one_pass(nhp, orc, kind, network, lgcp, N, M, T,
     assert np.max(np.abs(out - want) / np.abs(want)) < TOL
     single = np.array([nhp.loglikelihood(c["proc"], data, recursive=False) for c in cases])
     assert np.max(np.abs(out - single) / np.abs(single)) < 1e-13
+    # exponential models with flat baselines go four (or two) at a time through one pass over the child slices
+    # (k_slices_batch); NHP_BATCH_SLICES=0 keeps them on k_windowed_batch: same values, for every workgroup shape
+    monkeypatch.setenv("NHP_BATCH_SLICES", "0")
+    out0 = np.empty(n)
+    _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, ds.h, arr, n, 0, _lib.dptr(out0)), ctx.h)
+    assert np.max(np.abs(out0 - want) / np.abs(want)) < TOL
+    monkeypatch.delenv("NHP_BATCH_SLICES", raising=False)
+    for cfg in ("256,2", "256,4", "512,2", "512,4", "1024,2", "1024,4"):
+        monkeypatch.setenv("NHP_SETS_CFG", cfg)
+        out1 = np.empty(n)
+        _lib.check(_lib.lib().nhp_cont_loglik_batch(ctx.h, ds.h, arr, n, 0, _lib.dptr(out1)), ctx.h)
+        assert np.max(np.abs(out1 - want) / np.abs(want)) < TOL, cfg
+    monkeypatch.delenv("NHP_SETS_CFG", raising=False)
 
 
 def test_batch_handles_empty_windows_and_degenerate_intensities(nhp, orc):

@@ -13,7 +13,7 @@ prof() {   # prof <name> <script and args...>: kernel stats csv -> $O/${TAG}_<na
   cp $O/prof_${TAG}_$n/*/*kernel_stats.csv $O/${TAG}_${n}_kernel_stats.csv
 }
 prof bench $R/bench.py
-prof headline_only $R/bench.py --no-batch --no-default-dispatch --extra '' --configs '' --no-cpu
+prof headline_only $R/bench.py --no-batch --no-default-dispatch --no-two-streams --extra '' --configs '' --no-cpu
 prof config3_chain $R/tools/chain.py 50
 prof config4 $R/tools/c4.py
 DG_RATE=0.05 prof discrete_gibbs_parents $R/tools/dgibbs.py

@@ -36,7 +36,7 @@ try:
 except Exception as exc:
     print("calibration pass failed:", exc)
 for key, pre, kern, label, factor in (("windowed_k8", "k8", "k_windowed_slices<", "k_windowed_slices<512,2,true,false>", cal),
-                                      ("batch_8_sets", "b8", "k_windowed_batch", "k_windowed_batch<0,8,1024>", 2.0)):
+                                      ("batch_4_sets", "b8", "k_slices_batch<", "k_slices_batch<512,2,4>", cal)):
     f, w = mean(pre + "_fetch", kern, "FETCH_SIZE"), mean(pre + "_write", kern, "WRITE_SIZE")
     h, m = mean(pre + "_tcc", kern, "TCC_HIT_sum"), mean(pre + "_tcc", kern, "TCC_MISS_sum")
     if f is None or factor is None: continue
@@ -45,7 +45,7 @@ for key, pre, kern, label, factor in (("windowed_k8", "k8", "k_windowed_slices<"
                 "FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB_raw": w, "fetch_factor": factor,
                 "correction": ("FETCH_SIZE calibrated on this kernel's own access shape (nhp_probe_stream mode 1: 4 + 2 bytes per lane, known bytes per launch; "
                                "MI355X_MICROARCH.md HBM: other widths than 16 B per lane are uncalibrated): factor = known bytes / counter"
-                               if key == "windowed_k8" else
+                               if factor is cal else
                                "MI355X_MICROARCH.md HBM: FETCH_SIZE counts 128-B requests at 64 B on gfx950 -> doubled") + "; WRITE_SIZE exact; unit KB",
                 "traffic_bytes_per_launch": int(factor * f * 1024 + (w or 0) * 1024), "tcc_hit_rate": h / (h + m) if h is not None else None}
 json.dump(out, open(f"{R}/gpurun_out/traffic.json", "w"), indent=1)
