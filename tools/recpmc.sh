@@ -1,5 +1,8 @@
 #!/bin/bash
 # PMC passes over the full recursion (k_recursive*): where do the cycles go?  Usage: tools/recpmc.sh  (on the GPU box)
+# (Round 2's run of this script left gpurun_out/pmc_rec/s1-s3 only: the fourth set below produced no counter file on
+#  k_recursive_waves and no log of that pass was kept -- stdout / stderr go to /dev/null here -- so its cause is not known;
+#  profiles/r02_pmc/recursive_waves_counters.txt holds the three sets that finished.  Not re-run.)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 i=0
