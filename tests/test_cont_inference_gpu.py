@@ -420,6 +420,37 @@ def test_device_mle_reaches_a_maximum_the_host_optimizer_cannot_improve(nhp, orc
     assert back.maximum >= host.maximum - 1e-9 * scale
 
 
+def test_device_mle_with_most_weights_on_the_lower_bound(nhp, orc):
+    """A sparse truth: three quarters of W are zero, so at the optimum most weights sit on the box's lower bound 1e-6 and
+    the projection clips most quasi-Newton steps.  The line search accepts a trial only along a path that descends to first
+    order and never with a larger objective (csrc/nhp_lbfgs.h): the run must end at a point of the box where the projected
+    gradient vanishes, not below its start, with the clipped coordinates exactly on the bound, and the host optimizer
+    started there must find nothing better."""
+    N, T = 8, 600.0
+    rng = np.random.default_rng(12)
+    W = rng.uniform(0.1, 0.4, (N, N)) * (rng.uniform(size=(N, N)) < 0.25)          # 24 links of 64, spectral radius 0.72
+    proc = nhp.ContinuousStandardHawkesProcess(nhp.HomogeneousProcess(rng.uniform(0.5, 1.0, N)),
+                                               nhp.ExponentialImpulseResponse(rng.uniform(2.0, 4.0, (N, N)), 1.0, 1.0, 2.0),
+                                               nhp.DenseWeightModel(W))
+    data = nhp.synthetic.rand(proc, T, seed=4)
+    assert len(data[0]) > 3000
+    guess = np.random.default_rng(6).uniform(0.3, 0.9, len(proc.params()))
+    ll0 = nhp.loglikelihood(_set(proc, guess), data, recursive=False)
+    dev = nhp.mle_(proc, data, guess=guess, recursive=False, f_abstol=1e-10, max_steps=5000, optimizer="device")
+    x = dev.maximizer
+    assert dev.maximum >= ll0 and np.all(x >= 1e-6) and np.all(x <= 10.0)
+    Wfit = x[N + N * N:].reshape((N, N), order="F")
+    on_bound = Wfit == 1e-6
+    assert on_bound.sum() >= N * N // 4                             # (24 of the 40 true zeros end exactly on the bound)
+    ll, g = nhp.loglikelihood_gradient(proc, data, recursive=False)
+    assert ll == pytest.approx(dev.maximum, rel=1e-12)
+    scale = max(1.0, abs(dev.maximum)) ** 0.5
+    pg = np.where(((x <= 1e-6) & (g < 0)) | ((x >= 10.0) & (g > 0)), 0.0, g)
+    assert np.max(np.abs(pg)) < 5e-2 * scale
+    polish = nhp.mle_(proc, data, guess=x, recursive=False, f_abstol=1e-10, max_steps=3000)
+    assert polish.maximum - dev.maximum < 1e-4 * scale
+
+
 def _set(proc, x):
     proc.params_(np.asarray(x, dtype=np.float64))
     return proc

@@ -15,7 +15,7 @@ for rep in range(2):
     guess = np.clip(proc.params() * np.random.default_rng(9).uniform(0.5, 1.5, len(proc.params())), 1e-6, 10.0)
     nhp.device_dataset(proc, (times, nodes, T), ctx)
     t0 = time.perf_counter()
-    res = nhp.mle_(proc, (times, nodes, T), guess=guess, recursive=False, f_abstol=1e-12, max_steps=steps, optimizer="device", ctx=ctx)
+    res = nhp.mle_(proc, (times, nodes, T), guess=guess, recursive=bool(int(os.environ.get("REC", "0"))), f_abstol=1e-12, max_steps=steps, optimizer="device", ctx=ctx)
     dt = time.perf_counter() - t0
     print(f"device mle!: {res.steps} steps, {res.evaluations} evaluations in {dt:.3f} s = {1e3 * dt / max(1, res.steps):.3f} ms per step, "
           f"log-likelihood {res.maximum:.6f} ({res.status})", flush=True)
