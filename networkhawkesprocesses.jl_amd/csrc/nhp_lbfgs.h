@@ -42,18 +42,41 @@ __global__ __launch_bounds__(256) void k_mle_multidot3(const double *__restrict_
     double acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const double ui = u ? u[i] : 0.0, vi = v ? v[i] : 0.0, wi = w[i];
-        double b[NB];
-#pragma unroll
-        for (int j = 0; j < HIST; ++j) {
-            b[j] = j < na ? base[(size_t)j * n + i] : 0.0;
-            b[HIST + j] = j < na ? base[(size_t)(HIST + j) * n + i] : 0.0;
-        }
+    auto one = [&](const double ui, const double vi, const double wi, const double (&b)[NB]) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) { acc[j] += ui * b[j]; acc[NB + j] += vi * b[j]; acc[2 * NB + j] += wi * b[j]; }
         acc[3 * NB] += ui * ui; acc[3 * NB + 1] += vi * vi; acc[3 * NB + 2] += wi * wi;
         acc[3 * NB + 3] += ui * vi; acc[3 * NB + 4] += ui * wi; acc[3 * NB + 5] += vi * wi;
+    };
+    // two consecutive elements per thread and trip: 16-byte loads of every vector (vector starts are 16-byte aligned when n is even:
+    // the state is carved in units of n doubles from a hipMalloc'ed block); an odd n takes the scalar loop
+    if ((n & 1) == 0) {
+        const int64_t n2 = n >> 1;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+            const double2 z = make_double2(0.0, 0.0);
+            const double2 ui = u ? reinterpret_cast<const double2 *>(u)[i] : z, vi = v ? reinterpret_cast<const double2 *>(v)[i] : z;
+            const double2 wi = reinterpret_cast<const double2 *>(w)[i];
+            double b0[NB], b1[NB];
+#pragma unroll
+            for (int j = 0; j < HIST; ++j) {
+                const double2 s2 = j < na ? reinterpret_cast<const double2 *>(base + (size_t)j * n)[i] : z;
+                const double2 y2 = j < na ? reinterpret_cast<const double2 *>(base + (size_t)(HIST + j) * n)[i] : z;
+                b0[j] = s2.x; b1[j] = s2.y; b0[HIST + j] = y2.x; b1[HIST + j] = y2.y;
+            }
+            one(ui.x, vi.x, wi.x, b0);
+            one(ui.y, vi.y, wi.y, b1);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+            const double ui = u ? u[i] : 0.0, vi = v ? v[i] : 0.0, wi = w[i];
+            double b[NB];
+#pragma unroll
+            for (int j = 0; j < HIST; ++j) {
+                b[j] = j < na ? base[(size_t)j * n + i] : 0.0;
+                b[HIST + j] = j < na ? base[(size_t)(HIST + j) * n + i] : 0.0;
+            }
+            one(ui, vi, wi, b);
+        }
     }
 #pragma unroll
     for (int k = 0; k < NACC; ++k) {
@@ -110,6 +133,24 @@ __global__ __launch_bounds__(256) void k_mle_combine(double *__restrict__ d, con
                                                      mle_coef c, int na, const double *__restrict__ g, const double *__restrict__ x,
                                                      double lo, double hi, int64_t n)
 {
+    if ((n & 1) == 0) {                                             // 16-byte loads (see k_mle_multidot3)
+        const int64_t n2 = n >> 1;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+            const double2 qi = reinterpret_cast<const double2 *>(q)[i];
+            double v0 = c.q * qi.x, v1 = c.q * qi.y;
+#pragma unroll
+            for (int j = 0; j < HIST; ++j)
+                if (j < na) {
+                    const double2 s2 = reinterpret_cast<const double2 *>(base + (size_t)j * n)[i];
+                    const double2 y2 = reinterpret_cast<const double2 *>(base + (size_t)(HIST + j) * n)[i];
+                    v0 += c.b[j] * s2.x + c.b[HIST + j] * y2.x;
+                    v1 += c.b[j] * s2.y + c.b[HIST + j] * y2.y;
+                }
+            const double2 gi = reinterpret_cast<const double2 *>(g)[i], xi = reinterpret_cast<const double2 *>(x)[i];
+            reinterpret_cast<double2 *>(d)[i] = make_double2(held_at(xi.x, gi.x, lo, hi) ? 0.0 : v0, held_at(xi.y, gi.y, lo, hi) ? 0.0 : v1);
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         double v = c.q * q[i];
 #pragma unroll
