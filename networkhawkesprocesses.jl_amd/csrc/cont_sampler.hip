@@ -524,6 +524,13 @@ static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
     // NHP_SAMPLER=1 | 8 forces a kernel (8 still respects the threshold).
     const int force = getenv("NHP_SAMPLER") ? atoi(getenv("NHP_SAMPLER")) : 0;
     const double kbar = ds->M > 0 ? (double)ds->pairs / (double)ds->M : 0.0;
+    // logit-normal impulses on a sliced dataset: one lane per child over the slice planes (cont_slices.hip; same bits)
+    bool sliced = false;
+    if (!expo && !force) {
+        NHP_TRY(nhp_launch_sampler_slices(ctx, ds, m, d_u, seed, step, want_parents ? o->parents : nullptr,
+                                          want_parents ? o->pnodes : nullptr, o->pn_b, o->dt_b, d_err, &sliced));
+    }
+    if (!sliced) {
     const bool coop = force != 1 && ds->max_window + 1 <= 1024 && (force == 8 || kbar >= 24.0);
     const size_t lds = (expo ? 16 : 24) * N + (coop ? 0 : 8 * (size_t)NHP_BLOCK * SAMP_CLD);
     if (lds > 160 * 1024) { nhp_set_error(ctx, "n_nodes = %d exceeds the 160 KiB LDS column budget", ds->N); return NHP_ENOTIMPL; }
@@ -534,6 +541,7 @@ static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
     hipLaunchKernelGGL(fn, dim3((unsigned)ds->n_items), dim3(NHP_BLOCK), lds, st, a, d_u, seed, step,
                        want_parents ? o->parents : nullptr, want_parents ? o->pnodes : nullptr, o->pn_b, o->dt_b, d_err);
     NHP_HIP(ctx, hipGetLastError());
+    }
     ds->pn_valid = true;
     if (want_stats) {
         const size_t lds_stats = 8 * (3 * N + NHP_BLOCK + NHP_WAVES) + 4 * NHP_BLOCK + 4 * N + 16;

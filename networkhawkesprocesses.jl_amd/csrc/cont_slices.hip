@@ -20,6 +20,7 @@
 
 #include "nhp_internal.h"
 #include "nhp_math.h"
+#include "nhp_rng.h"
 
 struct nhp_slices {               // kernel-side view of nhp_cont_dataset::d_sl_*
     const uint32_t *row;          // [n_slices + 1]
@@ -697,6 +698,150 @@ __global__ __launch_bounds__(BLOCK) void k_slices_batch(nhp_cont_args a, nhp_sli
         __hip_atomic_store(&counter[32 * i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- parent sampler over the child slices, logit-normal impulses (config 3's sweep) -------------------------------------
+// resample_parent (src/parents.jl:25-46): weights [A·W·ħ(t_i - t_{i-1}), ..., λ0] most recent parent first, their sequential
+// sum, one uniform, the first index whose running sum of quotients w_k / s exceeds it.  A child is one lane, as in k_sampler --
+// the order of every addition and division is the contract -- but its records arrive row by row from the slice planes (one
+// coalesced load per row and wave instead of 64 cache lines per instruction) and the first CACHE weights wait in LDS, row by
+// lane, for the scan.  Padding records weigh exactly 0 and are added like the others: x + 0.0 = x, so a child's sum is the
+// sequential sum of ITS weights, bit for bit; the scan stops a lane at its own last parent.
+__global__ __launch_bounds__(256) void k_slices_build_lq(nhp_cont_args a, nhp_slices sl, double *__restrict__ L, double *__restrict__ Q)
+{
+#pragma clang fp contract(off)
+    const nhp_item it = a.items[blockIdx.x];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nchild = it.kend - it.kbeg;
+    const int s0 = sl.item0[blockIdx.x], ns = sl.item0[blockIdx.x + 1] - s0;
+    for (int j = w; j < ns; j += 4) {
+        const uint32_t row0 = sl.row[s0 + j];
+        const int K = (int)(sl.row[s0 + j + 1] - row0);
+        const int kk = 64 * j + lane;
+        nhp_child ch;
+        ch.t = 0.0; ch.first = 0; ch.idx = 0;
+        if (kk < nchild) ch = a.child_w[it.kbeg + kk];
+        const int len = ch.idx - ch.first;
+        for (int r = 0; r < K; ++r) {
+            double2 d = make_double2(0.0, 0.0);
+            if (r < len) d = nhp_logitnormal_data(a.inv_dtmax, ch.t - a.ev[ch.idx - 1 - r].t);
+            const size_t o = ((size_t)row0 + (size_t)r) * 64 + (size_t)lane;
+            L[o] = d.x;
+            Q[o] = d.y;
+        }
+    }
+}
+
+template <int BLOCK, int CACHE>
+__global__ __launch_bounds__(BLOCK) void k_sampler_slices(nhp_cont_args a, nhp_slices sl, const double *__restrict__ L, const double *__restrict__ Q,
+                                                           const double *__restrict__ u, uint64_t seed, uint64_t step,
+                                                           int64_t *__restrict__ parents, int64_t *__restrict__ pnodes,
+                                                           int32_t *__restrict__ pn_b, double *__restrict__ dt_b, int *__restrict__ err)
+{
+#pragma clang fp contract(off)
+    constexpr int NW = BLOCK / 64, C = 2;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 *col = reinterpret_cast<double2 *>(smem);               // [N + 1] {μ, √τ}; [N] = {0, 0}
+    double *colw = reinterpret_cast<double *>(col + a.N + 1);       // [N + 1] a·w; [N] = 0
+    double *cache = colw + a.N + 1;                                 // [NW][CACHE][64] the first weights of the slice's children
+    const nhp_item it = a.items[blockIdx.x];
+    const int c = it.node, N = a.N, tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchild = it.kend - it.kbeg;
+    const int s0 = sl.item0[blockIdx.x], ns = sl.item0[blockIdx.x + 1] - s0;
+    for (int p = tid; p < N; p += BLOCK) {
+        const size_t k = (size_t)p + (size_t)c * N;
+        double wv = a.W[k];
+        if (a.A) wv = a.A[k] * wv;
+        col[p] = make_double2(a.p1[k], __builtin_sqrt(a.p2[k]));
+        colw[p] = wv;
+    }
+    if (tid == 0) { col[N] = make_double2(0.0, 0.0); colw[N] = 0.0; }
+    __syncthreads();
+    double *wc = cache + (size_t)w * CACHE * 64 + lane;
+    const int nsh = sl.nsh;
+    struct chunk { uint32_t hi[C]; double l[C], q[C]; };
+    auto request = [&](chunk &qq, const uint32_t row0, const int r) {
+        const size_t o = ((size_t)row0 + (size_t)r) * 64;
+#pragma unroll
+        for (int x = 0; x < C; ++x) {
+            qq.hi[x] = sl.hi[o + x * 64 + lane];
+            qq.l[x] = L[o + x * 64 + lane];
+            qq.q[x] = Q[o + x * 64 + lane];
+        }
+    };
+    auto weight = [&](const uint32_t h, const double l, const double q) {
+        const int p = (int)(h >> nsh);
+        const double2 cq = col[p];
+        return colw[p] * nhp_pdf_logitnormal_cached(cq.x, cq.y, make_double2(l, q));
+    };
+    for (int j = w; j < ns; j += NW) {
+        const uint32_t row0 = sl.row[s0 + j];
+        const int K = (int)(sl.row[s0 + j + 1] - row0);
+        const int kk = 64 * j + lane;
+        const bool valid = kk < nchild;
+        nhp_child ch;
+        ch.t = 0.0; ch.first = 0; ch.idx = 0;
+        if (valid) ch = a.child_w[it.kbeg + kk];
+        const int i = ch.idx, nreal = ch.idx - ch.first, n = nreal + 1;
+        const double t = ch.t;
+        const double base = valid ? sl_baseline(a, c, t) : 1.0;
+        // ---- the sum, most recent parent first (0 + w_0 = w_0; the padding rows add 0), the baseline last
+        double v = 0.0;
+        chunk qa, qb;
+        request(qa, row0, 0);
+        for (int r0 = 0; r0 < K; r0 += 2 * C) {
+            request(qb, row0, r0 + C);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int x = 0; x < C; ++x)
+                if (r0 + x < K) {
+                    const double wk = weight(qa.hi[x], qa.l[x], qa.q[x]);
+                    if (r0 + x < CACHE) wc[(size_t)(r0 + x) * 64] = wk;
+                    v = v + wk;
+                }
+            request(qa, row0, r0 + 2 * C);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int x = 0; x < C; ++x)
+                if (r0 + C + x < K) {
+                    const double wk = weight(qb.hi[x], qb.l[x], qb.q[x]);
+                    if (r0 + C + x < CACHE) wc[(size_t)(r0 + C + x) * 64] = wk;
+                    v = v + wk;
+                }
+        }
+        const double s = v + base;
+        const bool live = valid && i > 0;                           // index == 1 -> (0, 0): src/parents.jl:26-28
+        if (live && (!(s > 0.0) || !(s < __builtin_inf()))) *err = 1;
+        const double draw = live ? (u ? u[i] : nhp_philox_uniform(seed, step, (uint64_t)i)) : 0.0;
+        // ---- the scan: cp_k = cp_{k-1} + w_k / s while cp_k <= u and k < n - 1 (the lanes of the wave step together; a lane
+        //      that has stopped stays stopped).  Weight k of a child: its k-th parent, or the baseline at k = n - 1.
+        auto wk_at = [&](const int k) {
+            if (k >= nreal) return base;
+            if (k < CACHE) return wc[(size_t)k * 64];
+            const size_t o = ((size_t)row0 + (size_t)k) * 64 + lane;
+            return weight(sl.hi[o], L[o], Q[o]);
+        };
+        int kk2 = 0;
+        double cp = live ? wk_at(0) / s : 0.0;
+        bool go = live && cp <= draw && kk2 < n - 1;
+        while (__ballot(go)) {
+            if (go) {
+                ++kk2;
+                cp = cp + wk_at(kk2) / s;
+                go = cp <= draw && kk2 < n - 1;
+            }
+        }
+        if (valid) {
+            const int parent = (live && kk2 < n - 1) ? i - 1 - kk2 : -1;
+            const int pnode = parent >= 0 ? a.nodes[parent] : -1;
+            if (parents) parents[i] = (int64_t)parent + 1;          // 1-based event index, 0 = baseline
+            if (pnodes) pnodes[i] = (int64_t)pnode + 1;
+            const int kb = a.wpos[it.kbeg + kk];
+            pn_b[kb] = pnode;
+            dt_b[kb] = parent >= 0 ? t - a.times[parent] : 0.0;
+        }
+    }
+}
+
 static nhp_slices slices_view(const nhp_cont_dataset *ds)
 {
     nhp_slices sl;
@@ -936,6 +1081,52 @@ nhp_status nhp_launch_slices_batch(nhp_ctx *ctx, const nhp_cont_dataset *ds, con
     if (lds > 160 * 1024) return NHP_OK;
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     if (S == 4) NHP_TRY(launch_sets<4>(ctx, ds, ms, slot0, lds)); else NHP_TRY(launch_sets<2>(ctx, ds, ms, slot0, lds));
+    *launched = true;
+    return NHP_OK;
+}
+
+nhp_status nhp_launch_sampler_slices(nhp_ctx *ctx, const nhp_cont_dataset *cds, const nhp_cont_model *m, const double *d_u, uint64_t seed,
+                                     uint64_t step, int64_t *parents, int64_t *pnodes, int32_t *pn_b, double *dt_b, int *d_err, bool *launched)
+{
+    *launched = false;
+    // (only windows below Julia's pairwise-sum threshold: the slice kernel sums sequentially)
+    if (!cds->d_sl_row || cds->n_items <= 0 || m->impulse_kind != NHP_IMPULSE_LOGITNORMAL || cds->sl_max_rows + 1 > 1024) return NHP_OK;
+    if ((getenv("NHP_SLICES") && atoi(getenv("NHP_SLICES")) == 0) || (getenv("NHP_SAMPLER_SLICES") && atoi(getenv("NHP_SAMPLER_SLICES")) == 0)) return NHP_OK;
+    int B = 512, CACHE = 8;
+    if (const char *cfg = getenv("NHP_SAMPLER_CFG")) sscanf(cfg, "%d,%d", &B, &CACHE);
+    if (!((B == 256 || B == 512) && (CACHE == 8 || CACHE == 16))) { B = 512; CACHE = 8; }
+    const size_t lds = 24 * ((size_t)cds->N + 1) + 8 * (size_t)(B / 64) * CACHE * 64;
+    if (lds > 160 * 1024) return NHP_OK;
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    nhp_cont_args a = nhp_make_args(cds, m);
+    NHP_TRY(ensure_slices(ctx, cds, a));
+    nhp_cont_dataset *ds = const_cast<nhp_cont_dataset *>(cds);
+    const nhp_slices sl = slices_view(ds);
+    if (!ds->d_sl_L) {
+        const size_t n = ((size_t)ds->sl_rows + 16) * 64;
+        if (hipMalloc((void **)&ds->d_sl_L, 8 * n) != hipSuccess || hipMalloc((void **)&ds->d_sl_Q, 8 * n) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(ds->d_sl_L); (void)hipFree(ds->d_sl_Q);
+            ds->d_sl_L = nullptr; ds->d_sl_Q = nullptr;
+            return NHP_OK;                                          // no room: the caller keeps its other kernel
+        }
+        NHP_HIP(ctx, hipMemsetAsync(ds->d_sl_L + (size_t)ds->sl_rows * 64, 0, 8 * 16 * 64, ctx->stream));
+        NHP_HIP(ctx, hipMemsetAsync(ds->d_sl_Q + (size_t)ds->sl_rows * 64, 0, 8 * 16 * 64, ctx->stream));
+        hipLaunchKernelGGL(k_slices_build_lq, dim3((unsigned)ds->n_items), dim3(256), 0, ctx->stream, a, sl, ds->d_sl_L, ds->d_sl_Q);
+        NHP_HIP(ctx, hipGetLastError());
+    }
+    dim3 grid((unsigned)ds->n_items);
+#define NHP_SAMP(b, cc)                                                                                                \
+    do {                                                                                                               \
+        if (lds > 64 * 1024)                                                                                           \
+            (void)hipFuncSetAttribute((const void *)k_sampler_slices<b, cc>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_sampler_slices<b, cc>), grid, dim3(b), lds, ctx->stream, a, sl, (const double *)ds->d_sl_L,   \
+                           (const double *)ds->d_sl_Q, d_u, seed, step, parents, pnodes, pn_b, dt_b, d_err);          \
+    } while (0)
+    if (B == 256 && CACHE == 8) NHP_SAMP(256, 8); else if (B == 256) NHP_SAMP(256, 16);
+    else if (CACHE == 8) NHP_SAMP(512, 8); else NHP_SAMP(512, 16);
+#undef NHP_SAMP
+    NHP_HIP(ctx, hipGetLastError());
     *launched = true;
     return NHP_OK;
 }

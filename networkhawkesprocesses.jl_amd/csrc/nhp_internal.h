@@ -117,6 +117,10 @@ struct nhp_cont_dataset {
     int32_t *d_sl_item0 = nullptr;      // [n_items + 1] first slice of each item
     uint32_t *d_sl_lo = nullptr;        // [(sl_rows + 16) * 64]
     uint16_t *d_sl_hi = nullptr;        // [(sl_rows + 16) * 64]
+    // logit-normal impulses: the data half of every record's pdf, {logit(x), 1/(x(1-x))} at x = Δt/Δtmax from the EXACT times with
+    // the operation sequence of nhp_logitnormal_data (the bits of d_plq), in the same rows as d_sl_lo / d_sl_hi (whose node
+    // field the consumers read); padding records hold {0, 0}.  Built at the first logit-normal parent sweep over the slices.
+    double *d_sl_L = nullptr, *d_sl_Q = nullptr;   // [(sl_rows + 16) * 64] each
     int64_t sl_rows = 0;
     int32_t n_slices = 0, sl_nb = 0;    // node bits
     int32_t sl_max_rows = 0;            // most rows of one slice
@@ -323,6 +327,10 @@ nhp_status nhp_launch_grad_slices(nhp_ctx *ctx, const nhp_cont_dataset *ds, cons
                                   bool *launched);
 // true: that launch stores every entry of the gradient itself; false: it adds to what k_grad_init left
 bool nhp_grad_slices_direct(const nhp_cont_dataset *ds, const nhp_cont_model *m);
+// resample_parents for logit-normal impulses over the child slices (one lane per child, rows coalesced, the first weights of a
+// child kept in LDS between the sum and the scan): same bits as k_sampler.  *launched = false when not covered.
+nhp_status nhp_launch_sampler_slices(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, const double *d_u, uint64_t seed,
+                                     uint64_t step, int64_t *parents, int64_t *pnodes, int32_t *pn_b, double *dt_b, int *d_err, bool *launched);
 // S = 2 or 4 exponential models with homogeneous baselines on one dataset in ONE pass over its child slices (every record is
 // fetched and decoded once, S columns sit in LDS): results -> ctx->d_results[slot0 .. slot0 + S).  *launched = false when the
 // models are not covered (the caller falls back to its other kernels).

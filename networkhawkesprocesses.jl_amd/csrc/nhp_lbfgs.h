@@ -237,6 +237,7 @@ nhp_status nhp_lbfgs_box(nhp_ctx *ctx, int64_t P, double lower, double upper, do
     hipStream_t st = ctx->stream;
     // NHP_TIMING=1: where a run spends its wall time outside the steps (stderr)
     static const bool timing = getenv("NHP_TIMING") && atoi(getenv("NHP_TIMING")) != 0;
+    static const bool trace = getenv("NHP_MLE_TRACE") && atoi(getenv("NHP_MLE_TRACE")) != 0;     // one line per accepted step (stderr)
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;
@@ -311,6 +312,7 @@ nhp_status nhp_lbfgs_box(nhp_ctx *ctx, int64_t P, double lower, double upper, do
     };
     for (int it = 0; it < max_steps; ++it) {
         if (!(qq > 0.0)) { converged = true; break; }          // projected gradient is zero: a stationary point of the box problem
+        const double qq_before = qq;
         // ---- two-loop recursion on coefficients: p = cq·q + Σ cs[j]·s_j + Σ cy[j]·y_j, starting from p = -q
         mle_coef c{};
         double *cs = c.b, *cy = c.b + HIST;
@@ -358,7 +360,8 @@ nhp_status nhp_lbfgs_box(nhp_ctx *ctx, int64_t P, double lower, double upper, do
         // ---- backtracking along the projected path; a trial = one fused (log-likelihood, gradient) evaluation and one readback
         //      of two scalars: the objective and the Armijo slope term g·(x_new - x) = q·s_new (s is zero on the held variables).
         //      A trial is accepted only on a path that descends to first order (dec < 0: once the projection has clipped the
-        //      descent components of a quasi-Newton step, what is left may point uphill) -- never with f_new > f.
+        //      descent components of a quasi-Newton step, what is left may point uphill; the step is then shortened like any
+        //      other failed trial) -- never with f_new > f.
         double *s_new = d_S + (size_t)head * P, *y_new = d_Y + (size_t)head * P;
         bool accepted = false;
         double fn = 0.0;
@@ -370,8 +373,7 @@ nhp_status nhp_lbfgs_box(nhp_ctx *ctx, int64_t P, double lower, double upper, do
             NHP_TRY(dot_with_ll(s, s_new, d_q, &dec, &ll));
             fn = -ll;
             if (std::isfinite(fn) && dec < 0.0 && fn <= f + 1e-4 * dec) { accepted = true; break; }
-            if (std::isfinite(fn) && !(dec < 0.0) && nhist > 0) break;     // clipped into an ascent path: not this direction
-            t *= std::isfinite(fn) ? 0.5 : 0.1;
+            t *= std::isfinite(fn) ? 0.5 : 0.1;                 // (a shorter step is clipped in fewer coordinates: g·d < 0 wins in the end)
         }
         if (!accepted) {
             NHP_HIP(ctx, hipMemsetAsync(s_new, 0, 8 * (size_t)P, st));     // the slot multiplies as zeros again
@@ -407,6 +409,7 @@ nhp_status nhp_lbfgs_box(nhp_ctx *ctx, int64_t P, double lower, double upper, do
             qs[head] = qy[head] = 0.0;
             if (nhist == HIST) nhist = HIST - 1;
         }
+        if (trace) fprintf(stderr, "[nhp mle] step %4d f %.9f  decrease %.3e  q.q %.3e  g.d %.3e  t %.3e  pairs %d  s.y %.3e  y.y %.3e\n", steps, fn, f - fn, qq_before, gd, t, nhist, s_y, y_y);
         std::swap(d_x, d_xn); std::swap(d_g, d_gn);
         f = fn; ++steps;
         if (std::fabs(f - minloss) < f_abstol) { converged = true; break; }     // the reference's callback rule

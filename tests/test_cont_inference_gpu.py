@@ -436,9 +436,11 @@ def test_device_mle_with_most_weights_on_the_lower_bound(nhp, orc):
     assert len(data[0]) > 3000
     guess = np.random.default_rng(6).uniform(0.3, 0.9, len(proc.params()))
     ll0 = nhp.loglikelihood(_set(proc, guess), data, recursive=False)
-    dev = nhp.mle_(proc, data, guess=guess, recursive=False, f_abstol=1e-10, max_steps=5000, optimizer="device")
+    # (the θ of a link without weight is a flat direction: scipy's L-BFGS-B needs ~1400 steps from this start, the device's
+    #  eight-pair projected L-BFGS 7-9 thousand -- 0.7 s)
+    dev = nhp.mle_(proc, data, guess=guess, recursive=False, f_abstol=1e-10, max_steps=40000, optimizer="device")
     x = dev.maximizer
-    assert dev.maximum >= ll0 and np.all(x >= 1e-6) and np.all(x <= 10.0)
+    assert dev.status == "success" and dev.maximum >= ll0 and np.all(x >= 1e-6) and np.all(x <= 10.0)
     Wfit = x[N + N * N:].reshape((N, N), order="F")
     on_bound = Wfit == 1e-6
     assert on_bound.sum() >= N * N // 4                             # (24 of the 40 true zeros end exactly on the bound)

@@ -170,6 +170,47 @@ def test_both_sampler_kernels_give_the_oracle_indices(nhp, orc, which, kind, mon
 
 
 
+@pytest.mark.parametrize("network,lgcp", [(False, False), (True, True)])
+def test_slice_sampler_gives_the_oracle_indices(nhp, orc, network, lgcp, monkeypatch):
+    """Logit-normal impulses on a sliced dataset draw their parents one lane per child over the slice planes
+    (k_sampler_slices: rows coalesced, the first 8 or 16 weights of a child kept in LDS for the scan, later ones evaluated
+    again).  Windows from empty to ~60 parents -- well past the cache -- ties and a burst in the data: indices, parent nodes
+    and statistics equal the oracle's and the lane-per-child kernel's (NHP_SAMPLER_SLICES=0), for every (workgroup, cache) shape,
+    with explicit uniforms and with the Philox stream."""
+    c = random_case(9, 7000, 350.0, "logitnormal", 1.2, network=network, lgcp=lgcp, seed=41, nhp=nhp, orc=orc)
+    t = c["times"].copy()
+    t[500:530:2] = t[501:531:2]
+    t[3000:3060] = np.sort(np.random.default_rng(8).uniform(t[3000], t[3000] + 0.9, 60))
+    t = np.sort(t)
+    data = (t, c["nodes"], c["T"])
+    M = len(t)
+    u = np.random.default_rng(17).uniform(size=M)
+    u[::97] = 0.0
+    u[5::89] = np.nextafter(1.0, 0.0)
+    wp, wpn = orc.resample_parents(c["om"], t, c["nodes"], u, flags=orc.MATH_DET)
+    ref = None
+    for cfg in (None, "256,8", "256,16", "512,8", "512,16", "off"):
+        monkeypatch.delenv("NHP_SAMPLER_SLICES", raising=False)
+        monkeypatch.delenv("NHP_SAMPLER_CFG", raising=False)
+        if cfg == "off":
+            monkeypatch.setenv("NHP_SAMPLER_SLICES", "0")
+        elif cfg:
+            monkeypatch.setenv("NHP_SAMPLER_CFG", cfg)
+        p, pn, st = nhp.resample_parents(c["proc"], data, u=u, with_stats=True)
+        assert np.array_equal(p, wp) and np.array_equal(pn, wpn), cfg
+        if ref is None:
+            ref = st
+        else:
+            for k in ("cnt0", "Mn", "Mnm"):
+                assert np.array_equal(st[k], ref[k]), (cfg, k)
+            assert np.array_equal(np.nan_to_num(st["Xnm"]), np.nan_to_num(ref["Xnm"])), cfg
+        p2, pn2 = nhp.resample_parents(c["proc"], data, seed=3, step=9)
+        w2, wn2 = orc.resample_parents(c["om"], t, c["nodes"], orc.uniform_stream(3, 9, M), flags=orc.MATH_DET)
+        assert np.array_equal(p2, w2) and np.array_equal(pn2, wn2), cfg
+    monkeypatch.delenv("NHP_SAMPLER_SLICES", raising=False)
+    monkeypatch.delenv("NHP_SAMPLER_CFG", raising=False)
+
+
 def test_logitnormal_pair_cache_keeps_every_index(nhp, monkeypatch):
     """The logit-normal sampler reads {logit(x), 1/(x(1-x))} made once per pair (k_plq_build) instead of taking the logarithm
     and the division per weight: the same operations in the same order, so parents and statistics are identical with the cache
