@@ -190,8 +190,10 @@ __global__ __launch_bounds__(256) void k_adj_lq(int64_t n, double inv_dtmax, con
 
 // Per sweep: x = W[p,c]·ħ(Δt) for every cached entry of column c (a streaming pass: coalesced reads of
 // {k, p, Δt}, the column of the tables in LDS) and λ_k = λ0 + Σ A[p,c]·x per child.
-template <int IMP>
-__global__ __launch_bounds__(NHP_BLOCK) void k_adj_eval(nhp_cont_args a, const double *__restrict__ A,
+// TH threads per column: the walk is a stream (24 bytes in, 8 out per entry) behind a column staged once, so a column takes as
+// many waves as the CU has room for (512: 76 -> see profiles/README.md)
+template <int IMP, int TH>
+__global__ __launch_bounds__(TH) void k_adj_eval(nhp_cont_args a, const double *__restrict__ A,
                                                         const int64_t *__restrict__ pair_off,
                                                         const int32_t *__restrict__ ent_k, const int32_t *__restrict__ ent_p,
                                                         const double *__restrict__ ent_dt, const double2 *__restrict__ ent_lq,
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_eval(nhp_cont_args a, const d
     double *acol = colw + (IMP == NHP_IMPULSE_EXPONENTIAL ? 0 : N);        // [N] A[·, c]
     double *lam = acol + N;                                                // [max_children] λ_k
     const int kb = a.boff[c], nchild = a.boff[c + 1] - kb;
-    for (int p = tid; p < N; p += NHP_BLOCK) {
+    for (int p = tid; p < N; p += TH) {
         const size_t k = (size_t)p + (size_t)c * N;
         if (IMP == NHP_IMPULSE_EXPONENTIAL) {
             col[p] = make_double2(a.p1[k], a.W[k]);
@@ -227,19 +229,19 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_eval(nhp_cont_args a, const d
         uni_out[k] = nhp_log(uu / (1.0 - uu));
         bias_out[k] = -(a.W[k] * a.cnt[p]) + nhp_log(rho) - nhp_log(1.0 - rho);
     }
-    for (int k = tid; k < nchild; k += NHP_BLOCK) lam[k] = adj_baseline(a, c, a.child[kb + k].t);
+    for (int k = tid; k < nchild; k += TH) lam[k] = adj_baseline(a, c, a.child[kb + k].t);
     __syncthreads();
     const int64_t e0 = pair_off[c], e1 = pair_off[c + 1];
     // four entries per thread and trip: their loads are in flight together and the four pdf evaluations are independent
     // instruction streams (the one-entry loop exposed one global-load latency per entry)
     constexpr int EU = 4;
-    for (int64_t eb = e0 + tid; eb < e1; eb += EU * NHP_BLOCK) {
+    for (int64_t eb = e0 + tid; eb < e1; eb += EU * TH) {
         int p[EU], k[EU];
         double dt[EU], x[EU];
         double2 lq[EU];
 #pragma unroll
         for (int u = 0; u < EU; ++u) {
-            const int64_t e = eb + u * NHP_BLOCK < e1 ? eb + u * NHP_BLOCK : eb;       // clamped: value unused
+            const int64_t e = eb + u * TH < e1 ? eb + u * TH : eb;       // clamped: value unused
             p[u] = ent_p[e]; k[u] = ent_k[e];
             if (IMP == NHP_IMPULSE_EXPONENTIAL) dt[u] = ent_dt[e];
             else lq[u] = ent_lq[e];                                  // {logit(x), 1/(x(1-x))}: the logarithm and the division are data
@@ -254,8 +256,8 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_eval(nhp_cont_args a, const d
         }
 #pragma unroll
         for (int u = 0; u < EU; ++u) {
-            if (eb + u * NHP_BLOCK < e1) {
-                const int64_t e = eb + u * NHP_BLOCK;
+            if (eb + u * TH < e1) {
+                const int64_t e = eb + u * TH;
                 // the first entry of a run of repeats carries the run's total, summed in list order (k_adj_build); the
                 // repeats themselves (child -1) are dead
                 for (int r = 1; r <= run[u]; ++r) {
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_adj_eval(nhp_cont_args a, const d
         }
     }
     __syncthreads();
-    for (int k = tid; k < nchild; k += NHP_BLOCK) lam_g[kb + k] = lam[k];
+    for (int k = tid; k < nchild; k += TH) lam_g[kb + k] = lam[k];
 }
 
 __device__ __forceinline__ float adj_dpp_add_f32(float v, const int sel)
@@ -584,12 +586,18 @@ nhp_status nhp_adj_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_mo
     const int32_t *d_k = ds->d_adj_k, *d_start = ds->d_adj_start;
     double *d_x = (double *)(base + o_x), *d_lam = (double *)(base + o_lam);
     double *d_uni = (double *)(base + o_uni), *d_bias = (double *)(base + o_bias);
+    static const int eval_threads = getenv("NHP_ADJ_EVAL_THREADS") ? atoi(getenv("NHP_ADJ_EVAL_THREADS")) : 512;
+#define NHP_AEVAL(imp, th, lqp)                                                                                        \
+    do {                                                                                                               \
+        if (lds_eval > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_eval<imp, th>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval)); \
+        hipLaunchKernelGGL((k_adj_eval<imp, th>), dim3(ncol), dim3(th), lds_eval, st, a, m->d_A, d_off, d_k, ds->d_adj_p, ds->d_adj_dt, lqp, d_x, \
+                           max_children, d_lam, d_rho, rho, d_rho_scalar, d_u, seed, step, d_uni, d_bias);            \
+    } while (0)
     if (expo) {
-        if (lds_eval > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_eval<NHP_IMPULSE_EXPONENTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval));
-        hipLaunchKernelGGL((k_adj_eval<NHP_IMPULSE_EXPONENTIAL>), dim3(ncol), dim3(NHP_BLOCK), lds_eval, st, a, m->d_A,
-                           d_off, d_k, ds->d_adj_p, ds->d_adj_dt, (const double2 *)nullptr, d_x, max_children, d_lam, d_rho, rho, d_rho_scalar, d_u, seed, step, d_uni, d_bias);
+        if (eval_threads == 256) NHP_AEVAL(NHP_IMPULSE_EXPONENTIAL, 256, (const double2 *)nullptr);
+        else if (eval_threads == 1024) NHP_AEVAL(NHP_IMPULSE_EXPONENTIAL, 1024, (const double2 *)nullptr);
+        else NHP_AEVAL(NHP_IMPULSE_EXPONENTIAL, 512, (const double2 *)nullptr);
     } else {
-        if (lds_eval > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_eval<NHP_IMPULSE_LOGITNORMAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval));
         if (!ds->d_adj_lq) {                                         // first logit-normal sweep on this dataset: the data half of the pdf
             nhp_cont_dataset *mds = const_cast<nhp_cont_dataset *>(ds);
             if (hipMalloc((void **)&mds->d_adj_lq, 16 * P) != hipSuccess) {
@@ -599,9 +607,11 @@ nhp_status nhp_adj_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_cont_mo
             }
             hipLaunchKernelGGL(k_adj_lq, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, (int64_t)ds->pairs, a.inv_dtmax, ds->d_adj_dt, mds->d_adj_lq);
         }
-        hipLaunchKernelGGL((k_adj_eval<NHP_IMPULSE_LOGITNORMAL>), dim3(ncol), dim3(NHP_BLOCK), lds_eval, st, a, m->d_A,
-                           d_off, d_k, ds->d_adj_p, ds->d_adj_dt, ds->d_adj_lq, d_x, max_children, d_lam, d_rho, rho, d_rho_scalar, d_u, seed, step, d_uni, d_bias);
+        if (eval_threads == 256) NHP_AEVAL(NHP_IMPULSE_LOGITNORMAL, 256, (const double2 *)ds->d_adj_lq);
+        else if (eval_threads == 1024) NHP_AEVAL(NHP_IMPULSE_LOGITNORMAL, 1024, (const double2 *)ds->d_adj_lq);
+        else NHP_AEVAL(NHP_IMPULSE_LOGITNORMAL, 512, (const double2 *)ds->d_adj_lq);
     }
+#undef NHP_AEVAL
     NHP_HIP(ctx, hipGetLastError());
     if (lds_sweep > 64 * 1024) NHP_HIP(ctx, hipFuncSetAttribute((const void *)k_adj_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sweep));
     hipLaunchKernelGGL(k_adj_sweep, dim3(ncol), dim3(64), lds_sweep, st, a, m->d_A, d_off, d_k, d_x, d_start, ds->d_adj_group, d_lam,
