@@ -15,6 +15,8 @@
 // scales by the column's constants and adds the column into the gradient.
 // Recursive form: the column-state recursion of cont_recursive.hip, extended with the
 // derivative state R_pc(t) = Σ_j (t - t_j) e^{-θ(t - t_j)}:  ∂λ/∂θ[p,c] = a·w·(S - θR).
+#include <algorithm>
+
 #include "nhp_internal.h"
 #include "nhp_math.h"
 
@@ -98,13 +100,15 @@ __global__ __launch_bounds__(256) void k_grad_init(nhp_cont_args a, int mask_int
     }
 }
 
-template <int IMP, int G>
-__global__ __launch_bounds__(NHP_BLOCK) void k_grad_windowed(nhp_cont_args a, const double *__restrict__ lambda,
+// TH threads per item: the pass is two LDS atomics and one exponential per pair behind a column staged once; at long windows
+// (the recursive objective's truncated window: 300-600 pairs per event) a column keeps 512 threads busy.
+template <int IMP, int G, int TH>
+__global__ __launch_bounds__(TH) void k_grad_windowed(nhp_cont_args a, const double *__restrict__ lambda,
                                                              double *__restrict__ grad)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     double *red = reinterpret_cast<double *>(smem);
-    double2 *col = reinterpret_cast<double2 *>(smem + 32);       // exp {θ, -θ·64/ln 2}; logit {μ, sqrt τ}
+    double2 *col = reinterpret_cast<double2 *>(smem + 64);       // exp {θ, -θ·64/ln 2}; logit {μ, sqrt τ}
     double *accH = reinterpret_cast<double *>(col + a.N);        // Σ g·ħ
     double *acc1 = accH + a.N;                                   // Σ g·∂ħ/∂θ  |  Σ g·ħ·sqrtτ·z
     double *acc2 = acc1 + a.N;                                   // logit: Σ g·ħ·(1 - z²)
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_grad_windowed(nhp_cont_args a, co
 
     const nhp_item it = a.items[blockIdx.x];
     const int c = it.node, N = a.N, tid = threadIdx.x;
-    for (int p = tid; p < N; p += NHP_BLOCK) {
+    for (int p = tid; p < N; p += TH) {
         const size_t k = (size_t)p + (size_t)c * N;
         if (IMP == NHP_IMPULSE_EXPONENTIAL) col[p] = make_double2(a.p1[k], -(a.p1[k] * 92.33248261689366));
         else col[p] = make_double2(a.p1[k], __builtin_sqrt(a.p2[k]));
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_grad_windowed(nhp_cont_args a, co
     }
     __syncthreads();
 
-    constexpr int GROUPS = NHP_BLOCK / G;
+    constexpr int GROUPS = TH / G;
     const int gid = tid / G, gl = tid % G;
     double gsum = 0.0;
     for (int k = it.kbeg + gid; k < it.kend; k += GROUPS) {
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_grad_windowed(nhp_cont_args a, co
     __syncthreads();
     const size_t Nn = grad_nbase(a), NN = (size_t)N * (size_t)N;      // Nn: offset of the impulse block
     const size_t nimp = IMP == NHP_IMPULSE_EXPONENTIAL ? NN : 2 * NN;
-    for (int p = tid; p < N; p += NHP_BLOCK) {
+    for (int p = tid; p < N; p += TH) {
         const size_t k = (size_t)p + (size_t)c * N;
         const double av = a.A ? a.A[k] : 1.0;
         const double aw = av * a.W[k];
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(NHP_BLOCK) void k_grad_windowed(nhp_cont_args a, co
             if (acc2[p] != 0.0) atomicAdd(&grad[Nn + NN + k], aw * (0.5 / a.p2[k]) * acc2[p]);
         }
     }
-    const double gs = nhp_block_sum(gsum, red);
+    const double gs = nhp_block_sum_n<TH / 64>(gsum, red);
     if (tid == 0 && gs != 0.0 && a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) atomicAdd(&grad[c], gs);
 }
 
@@ -381,22 +385,22 @@ __global__ __launch_bounds__(64 * H) void k_grad_recursive_waves(nhp_cont_args a
     if (tid == 0 && a.baseline_kind == NHP_BASELINE_HOMOGENEOUS) grad[c] = -a.duration + gsum;
 }
 
-template <int IMP>
+template <int IMP, int TH>
 static void launch_grad_group(int G, dim3 grid, size_t lds, hipStream_t st, const nhp_cont_args &a,
                               const double *lambda, double *grad)
 {
 #define NHP_CASE(g)                                                                                      \
     case g:                                                                                              \
         if (lds > 64 * 1024)                                                                             \
-            (void)hipFuncSetAttribute((const void *)k_grad_windowed<IMP, g>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_grad_windowed<IMP, g>), grid, dim3(NHP_BLOCK), lds, st, a, lambda, grad);  \
+            (void)hipFuncSetAttribute((const void *)k_grad_windowed<IMP, g, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_grad_windowed<IMP, g, TH>), grid, dim3(TH), lds, st, a, lambda, grad);     \
         break;
     switch (G) {
         NHP_CASE(1) NHP_CASE(2) NHP_CASE(4) NHP_CASE(8) NHP_CASE(16) NHP_CASE(32)
     default:
         if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void *)k_grad_windowed<IMP, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_grad_windowed<IMP, 64>), grid, dim3(NHP_BLOCK), lds, st, a, lambda, grad);
+            (void)hipFuncSetAttribute((const void *)k_grad_windowed<IMP, 64, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_grad_windowed<IMP, 64, TH>), grid, dim3(TH), lds, st, a, lambda, grad);
     }
 #undef NHP_CASE
 }
@@ -491,11 +495,17 @@ nhp_status nhp_grad_enqueue(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_
         NHP_HIP(ctx, hipGetLastError());
         NHP_TRY(nhp_launch_event_intensity_as(ctx, ds, m, child_cut, G, mask, d_lambda));   // pass A: partials + λ_i
         NHP_TRY(nhp_launch_finalize(ctx, a, ds->n_items, ctx->d_results));
-        const size_t lds = 32 + 16 * N + 8 * N * (exp_imp ? 2 : 3) + (exp_imp ? 512 : 0);     // + the exponential's 2^(j/64) table
+        const size_t lds = 64 + 16 * N + 8 * N * (exp_imp ? 2 : 3) + (exp_imp ? 512 : 0);     // + the exponential's 2^(j/64) table
         if (lds > 160 * 1024) { nhp_set_error(ctx, "gradient: n_nodes = %d exceeds the 160 KiB LDS budget", ds->N); return NHP_ENOTIMPL; }
         dim3 grid((unsigned)ds->n_items);
-        if (exp_imp) launch_grad_group<NHP_IMPULSE_EXPONENTIAL>(G, grid, lds, st, a, d_lambda, d_grad);
-        else launch_grad_group<NHP_IMPULSE_LOGITNORMAL>(G, grid, lds, st, a, d_lambda, d_grad);
+        // threads per item: 512 where an item has the pairs for them (NHP_GRAD_THREADS overrides)
+        const double pairs_per_item = (double)(child_cut ? ds->cut_pairs : ds->pairs) / (double)std::max(1, ds->n_items);
+        static const int forced = getenv("NHP_GRAD_THREADS") ? atoi(getenv("NHP_GRAD_THREADS")) : 0;
+        const int TH = forced == 256 || forced == 512 ? forced : (pairs_per_item >= 4096.0 ? 512 : 256);
+        if (exp_imp && TH == 512) launch_grad_group<NHP_IMPULSE_EXPONENTIAL, 512>(G, grid, lds, st, a, d_lambda, d_grad);
+        else if (exp_imp) launch_grad_group<NHP_IMPULSE_EXPONENTIAL, 256>(G, grid, lds, st, a, d_lambda, d_grad);
+        else if (TH == 512) launch_grad_group<NHP_IMPULSE_LOGITNORMAL, 512>(G, grid, lds, st, a, d_lambda, d_grad);
+        else launch_grad_group<NHP_IMPULSE_LOGITNORMAL, 256>(G, grid, lds, st, a, d_lambda, d_grad);
         NHP_HIP(ctx, hipGetLastError());
     }
     return NHP_OK;
