@@ -23,7 +23,10 @@
 
 namespace {
 
-constexpr int HIST = 8;               // limited-memory pairs
+#ifndef NHP_LBFGS_HIST
+#define NHP_LBFGS_HIST 8       // (variant builds: tools/dbg/mlesparse.py measured 4 / 8 / 16 pairs alike on a sparse fit)
+#endif
+constexpr int HIST = NHP_LBFGS_HIST;  // limited-memory pairs
 constexpr int NB = 2 * HIST;          // stored vectors: s_0..s_{HIST-1}, y_0..y_{HIST-1} (contiguous)
 constexpr int NACC = 3 * NB + 6;      // u·b_j, v·b_j, w·b_j (NB each), then u·u, v·v, w·w, u·v, u·w, v·w
 constexpr int RBLK = 512;             // workgroups of a reduction

@@ -9,7 +9,7 @@ import __graft_entry__ as entry
 nhp = entry.load_package()
 N, T = 8, 600.0
 rng = np.random.default_rng(12)
-W = rng.uniform(0.1, 0.4, (N, N)) * (rng.uniform(size=(N, N)) < 0.25)
+W = rng.uniform(0.1, 0.4, (N, N)) * (rng.uniform(size=(N, N)) < float(os.environ.get("LINKS", 0.25))) * float(os.environ.get("WSCALE", 1.0))
 proc = nhp.ContinuousStandardHawkesProcess(nhp.HomogeneousProcess(rng.uniform(0.5, 1.0, N)),
                                            nhp.ExponentialImpulseResponse(rng.uniform(2.0, 4.0, (N, N)), 1.0, 1.0, 2.0),
                                            nhp.DenseWeightModel(W))
