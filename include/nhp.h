@@ -268,6 +268,11 @@ nhp_status nhp_probe_gather(nhp_ctx *ctx, int32_t n_windows, int32_t recs, int64
  * (launched back to back: below 256 MB the Infinity Cache serves it, as it does the repeated log-likelihood) */
 nhp_status nhp_probe_stream(nhp_ctx *ctx, int32_t mode, int64_t bytes, int32_t blocks, int32_t threads, double *us_per_launch,
                             int64_t *bytes_read /* nullable: what a launch really reads (whole rows per wave) */);
+/* the mle! optimizer alone (csrc/nhp_lbfgs.h: the projected L-BFGS both nhp_cont_mle_run and nhp_disc_mle_run drive) on the
+ * separable quadratic f(x) = 1/2 sum_i h[i] (x[i] - c[i])^2 over the box [lower, upper]^n, host vectors h, c and x (start in,
+ * minimiser out): step counts that can be held against another L-BFGS without a likelihood in between */
+nhp_status nhp_probe_lbfgs(nhp_ctx *ctx, int64_t n, const double *h, const double *c, double lower, double upper, double f_abstol,
+                           int32_t max_steps, double *x, double *loss, int32_t *steps, int32_t *converged, int32_t *evaluations);
 
 /* ---- discrete data: N x T counts  src/discrete.jl:18,80 -------------------------------- */
 nhp_status nhp_disc_dataset_create(nhp_ctx *ctx, const int64_t *data, int32_t n_nodes, int64_t n_bins,

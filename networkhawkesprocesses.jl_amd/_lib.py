@@ -121,6 +121,7 @@ def _declare(lib):
     f("nhp_probe_rate", i32, _vp, i32, i32, i32, _dp)
     f("nhp_probe_gather", i32, _vp, i32, i32, i64, i32, _dp)
     f("nhp_probe_stream", i32, _vp, i32, i64, i32, i32, _dp, C.POINTER(C.c_int64))
+    f("nhp_probe_lbfgs", i32, _vp, i64, _dp, _dp, dbl, dbl, dbl, i32, _dp, _dp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32))
     for name, args in (
         ("nhp_cont_loglik_grad", (_vp, _vp, _vp, i32, _dp, _dp, i64)),
         ("nhp_cont_intensity", (_vp, _vp, _vp, _dp, i64, _dp)),

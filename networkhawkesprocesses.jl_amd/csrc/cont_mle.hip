@@ -52,3 +52,52 @@ extern "C" nhp_status nhp_cont_mle_run(nhp_ctx *ctx, nhp_comm *comm, const nhp_c
     };
     return nhp_lbfgs_box(ctx, P, lower, upper, f_abstol, max_steps, eval, x, loss, steps_out, converged_out, evals_out);
 }
+
+// ---- diagnostics: the optimizer alone on a separable quadratic (tools/dbg/lbfgsquad.py) ------------------------------------
+// f(x) = ½ Σ h_i (x_i - c_i)² on the box: the iteration counts of nhp_lbfgs_box can be held against scipy's L-BFGS-B without
+// a likelihood in between.
+__global__ __launch_bounds__(256) void k_probe_quad(const double *__restrict__ x, const double *__restrict__ h, const double *__restrict__ c,
+                                                    int64_t n, double *__restrict__ g, double *__restrict__ part)
+{
+    __shared__ double red[NHP_WAVES];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double d = x[i] - c[i];
+        g[i] = h[i] * d;
+        acc += 0.5 * h[i] * d * d;
+    }
+    acc = nhp_block_sum_n<NHP_WAVES>(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(64) void k_probe_quad_final(const double *__restrict__ part, int nblk, double *__restrict__ out)
+{
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int b = 0; b < nblk; ++b) t += part[b];
+        *out = -t;                                                  // the framework maximises "ll" = -f
+    }
+}
+
+extern "C" nhp_status nhp_probe_lbfgs(nhp_ctx *ctx, int64_t n, const double *h, const double *c, double lower, double upper, double f_abstol,
+                                      int32_t max_steps, double *x, double *loss, int32_t *steps_out, int32_t *converged_out, int32_t *evals_out)
+{
+    if (!ctx || n < 1 || !h || !c || !x || !loss || !steps_out || !converged_out) return NHP_EINVAL;
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    double *d_h = nullptr;
+    const int nblk = 64;
+    if (hipMalloc((void **)&d_h, 8 * (2 * (size_t)n + nblk)) != hipSuccess) return NHP_ENOMEM;
+    double *d_c = d_h + n, *d_part = d_c + n;
+    NHP_HIP(ctx, hipMemcpyAsync(d_h, h, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    NHP_HIP(ctx, hipMemcpyAsync(d_c, c, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    auto eval = [&](const double *d_x, double *d_g, bool) -> nhp_status {
+        hipLaunchKernelGGL(k_probe_quad, dim3(nblk), dim3(256), 0, ctx->stream, d_x, (const double *)d_h, (const double *)d_c, n, d_g, d_part);
+        hipLaunchKernelGGL(k_probe_quad_final, dim3(1), dim3(64), 0, ctx->stream, (const double *)d_part, nblk, ctx->d_results);
+        NHP_HIP(ctx, hipGetLastError());
+        return NHP_OK;
+    };
+    const nhp_status rc = nhp_lbfgs_box(ctx, n, lower, upper, f_abstol, max_steps, eval, x, loss, steps_out, converged_out, evals_out);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_h);
+    return rc;
+}

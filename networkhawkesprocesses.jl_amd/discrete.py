@@ -456,8 +456,11 @@ def disc_mle_(process, data, optimizer="L-BFGS-B", verbose=False, f_abstol=1e-6,
             raise StopIteration
         state["minloss"] = value
 
+    options = {"maxiter": max_steps}
+    if optimizer == "L-BFGS-B":       # scipy's own relative-decrease test off, as in inference.mle_ (Optim's g_tol = 1e-8 kept)
+        options.update(ftol=0.0, gtol=1e-8, maxfun=20 * max_steps + 1000)
     res = optimize.minimize(fg, np.clip(x0, lower, upper), jac=True, method=optimizer,
-                            bounds=[(lower, upper)] * len(x0), callback=status_update, options={"maxiter": max_steps})
+                            bounds=[(lower, upper)] * len(x0), callback=status_update, options=options)
     disc_params_(process, res.x)
     return MaximumLikelihood(res.x.copy(), -float(res.fun), state["steps"], time.time() - start,
                              "success" if (state["converged"] or res.success) else "failure")

@@ -166,9 +166,14 @@ def mle_(process, data, optimizer="L-BFGS-B", verbose=False, f_abstol=1e-6, regu
             raise StopIteration
         state["minloss"] = value
 
+    options = {"maxiter": max_steps}
+    if optimizer == "L-BFGS-B":
+        # scipy's own tests would end the run long before the reference's rule does (its default is a RELATIVE decrease of
+        # 2.2e-9, i.e. 2e-5 at |f| ~ 1e4): off, but for Optim's default gradient tolerance (g_tol = 1e-8)
+        options.update(ftol=0.0, gtol=1e-8, maxfun=20 * max_steps + 1000)
     res = optimize.minimize(fg, np.clip(x0, lower, upper), jac=True, method=optimizer,
                             bounds=[(lower, upper)] * len(x0), callback=status_update,
-                            options={"maxiter": max_steps})
+                            options=options)
     process.params_(res.x)
     return MaximumLikelihood(res.x.copy(), -float(res.fun), state["steps"], time.time() - start,
                              "success" if (state["converged"] or res.success) else "failure")

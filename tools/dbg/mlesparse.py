@@ -25,3 +25,11 @@ if os.environ.get("HOST"):
     t0 = time.time()
     host = nhp.mle_(proc, data, guess=guess, recursive=False, f_abstol=1e-10, max_steps=5000)
     print(f"host optimizer from the same start: {host.maximum:.6f} in {host.steps} steps ({host.status}), {time.time() - t0:.1f} s")
+    # scipy's own tests off (its defaults stop at a RELATIVE decrease of 2.2e-9 or a projected gradient of 1e-5, long before
+    # |f_k - f_{k-1}| < 1e-10 at |f| ~ 1e4): the same stopping rule as the device optimizer
+    from scipy import optimize
+    plain = optimize.minimize
+    optimize.minimize = lambda *a, **k: plain(*a, **{**k, "options": {**k.get("options", {}), "ftol": 0.0, "gtol": 0.0, "maxcor": 8, "maxfun": 10**6}})
+    t0 = time.time()
+    host = nhp.mle_(proc, data, guess=guess, recursive=False, f_abstol=1e-10, max_steps=20000)
+    print(f"host optimizer, its own tests off (m = 8): {host.maximum:.6f} in {host.steps} steps ({host.status}), {time.time() - t0:.1f} s")
