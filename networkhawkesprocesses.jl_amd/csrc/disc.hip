@@ -778,24 +778,48 @@ extern "C" nhp_status nhp_disc_dataset_create(nhp_ctx *ctx, const int64_t *data,
     }
     NHP_HIP(ctx, hipMemcpyAsync(d_raw, data, 8 * NT, hipMemcpyHostToDevice, st));
     int64_t vmax = 0, vmin = 0;
-    {   // occupied bins, time-major (data is N x T column-major: this is its memory order)
-        std::vector<int32_t> ot, oc, off((size_t)((T + NHP_DA_TT - 1) / NHP_DA_TT) + 1, 0);
+    {   // occupied bins by span of the time axis, within a span by (node, bin); data is N x T column-major
+        const int64_t want = 2 * (int64_t)ctx->cu_count, least = (T + NHP_DA_SPAN - 1) / NHP_DA_SPAN;
+        int64_t nsp = std::max<int64_t>(std::min<int64_t>(want, T), least);
+        if (const char *es = getenv("NHP_DADJ_SPANS")) { const int64_t v = atoll(es); if (v >= least && v <= T) nsp = v; }
+        std::vector<int32_t> ot, oc, off((size_t)nsp + 1, 0), spt((size_t)nsp + 1, 0);
         std::vector<double> os;
-        for (int64_t t = 0; t < T; ++t) {
-            if (t % NHP_DA_TT == 0) off[(size_t)(t / NHP_DA_TT)] = (int32_t)ot.size();
-            for (int32_t n = 0; n < N; ++n) {
-                const int64_t v = data[(size_t)n + (size_t)t * N];
-                if (v > 0) { ot.push_back((int32_t)t); oc.push_back(n); os.push_back((double)v); }
-                if (v > vmax) vmax = v;
-                if (v < vmin) vmin = v;
+        std::vector<int32_t> st_, sc_, cnt((size_t)N + 1);
+        std::vector<double> ss_;
+        int64_t nocc = 0;
+        for (int64_t k = 0; k < nsp; ++k) {
+            const int64_t ta = k * T / nsp, tb = (k + 1) * T / nsp;              // (tb - ta <= ceil(T / nsp) <= NHP_DA_SPAN)
+            spt[(size_t)k] = (int32_t)ta;
+            off[(size_t)k] = (int32_t)ot.size();
+            st_.clear(); sc_.clear(); ss_.clear();
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (int64_t t = ta; t < tb; ++t)
+                for (int32_t n = 0; n < N; ++n) {
+                    const int64_t v = data[(size_t)n + (size_t)t * N];
+                    if (v > 0) { st_.push_back((int32_t)t); sc_.push_back(n); ss_.push_back((double)v); ++cnt[(size_t)n + 1]; }
+                    if (v > vmax) vmax = v;
+                    if (v < vmin) vmin = v;
+                }
+            for (int32_t n = 0; n < N; ++n) cnt[(size_t)n + 1] += cnt[(size_t)n];
+            const size_t base = ot.size(), m = st_.size(), mp = (m + 3) / 4 * 4;
+            ot.resize(base + mp, (int32_t)ta); oc.resize(base + mp, 0); os.resize(base + mp, 0.0);      // (padding: bin ta, node 0, count 0)
+            for (size_t i = 0; i < m; ++i) {                                       // stable by node: bins stay ascending
+                const size_t d = base + (size_t)cnt[(size_t)sc_[i]]++;
+                ot[d] = st_[i]; oc[d] = sc_[i]; os[d] = ss_[i];
             }
+            nocc += (int64_t)m;
+            if (ot.size() >= ((size_t)1 << 31)) break;
         }
-        off.back() = (int32_t)ot.size();
-        ds->nocc = (int64_t)ot.size();
-        if (ds->nocc >= ((int64_t)1 << 31)) { (void)hipFree(d_raw); nhp_set_error(ctx, "too many occupied bins"); nhp_disc_dataset_destroy(ds); return NHP_ENOTIMPL; }
-        const size_t no = ot.size() ? ot.size() : 1;
+        off[(size_t)nsp] = (int32_t)ot.size();
+        spt[(size_t)nsp] = (int32_t)T;
+        ds->nocc = nocc;
+        ds->nocc_pad = (int64_t)ot.size();
+        ds->da_nspans = (int32_t)nsp;
+        if (ot.size() >= ((size_t)1 << 31)) { (void)hipFree(d_raw); nhp_set_error(ctx, "too many occupied bins"); nhp_disc_dataset_destroy(ds); return NHP_ENOTIMPL; }
+        const size_t no = ot.size() ? ot.size() : 4;
         if (hipMalloc(&ds->d_occ_t, 4 * no) != hipSuccess || hipMalloc(&ds->d_occ_c, 4 * no) != hipSuccess ||
-            hipMalloc(&ds->d_occ_s, 8 * no) != hipSuccess || hipMalloc(&ds->d_occ_off, 4 * off.size()) != hipSuccess) {
+            hipMalloc(&ds->d_occ_s, 8 * no) != hipSuccess || hipMalloc(&ds->d_occ_off, 4 * off.size()) != hipSuccess ||
+            hipMalloc(&ds->d_span_t, 4 * spt.size()) != hipSuccess) {
             (void)hipFree(d_raw); nhp_set_error(ctx, "out of device memory (occupied-bin list)"); nhp_disc_dataset_destroy(ds); return NHP_ENOMEM;
         }
         if (!ot.empty()) {
@@ -804,6 +828,18 @@ extern "C" nhp_status nhp_disc_dataset_create(nhp_ctx *ctx, const int64_t *data,
             NHP_HIP(ctx, hipMemcpy(ds->d_occ_s, os.data(), 8 * os.size(), hipMemcpyHostToDevice));
         }
         NHP_HIP(ctx, hipMemcpy(ds->d_occ_off, off.data(), 4 * off.size(), hipMemcpyHostToDevice));
+        NHP_HIP(ctx, hipMemcpy(ds->d_span_t, spt.data(), 4 * spt.size(), hipMemcpyHostToDevice));
+        // the adjacency sweep's entry word: node (16 bits) | count (8 bits) | bin % 256 (a span is at most 256 bins)
+        static_assert(NHP_DA_SPAN == 256, "the packed entry keeps 8 bits of the bin");
+        if (N <= 65536 && vmax < 256 && !ot.empty() && hipMalloc((void **)&ds->d_occ_pack, 4 * no) == hipSuccess) {
+            std::vector<uint32_t> pk(ot.size());
+            for (size_t i = 0; i < ot.size(); ++i)
+                pk[i] = ((uint32_t)oc[i] << 16) | ((uint32_t)os[i] << 8) | (uint32_t)(ot[i] % NHP_DA_SPAN);
+            NHP_HIP(ctx, hipMemcpy(ds->d_occ_pack, pk.data(), 4 * pk.size(), hipMemcpyHostToDevice));
+        } else {
+            (void)hipGetLastError();
+            ds->d_occ_pack = nullptr;
+        }
     }
     // counts that fit a byte are kept in bytes too: the convolution then reads 1/8 of the bytes next to its 3.3 GB of stores
     if (vmin >= 0 && vmax <= 255 && hipMalloc((void **)&ds->d_data8, NT) != hipSuccess) ds->d_data8 = nullptr;
@@ -830,7 +866,7 @@ extern "C" void nhp_disc_dataset_destroy(nhp_disc_dataset *ds)
     (void)hipSetDevice(ds->ctx->device);
     (void)hipStreamSynchronize(ds->ctx->stream);
     (void)hipFree(ds->d_dataT); (void)hipFree(ds->d_data8); (void)hipFree(ds->d_conv); (void)hipFree(ds->d_colsum);
-    (void)hipFree(ds->d_occ_t); (void)hipFree(ds->d_occ_c); (void)hipFree(ds->d_occ_s); (void)hipFree(ds->d_occ_off);
+    (void)hipFree(ds->d_occ_t); (void)hipFree(ds->d_occ_c); (void)hipFree(ds->d_occ_s); (void)hipFree(ds->d_occ_off); (void)hipFree(ds->d_occ_pack); (void)hipFree(ds->d_span_t);
     (void)hipFree(ds->d_convsum); (void)hipFree(ds->d_baseT); (void)hipFree(ds->d_base_counts);
     delete ds;
 }

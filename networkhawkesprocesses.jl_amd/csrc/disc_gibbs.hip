@@ -327,112 +327,336 @@ extern "C" nhp_status nhp_disc_gibbs_step(nhp_ctx *ctx, const nhp_disc_dataset *
 //     x_t = W[p,c] dt Σ_b Ŝ[t,p,b] θ[p,c,b],   λ⁰ = the intensity with A[p,c] = 0,
 // where only OCCUPIED bins need a log and Σ_t x_t = Σ_b (W θ dt)[p,c,b] · Σ_t Ŝ[t,p,b] uses per-dataset column
 // sums.  Columns are independent, entries of a column sequential in p -- so the sweep is N steps, each over
-// all occupied bins of all columns at once: k_dadj_accum (time-tiled: the Ŝ[·, p, ·] slice of the tile sits
-// in LDS, each lane owns occupied bins, per-column sums collect in LDS and leave as one row of partials per
-// tile) then k_dadj_decide (adds the tiles in fixed order, draws A[p, ·], and prepares step p+1).  λ of the
-// occupied bins is carried incrementally.
+// all occupied bins of all columns at once, ONE launch per step (k_dadj_step).  λ of the occupied bins is carried
+// incrementally.
+//
+// Round 3 (PMC pass on the two-kernel step of round 2, profiles/r03_pmc/dadj_accum_counters.txt: three waves per SIMD, each
+// waiting 80 % of its life on a chain of dependent loads -- entry -> dprev[c], V[c,·] out of L2 at ~220 cycles a request ->
+// arithmetic -- 13 entries a thread one after the other; then 16.5 µs of a 16-workgroup reduction kernel):
+//  * what does not depend on the decisions is tabulated once per sweep (k_dadj_tables): V[p][c][·] = W θ dt row-major in p,
+//    A's rows, logit(u) and the two logarithms of ρ;
+//  * a workgroup takes a span of whole DA_TT tiles (<= 256 bins; the grid is one balanced round of two workgroups per CU);
+//    row p of V, A's row and dprev sit in LDS next to the Ŝ span, an entry is one coalesced 4 + 8-byte read and LDS;
+//  * x of the previous step is recomputed for the columns that flipped instead of being stored and re-read for all
+//    (the Ŝ span of p - 1 is staged only when a flip happened);
+//  * the decision is the tail of the same launch: per-workgroup rows of partial sums -> the last workgroup of each group of
+//    NHP_DA_GROUP adds its group's rows -> the last group adds the group rows and draws A[p, ·] (a fixed summation tree;
+//    every row of a batch is requested before the first is used: a serial `sum += load` is one L2 round trip per row).
 __global__ __launch_bounds__(256) void k_dadj_gather(const double *__restrict__ lam, const int32_t *__restrict__ occ_t,
                                                      const int32_t *__restrict__ occ_c, int64_t nocc, int64_t T,
-                                                     double *__restrict__ lam_occ, double *__restrict__ xprev)
+                                                     double *__restrict__ lam_occ)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < nocc) { lam_occ[i] = lam[(size_t)occ_t[i] + (size_t)T * occ_c[i]]; xprev[i] = 0.0; }
+    if (i < nocc) lam_occ[i] = lam[(size_t)occ_t[i] + (size_t)T * occ_c[i]];
 }
 
-// V[c*B + b] = W[p,c] θ[p,c,b] dt,  a_p[c] = A[p,c]   (row p of the tables, gathered once per step)
-__device__ __forceinline__ void dadj_prep_row(int p, int c, int N, int B, double dt, const double *W, const double *theta,
-                                              const double *A, double *V, double *a_p)
+// Vall[p][c*B + b] = W[p,c] θ[p,c,b] dt,  AT[p][c] = A[p,c],  LU[p][c] = logit(u[p,c]),  LR1 / LR2 = log ρ, log(1 - ρ)
+__global__ __launch_bounds__(256) void k_dadj_tables(int N, int B, double dt, const double *__restrict__ W, const double *__restrict__ theta,
+                                                     const double *__restrict__ A, const double *__restrict__ rho_mat, double rho_scalar,
+                                                     const double *__restrict__ u, uint64_t seed, uint64_t step, double *__restrict__ Vall,
+                                                     double *__restrict__ AT, double *__restrict__ LU, double *__restrict__ LR1,
+                                                     double *__restrict__ LR2)
 {
-    const size_t pc = (size_t)p + (size_t)c * N;
-    for (int b = 0; b < B; ++b) V[(size_t)c * B + b] = (W[pc] * theta[pc + (size_t)b * N * N]) * dt;
-    a_p[c] = A[pc];
+    // a 16 x 16 patch of (p, c) per workgroup: reads run along p (the tables are column-major), writes along c
+    __shared__ double tw[16][17], ta[16][17], tu[16][17], t1[16][17], t2[16][17];
+    const int lp = threadIdx.x & 15, lc = threadIdx.x >> 4;
+    const int p0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
+    const size_t NN = (size_t)N * N;
+    {
+        const int p = p0 + lp, c = c0 + lc;
+        if (p < N && c < N) {
+            const size_t pc = (size_t)p + (size_t)c * N;
+            const double rho = rho_mat ? rho_mat[pc] : rho_scalar;
+            const double uu = u ? u[pc] : nhp_philox_uniform(seed ^ 0xAD7AC3117D15C0DEull, step, pc);
+            tw[lc][lp] = W[pc]; ta[lc][lp] = A[pc];
+            tu[lc][lp] = nhp_log(uu / (1.0 - uu)); t1[lc][lp] = nhp_log(rho); t2[lc][lp] = nhp_log(1.0 - rho);
+        }
+    }
+    __syncthreads();
+    const int wp = threadIdx.x >> 4, wc = threadIdx.x & 15;      // now lanes run along c
+    const int p = p0 + wp, c = c0 + wc;
+    if (p >= N || c >= N) return;
+    const size_t row = (size_t)p * N + c, pc = (size_t)p + (size_t)c * N;
+    AT[row] = ta[wc][wp]; LU[row] = tu[wc][wp]; LR1[row] = t1[wc][wp]; LR2[row] = t2[wc][wp];
+    const double w = tw[wc][wp];
+    for (int b = 0; b < B; ++b) Vall[row * B + b] = (w * theta[pc + (size_t)b * NN]) * dt;
 }
 
-__global__ __launch_bounds__(256) void k_dadj_prep(int p, int N, int B, double dt, const double *__restrict__ W,
-                                                   const double *__restrict__ theta, const double *__restrict__ A,
-                                                   double *__restrict__ V, double *__restrict__ a_p, double *__restrict__ dprev)
+#define NHP_DA_GROUP 16
+#ifndef DADJ_ABL
+#define DADJ_ABL 0      // (timing ablations: wrong results)
+#endif
+template <int BT>
+__device__ __forceinline__ double dadj_x(const double *__restrict__ G, int tt, const double *__restrict__ v, int B)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < N) { dadj_prep_row(p, c, N, B, dt, W, theta, A, V, a_p); dprev[c] = 0.0; }
+    double x = 0.0;
+    if (BT > 0) {
+#pragma unroll
+        for (int b = 0; b < BT; ++b) x += G[b * NHP_DA_SPAN + tt] * v[b];
+    } else {
+        for (int b = 0; b < B; ++b) x += G[b * NHP_DA_SPAN + tt] * v[b];
+    }
+    return x;
 }
 
-__global__ __launch_bounds__(256) void k_dadj_accum(int p, int N, int B, int64_t T, const double *__restrict__ conv,
-                                                    const int32_t *__restrict__ occ_t, const int32_t *__restrict__ occ_c,
-                                                    const double *__restrict__ occ_s, const int32_t *__restrict__ occ_off,
-                                                    const double *__restrict__ V, const double *__restrict__ a_p,
-                                                    const double *__restrict__ dprev, double *__restrict__ lam_occ,
-                                                    double *__restrict__ xprev, double *__restrict__ partial)
+// log((l0 + x) / l0) for the occupied bin of one entry.  One parent's share x of a bin's intensity is small against the rest
+// l0 almost always: then 2 atanh(s), s = x / (2 l0 + x), as its odd series (|s| < 1/8: the first omitted term is 2e-16 of the
+// value) with the quotient from the hardware reciprocal and two Newton steps -- a quarter of the instructions of two
+// logarithms, and without their cancellation.  Elsewhere the difference of the two logarithms as the reference writes it.
+__device__ __forceinline__ double dadj_logratio(double l0, double x)
+{
+    const double den = 2.0 * l0 + x;
+    double r = __builtin_amdgcn_rcp(den);
+    r = r * (2.0 - den * r);
+    r = r * (2.0 - den * r);
+    const double sq = x * r;
+    if (!(sq < 0.125) || !(den > 0.0)) return nhp_log(l0 + x) - nhp_log(l0);
+    const double z = sq * sq;
+    const double poly = 2.0 + z * (2.0 / 3.0 + z * (2.0 / 5.0 + z * (2.0 / 7.0 + z * (2.0 / 9.0 + z * (2.0 / 11.0 + z * (2.0 / 13.0 + z * (2.0 / 15.0 + z * (2.0 / 17.0))))))));
+    return sq * poly;
+}
+
+struct nhp_dadj_args {
+    int N, B;
+    int gsz;                             // doubles of the LDS region that holds the two Ŝ spans, then the decision's partial sums
+    int64_t T;
+    const double *conv;
+    const uint32_t *occ_pack;
+    const int32_t *occ_t, *occ_c, *occ_off, *span_t;     // workgroup k: entries [occ_off[k], occ_off[k+1]), bins [span_t[k], span_t[k+1])
+    const double *occ_s;
+    const double *Vall, *AT, *LU, *LR1, *LR2;
+    double *dprev;                       // [N] A_new - A_old of row p - 1
+    int *nflip;                          // entries of row p - 1 that changed
+    double *lam_occ;
+    double *partial, *gpartial;          // [workgroups][N], [groups][N]
+    unsigned int *tick;                  // [1 + groups] words 32 apart
+    double *A;
+    const double *convsum;
+    unsigned long long *stamps;          // (DADJ_STAMP builds: 8 per workgroup)
+};
+
+#ifdef DADJ_STAMP
+#define DADJ_ST(k) do { if (tid == 0 && a.stamps) a.stamps[8 * (size_t)blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DADJ_ST(k) do { } while (0)
+#endif
+template <int BT, bool PACK, bool VLDS, int TH>
+__global__ __launch_bounds__(TH, TH / 128) void k_dadj_step(int p, nhp_dadj_args a)
 {
     extern __shared__ __align__(16) double dsm[];
-    double *Gt = dsm;                    // [B][NHP_DA_TT]
-    double *acc = dsm + (size_t)B * NHP_DA_TT;   // [N]
-    const int tid = threadIdx.x;
-    const int64_t t0 = (int64_t)blockIdx.x * NHP_DA_TT;
-    for (int e = tid; e < B * NHP_DA_TT; e += 256) {
-        const int b = e / NHP_DA_TT, tt = e % NHP_DA_TT;
-        const int64_t t = t0 + tt;
-        Gt[e] = t < T ? conv[(size_t)t + (size_t)T * ((size_t)p + (size_t)N * b)] : 0.0;
+    const int N = a.N, B = BT > 0 ? BT : a.B, tid = threadIdx.x;
+    double *Gt = dsm;                                       // [B][SPAN]
+    double *Gp = Gt + (size_t)B * NHP_DA_SPAN;              // [B][SPAN]  (step p - 1)
+    double *acc = dsm + a.gsz;                              // [N]
+    double *apl = acc + N, *dpl = apl + N;                  // [N] each
+    double *Vl = dpl + N;                                   // [N·B] (VLDS)
+    __shared__ int flag;
+    DADJ_ST(0);
+    const int64_t t0 = a.span_t[blockIdx.x];
+    const int span = a.span_t[blockIdx.x + 1] - (int)t0;    // <= SPAN
+    const double *Vc = a.Vall + (size_t)p * N * B, *Vp = a.Vall + (size_t)(p > 0 ? p - 1 : 0) * N * B;
+    // A thread takes `per` consecutive entries (a multiple of 4: 16-byte reads of the entry words, 2 x 16 bytes of λ).  Its first
+    // DADJ_PRE groups of four are requested while the tables are staged.
+    const int i0 = a.occ_off[blockIdx.x], i1 = a.occ_off[blockIdx.x + 1];          // (multiples of 4: the spans are padded)
+    const int per = ((i1 - i0 + 4 * TH - 1) / (4 * TH)) * 4;
+    const int mine = i0 + tid * per, mend = DADJ_ABL == 1 ? mine : min(mine + per, i1);
+    constexpr int DADJ_PRE = 3;
+    uint4 pre_w[DADJ_PRE];
+    double2 pre_a[DADJ_PRE], pre_b[DADJ_PRE];
+    // staging: every global load is requested before the first LDS store (one round trip, not one per table)
+    constexpr int GN = (8 * NHP_DA_SPAN + TH - 1) / TH;        // Ŝ elements a thread stages when B <= 8 (more: the loop below)
+    const bool flips = p > 0 && *a.nflip > 0;
+    {
+        double rg[GN], rgp[GN], ra[2], rd[2];
+#pragma unroll
+        for (int r = 0; r < GN; ++r) {
+            const int e = tid + TH * r, b = e / NHP_DA_SPAN, tt = e % NHP_DA_SPAN;
+            const int64_t t = t0 + tt;
+            const bool ok = e < B * NHP_DA_SPAN && tt < span && t < a.T;
+            rg[r] = ok ? a.conv[(size_t)t + (size_t)a.T * ((size_t)p + (size_t)N * b)] : 0.0;
+            rgp[r] = ok && flips ? a.conv[(size_t)t + (size_t)a.T * ((size_t)(p - 1) + (size_t)N * b)] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int c = tid + TH * r;
+            ra[r] = c < N ? a.AT[(size_t)p * N + c] : 0.0;
+            rd[r] = c < N && p > 0 ? a.dprev[c] : 0.0;
+        }
+        if (VLDS && DADJ_ABL != 4) {
+            if ((N * B) % 2 == 0) {
+                const double2 *src = reinterpret_cast<const double2 *>(Vc);
+                double2 *dst = reinterpret_cast<double2 *>(Vl);
+                for (int e = tid; e < N * B / 2; e += TH) dst[e] = src[e];
+            } else {
+                for (int e = tid; e < N * B; e += TH) Vl[e] = Vc[e];
+            }
+        }
+        // (the entries' requests go out behind the tables': they return while the tables are written to LDS)
+        if (PACK) {
+#pragma unroll
+            for (int g = 0; g < DADJ_PRE; ++g) {
+                const int base = mine + 4 * g;
+                if (base < mend) {
+                    pre_w[g] = *reinterpret_cast<const uint4 *>(a.occ_pack + base);
+                    pre_a[g] = *reinterpret_cast<const double2 *>(a.lam_occ + base);
+                    pre_b[g] = *reinterpret_cast<const double2 *>(a.lam_occ + base + 2);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < GN; ++r) { const int e = tid + TH * r; if (e < B * NHP_DA_SPAN) { Gt[e] = rg[r]; if (flips) Gp[e] = rgp[r]; } }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { const int c = tid + TH * r; if (c < N) { acc[c] = 0.0; apl[c] = ra[r]; dpl[c] = rd[r]; } }
+        for (int e = tid + TH * GN; e < B * NHP_DA_SPAN; e += TH) {                       // B > 8
+            const int b = e / NHP_DA_SPAN, tt = e % NHP_DA_SPAN;
+            const int64_t t = t0 + tt;
+            Gt[e] = tt < span && t < a.T ? a.conv[(size_t)t + (size_t)a.T * ((size_t)p + (size_t)N * b)] : 0.0;
+        }
+        for (int c = tid + 2 * TH; c < N; c += TH) { acc[c] = 0.0; apl[c] = a.AT[(size_t)p * N + c]; dpl[c] = p > 0 ? a.dprev[c] : 0.0; }
     }
-    for (int c = tid; c < N; c += 256) acc[c] = 0.0;
+    if (flips)
+        for (int e = tid + TH * GN; e < B * NHP_DA_SPAN; e += TH) {                           // B > 8
+            const int b = e / NHP_DA_SPAN, tt = e % NHP_DA_SPAN;
+            const int64_t t = t0 + tt;
+            Gp[e] = tt < span && t < a.T ? a.conv[(size_t)t + (size_t)a.T * ((size_t)(p - 1) + (size_t)N * b)] : 0.0;
+        }
     __syncthreads();
-    for (int i = occ_off[blockIdx.x] + tid; i < occ_off[blockIdx.x + 1]; i += 256) {
-        const int c = occ_c[i], tt = occ_t[i] - (int)t0;
-        double lam = lam_occ[i];
-        const double dp = dprev[c];
-        if (dp != 0.0) { lam += dp * xprev[i]; lam_occ[i] = lam; }       // entry (p-1, c) flipped: carry it into λ
-        double x = 0.0;
-        const double *v = V + (size_t)c * B;
-        for (int b = 0; b < B; ++b) x += Gt[b * NHP_DA_TT + tt] * v[b];
-        xprev[i] = x;
+    DADJ_ST(1);
+    const double *Vx = VLDS ? Vl : Vc;
+    const int tb = (int)(t0 % NHP_DA_SPAN);
+    // The entries are sorted by node, so a thread's entries mostly share their column: row c of V, a_p[c], dprev[c] are read
+    // when the node changes, the sum stays in a register and reaches acc[c] -- one LDS atomic -- at the end of the run.
+    int c_cur = -1;
+    double run = 0.0, apc = 0.0, dpc = 0.0;
+    double v[BT > 0 ? BT : 1], vp[BT > 0 ? BT : 1];
+    const double *vrow = Vx, *vprow = Vp;
+    auto entry = [&](int idx, int c, int tt, double sv, double lam) __attribute__((always_inline)) {
+        if (c != c_cur) {
+            if (c_cur >= 0 && run != 0.0) atomicAdd(&acc[c_cur], run);
+            c_cur = c; run = 0.0; apc = apl[c]; dpc = DADJ_ABL == 7 ? 0.0 : dpl[c];
+            vrow = Vx + (size_t)c * B; vprow = Vp + (size_t)c * B;
+            if (BT > 0) {
+#pragma unroll
+                for (int b = 0; b < BT; ++b) v[b] = vrow[b];
+                if (dpc != 0.0) {
+#pragma unroll
+                    for (int b = 0; b < BT; ++b) vp[b] = vprow[b];
+                }
+            }
+        }
+        if (dpc != 0.0) {                                              // entry (p-1, c) flipped: carry it into λ
+            lam += dpc * (BT > 0 ? dadj_x<BT>(Gp, tt, vp, B) : dadj_x<BT>(Gp, tt, vprow, B));
+            a.lam_occ[idx] = lam;
+        }
+        const double x = BT > 0 ? dadj_x<BT>(Gt, tt, v, B) : dadj_x<BT>(Gt, tt, vrow, B);
         if (x > 0.0) {
-            const double l0 = lam - a_p[c] * x;
-            atomicAdd(&acc[c], occ_s[i] * (nhp_log(l0 + x) - nhp_log(l0)));
+            const double l0 = lam - apc * x;
+            if (DADJ_ABL == 2) run += sv * l0;
+            else if (DADJ_ABL == 6) run += sv * (nhp_log(l0 + x) - nhp_log(l0));
+            else run += sv * dadj_logratio(l0, x);
         }
+    };
+    auto packed4 = [&](int base, const uint4 q, const double2 la, const double2 lb) __attribute__((always_inline)) {
+        const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+        const double l4[4] = {la.x, la.y, lb.x, lb.y};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            entry(base + j, (int)(w4[j] >> 16), ((int)(w4[j] & 255u) - tb) & (NHP_DA_SPAN - 1), (double)((w4[j] >> 8) & 255u), l4[j]);
+    };
+    if (PACK) {
+#pragma unroll
+        for (int g = 0; g < DADJ_PRE; ++g) {
+            const int base = mine + 4 * g;
+            if (base < mend) packed4(base, pre_w[g], pre_a[g], pre_b[g]);
+        }
+        for (int base = mine + 4 * DADJ_PRE; base < mend; base += 4)
+            packed4(base, *reinterpret_cast<const uint4 *>(a.occ_pack + base), *reinterpret_cast<const double2 *>(a.lam_occ + base),
+                    *reinterpret_cast<const double2 *>(a.lam_occ + base + 2));
+    } else {
+        for (int i = mine; i < mend; ++i) entry(i, a.occ_c[i], a.occ_t[i] - (int)t0, a.occ_s[i], a.lam_occ[i]);
+    }
+    if (c_cur >= 0 && run != 0.0) atomicAdd(&acc[c_cur], run);
+    __syncthreads();
+    DADJ_ST(2);
+    // ---- tail: this workgroup's row, then the two tickets
+    const unsigned int nwg = gridDim.x, grp = blockIdx.x / NHP_DA_GROUP, ngrp = (nwg + NHP_DA_GROUP - 1) / NHP_DA_GROUP;
+    const unsigned int gfirst = grp * NHP_DA_GROUP, gsize = min((unsigned int)NHP_DA_GROUP, nwg - gfirst);
+    for (int c = tid; c < N; c += TH)
+        __hip_atomic_store(&a.partial[(size_t)blockIdx.x * N + c], acc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    DADJ_ST(3);
+    if (tid == 0) flag = __hip_atomic_fetch_add(&a.tick[32 * (1 + grp)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1;
+    __syncthreads();
+    DADJ_ST(4);
+    if (!flag) return;
+    // (what the decision needs besides the sums is requested here, under the group's batch: any group may turn out the last)
+    double q_lu = 0.0, q_l1 = 0.0, q_l2 = 0.0, q_sx = 0.0;
+    if (tid < N) {
+        const size_t row = (size_t)p * N + tid;
+        q_lu = a.LU[row]; q_l1 = a.LR1[row]; q_l2 = a.LR2[row];
+        for (int b = 0; b < B; ++b) q_sx += Vc[(size_t)tid * B + b] * a.convsum[(size_t)p + (size_t)N * b];      // Σ_t x_t
+    }
+    for (int c = tid; c < N; c += TH) {
+        double r[NHP_DA_GROUP];
+#pragma unroll
+        for (unsigned int k = 0; k < NHP_DA_GROUP; ++k)
+            r[k] = __hip_atomic_load(&a.partial[(size_t)(gfirst + (k < gsize ? k : 0)) * N + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double sum = 0.0;
+#pragma unroll
+        for (unsigned int k = 0; k < NHP_DA_GROUP; ++k) sum += k < gsize ? r[k] : 0.0;
+        __hip_atomic_store(&a.gpartial[(size_t)grp * N + c], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    DADJ_ST(5);
+    if (tid == 0) flag = __hip_atomic_fetch_add(&a.tick[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1;
+    __syncthreads();
+    DADJ_ST(6);
+    if (!flag) return;
+    // ---- the last workgroup decides row p.  The group rows of a column are split over `parts` threads (16 rows a batch),
+    //      whose sums meet in LDS in a fixed order.
+    const int parts = N <= TH ? min(TH / N, 4) : 1;                  // red[parts][N] <= gsz doubles
+    double *red = Gt;
+    for (int cc = tid; cc < N * parts; cc += TH) {
+        const int c = cc % N, part = cc / N;
+        double sum = 0.0;
+        for (unsigned int g0 = part; g0 < ngrp; g0 += 16 * parts) {
+            double r[16];
+#pragma unroll
+            for (unsigned int k = 0; k < 16; ++k) {
+                const unsigned int g = g0 + k * parts;
+                r[k] = __hip_atomic_load(&a.gpartial[(size_t)(g < ngrp ? g : g0) * N + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (unsigned int k = 0; k < 16; ++k) sum += g0 + k * parts < ngrp ? r[k] : 0.0;
+        }
+        red[(size_t)part * N + c] = sum;
     }
     __syncthreads();
-    for (int c = tid; c < N; c += 256) partial[(size_t)blockIdx.x * N + c] = acc[c];
-}
-
-__global__ __launch_bounds__(256) void k_dadj_decide(int p, int N, int B, int ntiles, double dt, const double *__restrict__ W,
-                                                     const double *__restrict__ theta, double *__restrict__ A,
-                                                     const double *__restrict__ partial, const double *__restrict__ convsum,
-                                                     const double *__restrict__ rho_mat, double rho_scalar,
-                                                     const double *__restrict__ u, uint64_t seed, uint64_t step,
-                                                     double *__restrict__ V, double *__restrict__ a_p, double *__restrict__ dprev)
-{
-    // 32 columns per workgroup, 8 lane-groups per column: group g adds tiles g, g+8, ... (four independent
-    // chains in flight), then the eight group sums are added in order -- a fixed summation tree
-    __shared__ double gsum[8][32];
-    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    if (c < N) {
-        int k = grp;
-        for (; k + 24 < ntiles; k += 32) {
-            s0 += partial[(size_t)k * N + c];
-            s1 += partial[(size_t)(k + 8) * N + c];
-            s2 += partial[(size_t)(k + 16) * N + c];
-            s3 += partial[(size_t)(k + 24) * N + c];
+    int nf = 0;
+    for (int c = tid; c < N; c += TH) {
+        double delta = 0.0;
+        for (int part = 0; part < parts; ++part) delta += red[(size_t)part * N + c];
+        double sx = q_sx, lu = q_lu, l1 = q_l1, l2 = q_l2;
+        if (c != tid) {                                                                  // N > TH: the columns past the first TH
+            const size_t row = (size_t)p * N + c;
+            lu = a.LU[row]; l1 = a.LR1[row]; l2 = a.LR2[row];
+            sx = 0.0;
+            for (int b = 0; b < B; ++b) sx += Vc[(size_t)c * B + b] * a.convsum[(size_t)p + (size_t)N * b];
         }
-        for (; k < ntiles; k += 8) s0 += partial[(size_t)k * N + c];
+        const double d = (delta - sx) + l1 - l2;                                         // ll1 - ll0
+        // rand(Bernoulli(exp(ll1 - logsumexp(ll0, ll1)))): u <= 1/(1 + e^{-d})  <=>  logit(u) <= d
+        const double anew = lu <= d ? 1.0 : 0.0;
+        const double aold = apl[c];
+        a.A[(size_t)p + (size_t)c * N] = anew;
+        a.dprev[c] = anew - aold;
+        nf += anew != aold;
     }
-    gsum[grp][cl] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (grp != 0 || c >= N) return;
-    double delta = 0.0;
-    for (int g8 = 0; g8 < 8; ++g8) delta += gsum[g8][cl];
-    double sx = 0.0;                                                                // Σ_t x_t
-    for (int b = 0; b < B; ++b) sx += V[(size_t)c * B + b] * convsum[(size_t)p + (size_t)N * b];
-    const size_t pc = (size_t)p + (size_t)c * N;
-    const double rho = rho_mat ? rho_mat[pc] : rho_scalar;
-    const double d = (delta - sx) + nhp_log(rho) - nhp_log(1.0 - rho);              // ll1 - ll0
-    // rand(Bernoulli(exp(ll1 - logsumexp(ll0, ll1)))): u <= 1/(1 + e^{-d})  <=>  logit(u) <= d
-    const double uu = u ? u[pc] : nhp_philox_uniform(seed ^ 0xAD7AC3117D15C0DEull, step, pc);
-    const double anew = nhp_log(uu / (1.0 - uu)) <= d ? 1.0 : 0.0;
-    const double aold = a_p[c];
-    A[pc] = anew;
-    if (p + 1 < N) dadj_prep_row(p + 1, c, N, B, dt, W, theta, A, V, a_p);
-    dprev[c] = anew - aold;
+    nf = __syncthreads_count(nf);      // (non-zero where any thread saw a flip: only its being zero is read)
+    if (tid == 0) *a.nflip = nf;
+    DADJ_ST(7);
+    for (unsigned int i = tid; i <= ngrp; i += TH) __hip_atomic_store(&a.tick[32 * i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 extern "C" nhp_status nhp_disc_resample_adjacency(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
@@ -444,23 +668,39 @@ extern "C" nhp_status nhp_disc_resample_adjacency(nhp_ctx *ctx, const nhp_disc_d
     if (!rho_matrix && !(rho >= 0.0 && rho <= 1.0)) { nhp_set_error(ctx, "link probability must lie in [0, 1]"); return NHP_EDOMAIN; }
     NHP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t N = (size_t)ds->N, NN = N * N, B = (size_t)ds->B, TN = (size_t)ds->T * N;
-    const size_t nocc = (size_t)(ds->nocc > 0 ? ds->nocc : 1);
-    const int ntiles = (int)((ds->T + NHP_DA_TT - 1) / NHP_DA_TT);
-    const size_t lds = 8 * (B * NHP_DA_TT + N);
-    if (lds > 160 * 1024) { nhp_set_error(ctx, "resample_adjacency: N = %d, B = %d exceed the LDS budget", ds->N, ds->B); return NHP_ENOTIMPL; }
-    // scratch after stage_bump's own block: λ (T·N, for the initial gather) | λ_occ | xprev | partial | V | a_p | dprev | u | ρ
-    const size_t extra = TN + 2 * nocc + (size_t)ntiles * N + N * B + 2 * N + 2 * NN;
+    const size_t nocc = (size_t)(ds->nocc_pad > 0 ? ds->nocc_pad : 4);
+    const int nwg = ds->da_nspans;                                     // the spans were cut when the dataset was made (NHP_DADJ_SPANS)
+    int th = 512;                                                      // (1024 threads: 64 registers each -- the loop spills, 47 ms against 25)
+    if (const char *cs = getenv("NHP_DADJ_THREADS")) th = atoi(cs);
+    if (th != 256 && th != 1024) th = 512;
+    const int ngrp = (nwg + NHP_DA_GROUP - 1) / NHP_DA_GROUP;
+    const size_t gsz = std::max<size_t>(2 * B * (size_t)NHP_DA_SPAN, std::max<size_t>(N, 1024));
+    const size_t lds_base = 8 * (gsz + 3 * N), lds_v = 8 * N * B;
+    const bool vlds = lds_base + lds_v <= 78 * 1024;                 // (two workgroups per CU)
+    const size_t lds = lds_base + (vlds ? lds_v : 0);
+    if (lds > 160 * 1024 - 64) {
+        nhp_set_error(ctx, "resample_adjacency: N = %d, B = %d exceed the LDS budget", ds->N, ds->B);
+        return NHP_ENOTIMPL;
+    }
+    // scratch after stage_bump's own block: λ (T·N, for the initial gather) | λ_occ | partial | group partials | V (all rows) |
+    // A's rows | logit u | log ρ | log(1-ρ) | dprev | u | ρ | tickets and the flip count
+    const size_t extra = TN + nocc + 2 + (size_t)nwg * N + (size_t)ngrp * N + NN * B + 4 * NN + N + 2 * NN + 4 * (size_t)(2 + ngrp) * 4 + 8;
     double *E, *base, *x;
     NHP_TRY(nhp_disc_stage_bump(ctx, ds, lambda0, W, theta, A, dt, &E, &base, extra, &x, 0));
     double *dlam = x; x += TN;
-    double *lam_occ = x; x += nocc;
-    double *xprev = x; x += nocc;
-    double *partial = x; x += (size_t)ntiles * N;
-    double *V = x; x += N * B;
-    double *a_p = x; x += N;
+    double *lam_occ = x + (((uintptr_t)x & 15) ? 1 : 0); x += nocc + 2;      // (16-byte aligned: read as double2)
+    double *partial = x; x += (size_t)nwg * N;
+    double *gpartial = x; x += (size_t)ngrp * N;
+    double *Vall = x; x += NN * B;
+    double *AT = x; x += NN;
+    double *LU = x; x += NN;
+    double *LR1 = x; x += NN;
+    double *LR2 = x; x += NN;
     double *dprev = x; x += N;
     double *d_u = x; x += NN;
-    double *d_rho = x;
+    double *d_rho = x; x += NN;
+    unsigned int *tick = reinterpret_cast<unsigned int *>(x);            // 32 words per ticket, then the flip count
+    int *nflip = reinterpret_cast<int *>(tick + 32 * (size_t)(1 + ngrp));
     // stage_bump left W, θ, A on the device just before the extra block: recover the pointers
     double *dW = base + 2 * N, *dth = dW + NN, *dA = dth + NN * B;
     hipStream_t st = ctx->stream;
@@ -469,17 +709,51 @@ extern "C" nhp_status nhp_disc_resample_adjacency(nhp_ctx *ctx, const nhp_disc_d
     // λ under the current A (GEMM-1), gathered at the occupied bins
     NHP_TRY(nhp_disc_launch_intensity(ctx, ds, E, base, lambda0 == nullptr, dlam));
     hipLaunchKernelGGL(k_dadj_gather, dim3((unsigned)((nocc + 255) / 256)), dim3(256), 0, st, dlam, ds->d_occ_t, ds->d_occ_c,
-                       ds->nocc, ds->T, lam_occ, xprev);
-    const unsigned cb = (unsigned)((N + 255) / 256);
-    hipLaunchKernelGGL(k_dadj_prep, dim3(cb), dim3(256), 0, st, 0, ds->N, ds->B, dt, dW, dth, dA, V, a_p, dprev);
+                       ds->nocc_pad, ds->T, lam_occ);
+    hipLaunchKernelGGL(k_dadj_tables, dim3((unsigned)((N + 15) / 16), (unsigned)((N + 15) / 16)), dim3(256), 0, st, ds->N, ds->B, dt, dW, dth, dA,
+                       rho_matrix ? d_rho : nullptr, rho, u ? d_u : nullptr, seed, step, Vall, AT, LU, LR1, LR2);
+    NHP_HIP(ctx, hipMemsetAsync(tick, 0, 4 * (32 * (size_t)(1 + ngrp) + 2), st));
     NHP_HIP(ctx, hipGetLastError());
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_dadj_accum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    for (int p = 0; p < ds->N; ++p) {
-        hipLaunchKernelGGL(k_dadj_accum, dim3((unsigned)ntiles), dim3(256), lds, st, p, ds->N, ds->B, ds->T, ds->d_conv, ds->d_occ_t,
-                           ds->d_occ_c, ds->d_occ_s, ds->d_occ_off, V, a_p, dprev, lam_occ, xprev, partial);
-        hipLaunchKernelGGL(k_dadj_decide, dim3((unsigned)((N + 31) / 32)), dim3(256), 0, st, p, ds->N, ds->B, ntiles, dt, dW, dth, dA, partial, ds->d_convsum,
-                           rho_matrix ? d_rho : nullptr, rho, u ? d_u : nullptr, seed, step, V, a_p, dprev);
+    nhp_dadj_args a{};
+    a.N = ds->N; a.B = ds->B; a.gsz = (int)gsz; a.T = ds->T; a.conv = ds->d_conv; a.occ_pack = ds->d_occ_pack;
+    a.occ_t = ds->d_occ_t; a.occ_c = ds->d_occ_c; a.occ_off = ds->d_occ_off; a.span_t = ds->d_span_t; a.occ_s = ds->d_occ_s;
+    a.Vall = Vall; a.AT = AT; a.LU = LU; a.LR1 = LR1; a.LR2 = LR2; a.dprev = dprev; a.nflip = nflip; a.lam_occ = lam_occ;
+    a.partial = partial; a.gpartial = gpartial; a.tick = tick; a.A = dA; a.convsum = ds->d_convsum;
+#ifdef DADJ_STAMP
+    unsigned long long *d_st = nullptr;
+    const int st_step = getenv("NHP_DADJ_STAMP_STEP") ? atoi(getenv("NHP_DADJ_STAMP_STEP")) : 100;
+    if (getenv("NHP_DADJ_STAMPS") && hipMalloc((void **)&d_st, 64 * (size_t)nwg) == hipSuccess) (void)hipMemsetAsync(d_st, 0, 64 * (size_t)nwg, st);
+#define DADJ_STAMP_ARG a.stamps = (p == st_step ? d_st : nullptr)
+#else
+#define DADJ_STAMP_ARG (void)0
+#endif
+#define DADJ_GO(BT, PK, VL, TH_)                                                                                                    \
+    do {                                                                                                                           \
+        if (lds > 64 * 1024)                                                                                                       \
+            (void)hipFuncSetAttribute((const void *)k_dadj_step<BT, PK, VL, TH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        for (int p = 0; p < ds->N; ++p) {                                                                                          \
+            DADJ_STAMP_ARG;                                                                                                        \
+            hipLaunchKernelGGL((k_dadj_step<BT, PK, VL, TH_>), dim3((unsigned)nwg), dim3(TH_), lds, st, p, a);                     \
+        }                                                                                                                          \
+    } while (0)
+#define DADJ_TH(BT, PK, VL) do { if (th == 256) DADJ_GO(BT, PK, VL, 256); else if (th == 512) DADJ_GO(BT, PK, VL, 512); else DADJ_GO(BT, PK, VL, 1024); } while (0)
+#define DADJ_V(BT, PK) do { if (vlds) DADJ_TH(BT, PK, true); else DADJ_TH(BT, PK, false); } while (0)
+    const bool pk = ds->d_occ_pack != nullptr;
+    if (ds->B == 8) { if (pk) DADJ_V(8, true); else DADJ_V(8, false); }
+    else if (ds->B == 4) { if (pk) DADJ_V(4, true); else DADJ_V(4, false); }
+    else { if (pk) DADJ_V(0, true); else DADJ_V(0, false); }
+#undef DADJ_V
+#undef DADJ_TH
+#undef DADJ_GO
+#ifdef DADJ_STAMP
+    if (d_st) {
+        std::vector<unsigned long long> h(8 * (size_t)nwg);
+        (void)hipMemcpyAsync(h.data(), d_st, 64 * (size_t)nwg, hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        if (FILE *f = fopen(getenv("NHP_DADJ_STAMPS"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        (void)hipFree(d_st);
     }
+#endif
     NHP_HIP(ctx, hipGetLastError());
     NHP_HIP(ctx, hipMemcpyAsync(A, dA, 8 * NN, hipMemcpyDeviceToHost, st));
     NHP_HIP(ctx, hipStreamSynchronize(st));

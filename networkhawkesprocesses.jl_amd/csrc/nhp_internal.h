@@ -262,10 +262,18 @@ struct nhp_disc_dataset {
     double *d_colsum = nullptr;         // [2N] Σ_t data[n,t], then Σ_t loggamma(data[n,t]+1)
     double lgamma_sum = 0.0;            // Σ_{n,t} loggamma(data[n,t]+1): the data-only term of the Poisson ll
     // occupied bins (count > 0) in time-major order, for the discrete adjacency sweep
-    int64_t nocc = 0;
-    int32_t *d_occ_t = nullptr, *d_occ_c = nullptr;   // [nocc] bin, node (0-based)
-    double *d_occ_s = nullptr;                        // [nocc] the count
-    int32_t *d_occ_off = nullptr;                     // [ntiles + 1] first occupied bin of each DA_TT-bin tile
+    int64_t nocc = 0;                                 // occupied bins
+    // the discrete adjacency sweep's entry lists: the time axis cut into `da_nspans` spans of at most NHP_DA_SPAN bins (a
+    // balanced round of two workgroups per CU where T allows); within a span the occupied bins are sorted by (node, bin)
+    // and padded with empty entries (count 0) to a multiple of 4, so a thread takes whole 16-byte groups of consecutive
+    // entries that mostly share their node
+    int32_t da_nspans = 0;
+    int64_t nocc_pad = 0;                             // entries incl. padding
+    int32_t *d_occ_t = nullptr, *d_occ_c = nullptr;   // [nocc_pad] bin, node (0-based)
+    double *d_occ_s = nullptr;                        // [nocc_pad] the count
+    uint32_t *d_occ_pack = nullptr;                   // [nocc_pad] node << 16 | count << 8 | bin % 256 (null when a node index or count does not fit)
+    int32_t *d_occ_off = nullptr;                     // [da_nspans + 1] first entry of each span
+    int32_t *d_span_t = nullptr;                      // [da_nspans + 1] first bin of each span
     double *d_convsum = nullptr;                      // [N*B] Σ_t Ŝ[t, p, b] (filled with the convolution)
     // time-varying baseline of a DiscreteLogGaussianCoxProcess (nhp_disc_set_lgcp_baseline); used when a call passes lambda0 = NULL
     double *d_baseT = nullptr;                        // [T*N] baseline intensity per bin, t fastest
@@ -274,8 +282,8 @@ struct nhp_disc_dataset {
     std::vector<double> h_grid_x;                     // the LGCP grid [G]
 };
 
-#ifndef NHP_DA_TT
-#define NHP_DA_TT 128    // bins per workgroup tile of the discrete adjacency sweep (also the granularity of d_occ_off)
+#ifndef NHP_DA_SPAN
+#define NHP_DA_SPAN 256  // bins of a workgroup's span in the discrete adjacency sweep, at most (the packed entry keeps bin % 256)
 #endif
 
 // disc.hip pieces shared with disc_gibbs.hip: upload W, θ, A (and λ0) and build the bump table E [N·B x N] on the device
