@@ -808,6 +808,7 @@ extern "C" nhp_status nhp_disc_dataset_create(nhp_ctx *ctx, const int64_t *data,
                 ot[d] = st_[i]; oc[d] = sc_[i]; os[d] = ss_[i];
             }
             nocc += (int64_t)m;
+            ds->da_max_entries = std::max<int32_t>(ds->da_max_entries, (int32_t)mp);
             if (ot.size() >= ((size_t)1 << 31)) break;
         }
         off[(size_t)nsp] = (int32_t)ot.size();

@@ -334,14 +334,20 @@ extern "C" nhp_status nhp_disc_gibbs_step(nhp_ctx *ctx, const nhp_disc_dataset *
 // waiting 80 % of its life on a chain of dependent loads -- entry -> dprev[c], V[c,·] out of L2 at ~220 cycles a request ->
 // arithmetic -- 13 entries a thread one after the other; then 16.5 µs of a 16-workgroup reduction kernel):
 //  * what does not depend on the decisions is tabulated once per sweep (k_dadj_tables): V[p][c][·] = W θ dt row-major in p,
-//    A's rows, logit(u) and the two logarithms of ρ;
-//  * a workgroup takes a span of whole DA_TT tiles (<= 256 bins; the grid is one balanced round of two workgroups per CU);
-//    row p of V, A's row and dprev sit in LDS next to the Ŝ span, an entry is one coalesced 4 + 8-byte read and LDS;
-//  * x of the previous step is recomputed for the columns that flipped instead of being stored and re-read for all
-//    (the Ŝ span of p - 1 is staged only when a flip happened);
-//  * the decision is the tail of the same launch: per-workgroup rows of partial sums -> the last workgroup of each group of
-//    NHP_DA_GROUP adds its group's rows -> the last group adds the group rows and draws A[p, ·] (a fixed summation tree;
-//    every row of a batch is requested before the first is used: a serial `sum += load` is one L2 round trip per row).
+//    A's rows, logit(u), the two logarithms of ρ and Σ_t x_t;
+//  * the time axis is cut into spans of at most 256 bins when the dataset is made (a balanced round of two workgroups per CU),
+//    a span's occupied bins sorted by (node, bin): a thread takes consecutive entries -- 16-byte reads of the packed words
+//    (node | count | bin % 256) and of λ, requested while the tables are staged -- that mostly share their column, so row c
+//    of V, a_p[c] and the flip of (p - 1, c) are read once per run and the run's sum reaches the column's LDS accumulator
+//    as one atomic;
+//  * x of the previous step is recomputed for the columns that flipped instead of being stored and re-read for all;
+//  * log((l0 + x)/l0) is an atanh series where x is small against l0 (dadj_logratio);
+//  * a workgroup leaves its row of partial sums, the last of each group of NHP_DA_GROUP adds its group's rows (every row
+//    requested before the first is used: a serial `sum += load` is one L2 round trip per row), and row p is DECIDED AT
+//    THE START OF LAUNCH p + 1 by every workgroup for itself from the group rows (128 KB out of L2) -- a second ticket
+//    and one deciding workgroup at the end of the launch, with everybody else gone, cost 3.5 µs more a step.
+// 55 µs (two launches) -> 29 µs a step at config-4 scale; 36.2 -> 23.6 ms per sweep, 7.5 ms of which are the intensity GEMM
+// and the tables before the first step.
 __global__ __launch_bounds__(256) void k_dadj_gather(const double *__restrict__ lam, const int32_t *__restrict__ occ_t,
                                                      const int32_t *__restrict__ occ_c, int64_t nocc, int64_t T,
                                                      double *__restrict__ lam_occ)
@@ -350,12 +356,13 @@ __global__ __launch_bounds__(256) void k_dadj_gather(const double *__restrict__ 
     if (i < nocc) lam_occ[i] = lam[(size_t)occ_t[i] + (size_t)T * occ_c[i]];
 }
 
-// Vall[p][c*B + b] = W[p,c] θ[p,c,b] dt,  AT[p][c] = A[p,c],  LU[p][c] = logit(u[p,c]),  LR1 / LR2 = log ρ, log(1 - ρ)
+// Vall[p][c*B + b] = W[p,c] θ[p,c,b] dt,  AT[p][c] = A[p,c],  LU[p][c] = logit(u[p,c]),  LR1 / LR2 = log ρ, log(1 - ρ),
+// SX[p][c] = Σ_t x_t
 __global__ __launch_bounds__(256) void k_dadj_tables(int N, int B, double dt, const double *__restrict__ W, const double *__restrict__ theta,
                                                      const double *__restrict__ A, const double *__restrict__ rho_mat, double rho_scalar,
                                                      const double *__restrict__ u, uint64_t seed, uint64_t step, double *__restrict__ Vall,
                                                      double *__restrict__ AT, double *__restrict__ LU, double *__restrict__ LR1,
-                                                     double *__restrict__ LR2)
+                                                     double *__restrict__ LR2, const double *__restrict__ convsum, double *__restrict__ SX)
 {
     // a 16 x 16 patch of (p, c) per workgroup: reads run along p (the tables are column-major), writes along c
     __shared__ double tw[16][17], ta[16][17], tu[16][17], t1[16][17], t2[16][17];
@@ -379,10 +386,18 @@ __global__ __launch_bounds__(256) void k_dadj_tables(int N, int B, double dt, co
     const size_t row = (size_t)p * N + c, pc = (size_t)p + (size_t)c * N;
     AT[row] = ta[wc][wp]; LU[row] = tu[wc][wp]; LR1[row] = t1[wc][wp]; LR2[row] = t2[wc][wp];
     const double w = tw[wc][wp];
-    for (int b = 0; b < B; ++b) Vall[row * B + b] = (w * theta[pc + (size_t)b * NN]) * dt;
+    double sx = 0.0;                                                  // Σ_t x_t = Σ_b (W θ dt)[p,c,b] · Σ_t Ŝ[t,p,b]
+    for (int b = 0; b < B; ++b) {
+        const double vb = (w * theta[pc + (size_t)b * NN]) * dt;
+        Vall[row * B + b] = vb;
+        sx += vb * convsum[(size_t)p + (size_t)N * b];
+    }
+    SX[row] = sx;
 }
 
-#define NHP_DA_GROUP 16
+#ifndef NHP_DA_GROUP
+#define NHP_DA_GROUP 16     // workgroups whose rows one of them adds; the next launch reads nspans / GROUP rows (8: 24.9, 16: 23.6, 32: 24.3, 64: 27.3 ms per sweep)
+#endif
 #ifndef DADJ_ABL
 #define DADJ_ABL 0      // (timing ablations: wrong results)
 #endif
@@ -403,6 +418,8 @@ __device__ __forceinline__ double dadj_x(const double *__restrict__ G, int tt, c
 // l0 almost always: then 2 atanh(s), s = x / (2 l0 + x), as its odd series (|s| < 1/8: the first omitted term is 2e-16 of the
 // value) with the quotient from the hardware reciprocal and two Newton steps -- a quarter of the instructions of two
 // logarithms, and without their cancellation.  Elsewhere the difference of the two logarithms as the reference writes it.
+__device__ __attribute__((noinline)) double dadj_logdiff(double l0, double x) { return nhp_log(l0 + x) - nhp_log(l0); }
+
 __device__ __forceinline__ double dadj_logratio(double l0, double x)
 {
     const double den = 2.0 * l0 + x;
@@ -410,28 +427,25 @@ __device__ __forceinline__ double dadj_logratio(double l0, double x)
     r = r * (2.0 - den * r);
     r = r * (2.0 - den * r);
     const double sq = x * r;
-    if (!(sq < 0.125) || !(den > 0.0)) return nhp_log(l0 + x) - nhp_log(l0);
+    if (!(sq < 0.125) || !(den > 0.0)) return dadj_logdiff(l0, x);       // (a call: twelve inlined copies of two logarithms are 30 KB of code)
     const double z = sq * sq;
     const double poly = 2.0 + z * (2.0 / 3.0 + z * (2.0 / 5.0 + z * (2.0 / 7.0 + z * (2.0 / 9.0 + z * (2.0 / 11.0 + z * (2.0 / 13.0 + z * (2.0 / 15.0 + z * (2.0 / 17.0))))))));
     return sq * poly;
 }
 
 struct nhp_dadj_args {
-    int N, B;
+    int N, B, nspans;
     int gsz;                             // doubles of the LDS region that holds the two Ŝ spans, then the decision's partial sums
     int64_t T;
     const double *conv;
     const uint32_t *occ_pack;
     const int32_t *occ_t, *occ_c, *occ_off, *span_t;     // workgroup k: entries [occ_off[k], occ_off[k+1]), bins [span_t[k], span_t[k+1])
     const double *occ_s;
-    const double *Vall, *AT, *LU, *LR1, *LR2;
-    double *dprev;                       // [N] A_new - A_old of row p - 1
-    int *nflip;                          // entries of row p - 1 that changed
+    const double *Vall, *AT, *LU, *LR1, *LR2, *SX;
     double *lam_occ;
-    double *partial, *gpartial;          // [workgroups][N], [groups][N]
-    unsigned int *tick;                  // [1 + groups] words 32 apart
+    double *partial, *gpartial;          // [workgroups][N], [2][groups][N]: step p's group rows in half p & 1
+    unsigned int *tick;                  // [groups] words 32 apart
     double *A;
-    const double *convsum;
     unsigned long long *stamps;          // (DADJ_STAMP builds: 8 per workgroup)
 };
 
@@ -463,11 +477,37 @@ __global__ __launch_bounds__(TH, TH / 128) void k_dadj_step(int p, nhp_dadj_args
     constexpr int DADJ_PRE = 3;
     uint4 pre_w[DADJ_PRE];
     double2 pre_a[DADJ_PRE], pre_b[DADJ_PRE];
+    // ---- row p - 1 is decided here, by every workgroup for itself (the group rows of step p - 1 are 128 KB out of L2: cheaper
+    //      than a second ticket and a deciding workgroup at the end of that launch with everybody else gone); workgroup 0
+    //      writes A.  Launch p = N does only this.
+    const unsigned int nwg = a.nspans, grp = blockIdx.x / NHP_DA_GROUP, ngrp = (nwg + NHP_DA_GROUP - 1) / NHP_DA_GROUP;
+    const unsigned int gfirst = grp * NHP_DA_GROUP, gsize = min((unsigned int)NHP_DA_GROUP, nwg - gfirst);
+    auto decide = [&]() __attribute__((always_inline)) {
+        const double *gp = a.gpartial + (size_t)((p - 1) & 1) * ngrp * N;
+        for (int c = tid; c < N; c += TH) {
+            const size_t row = (size_t)(p - 1) * N + c;
+            const double lu = a.LU[row], l1 = a.LR1[row], l2 = a.LR2[row], sx = a.SX[row], aold = a.AT[row];
+            double delta = 0.0;
+            for (unsigned int g0 = 0; g0 < ngrp; g0 += 16) {
+                double r[16];
+#pragma unroll
+                for (unsigned int k = 0; k < 16; ++k) r[k] = gp[(size_t)(g0 + k < ngrp ? g0 + k : g0) * N + c];
+#pragma unroll
+                for (unsigned int k = 0; k < 16; ++k) delta += g0 + k < ngrp ? r[k] : 0.0;
+            }
+            const double d = (delta - sx) + l1 - l2;                                     // ll1 - ll0
+            // rand(Bernoulli(exp(ll1 - logsumexp(ll0, ll1)))): u <= 1/(1 + e^{-d})  <=>  logit(u) <= d
+            const double anew = lu <= d ? 1.0 : 0.0;
+            dpl[c] = anew - aold;
+            if (blockIdx.x == 0) a.A[(size_t)(p - 1) + (size_t)c * N] = anew;
+        }
+    };
+    if (p == N) { decide(); return; }
     // staging: every global load is requested before the first LDS store (one round trip, not one per table)
     constexpr int GN = (8 * NHP_DA_SPAN + TH - 1) / TH;        // Ŝ elements a thread stages when B <= 8 (more: the loop below)
-    const bool flips = p > 0 && *a.nflip > 0;
+    const bool flips = p > 0;                                   // (the span of p - 1 is staged whether or not a column flipped)
     {
-        double rg[GN], rgp[GN], ra[2], rd[2];
+        double rg[GN], rgp[GN], ra[2];
 #pragma unroll
         for (int r = 0; r < GN; ++r) {
             const int e = tid + TH * r, b = e / NHP_DA_SPAN, tt = e % NHP_DA_SPAN;
@@ -480,7 +520,6 @@ __global__ __launch_bounds__(TH, TH / 128) void k_dadj_step(int p, nhp_dadj_args
         for (int r = 0; r < 2; ++r) {
             const int c = tid + TH * r;
             ra[r] = c < N ? a.AT[(size_t)p * N + c] : 0.0;
-            rd[r] = c < N && p > 0 ? a.dprev[c] : 0.0;
         }
         if (VLDS && DADJ_ABL != 4) {
             if ((N * B) % 2 == 0) {
@@ -506,14 +545,15 @@ __global__ __launch_bounds__(TH, TH / 128) void k_dadj_step(int p, nhp_dadj_args
 #pragma unroll
         for (int r = 0; r < GN; ++r) { const int e = tid + TH * r; if (e < B * NHP_DA_SPAN) { Gt[e] = rg[r]; if (flips) Gp[e] = rgp[r]; } }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) { const int c = tid + TH * r; if (c < N) { acc[c] = 0.0; apl[c] = ra[r]; dpl[c] = rd[r]; } }
+        for (int r = 0; r < 2; ++r) { const int c = tid + TH * r; if (c < N) { acc[c] = 0.0; apl[c] = ra[r]; if (p == 0) dpl[c] = 0.0; } }
         for (int e = tid + TH * GN; e < B * NHP_DA_SPAN; e += TH) {                       // B > 8
             const int b = e / NHP_DA_SPAN, tt = e % NHP_DA_SPAN;
             const int64_t t = t0 + tt;
             Gt[e] = tt < span && t < a.T ? a.conv[(size_t)t + (size_t)a.T * ((size_t)p + (size_t)N * b)] : 0.0;
         }
-        for (int c = tid + 2 * TH; c < N; c += TH) { acc[c] = 0.0; apl[c] = a.AT[(size_t)p * N + c]; dpl[c] = p > 0 ? a.dprev[c] : 0.0; }
+        for (int c = tid + 2 * TH; c < N; c += TH) { acc[c] = 0.0; apl[c] = a.AT[(size_t)p * N + c]; if (p == 0) dpl[c] = 0.0; }
     }
+    if (p > 0) decide();                        // (its requests queue behind the tables' and the entries': one round trip for all)
     if (flips)
         for (int e = tid + TH * GN; e < B * NHP_DA_SPAN; e += TH) {                           // B > 8
             const int b = e / NHP_DA_SPAN, tt = e % NHP_DA_SPAN;
@@ -578,87 +618,39 @@ __global__ __launch_bounds__(TH, TH / 128) void k_dadj_step(int p, nhp_dadj_args
     if (c_cur >= 0 && run != 0.0) atomicAdd(&acc[c_cur], run);
     __syncthreads();
     DADJ_ST(2);
-    // ---- tail: this workgroup's row, then the two tickets
-    const unsigned int nwg = gridDim.x, grp = blockIdx.x / NHP_DA_GROUP, ngrp = (nwg + NHP_DA_GROUP - 1) / NHP_DA_GROUP;
-    const unsigned int gfirst = grp * NHP_DA_GROUP, gsize = min((unsigned int)NHP_DA_GROUP, nwg - gfirst);
+    // ---- tail: this workgroup's row; the last workgroup of each group adds its group's rows (fixed order; every row requested
+    //      before the first is used: a serial `sum += load` is one L2 round trip per row)
     for (int c = tid; c < N; c += TH)
         __hip_atomic_store(&a.partial[(size_t)blockIdx.x * N + c], acc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     DADJ_ST(3);
-    if (tid == 0) flag = __hip_atomic_fetch_add(&a.tick[32 * (1 + grp)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1;
+    if (tid == 0) flag = __hip_atomic_fetch_add(&a.tick[32 * grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1;
     __syncthreads();
     DADJ_ST(4);
     if (!flag) return;
-    // (what the decision needs besides the sums is requested here, under the group's batch: any group may turn out the last)
-    double q_lu = 0.0, q_l1 = 0.0, q_l2 = 0.0, q_sx = 0.0;
-    if (tid < N) {
-        const size_t row = (size_t)p * N + tid;
-        q_lu = a.LU[row]; q_l1 = a.LR1[row]; q_l2 = a.LR2[row];
-        for (int b = 0; b < B; ++b) q_sx += Vc[(size_t)tid * B + b] * a.convsum[(size_t)p + (size_t)N * b];      // Σ_t x_t
-    }
+    double *gout = a.gpartial + ((size_t)(p & 1) * ngrp + grp) * N;
     for (int c = tid; c < N; c += TH) {
-        double r[NHP_DA_GROUP];
-#pragma unroll
-        for (unsigned int k = 0; k < NHP_DA_GROUP; ++k)
-            r[k] = __hip_atomic_load(&a.partial[(size_t)(gfirst + (k < gsize ? k : 0)) * N + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         double sum = 0.0;
-#pragma unroll
-        for (unsigned int k = 0; k < NHP_DA_GROUP; ++k) sum += k < gsize ? r[k] : 0.0;
-        __hip_atomic_store(&a.gpartial[(size_t)grp * N + c], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    DADJ_ST(5);
-    if (tid == 0) flag = __hip_atomic_fetch_add(&a.tick[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1;
-    __syncthreads();
-    DADJ_ST(6);
-    if (!flag) return;
-    // ---- the last workgroup decides row p.  The group rows of a column are split over `parts` threads (16 rows a batch),
-    //      whose sums meet in LDS in a fixed order.
-    const int parts = N <= TH ? min(TH / N, 4) : 1;                  // red[parts][N] <= gsz doubles
-    double *red = Gt;
-    for (int cc = tid; cc < N * parts; cc += TH) {
-        const int c = cc % N, part = cc / N;
-        double sum = 0.0;
-        for (unsigned int g0 = part; g0 < ngrp; g0 += 16 * parts) {
+        for (unsigned int k0 = 0; k0 < NHP_DA_GROUP; k0 += 16) {
             double r[16];
 #pragma unroll
-            for (unsigned int k = 0; k < 16; ++k) {
-                const unsigned int g = g0 + k * parts;
-                r[k] = __hip_atomic_load(&a.gpartial[(size_t)(g < ngrp ? g : g0) * N + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            for (unsigned int k = 0; k < 16; ++k)
+                r[k] = __hip_atomic_load(&a.partial[(size_t)(gfirst + (k0 + k < gsize ? k0 + k : 0)) * N + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (unsigned int k = 0; k < 16; ++k) sum += g0 + k * parts < ngrp ? r[k] : 0.0;
+            for (unsigned int k = 0; k < 16; ++k) sum += k0 + k < gsize ? r[k] : 0.0;
         }
-        red[(size_t)part * N + c] = sum;
+        gout[c] = sum;                                              // (read by the next launch)
     }
-    __syncthreads();
-    int nf = 0;
-    for (int c = tid; c < N; c += TH) {
-        double delta = 0.0;
-        for (int part = 0; part < parts; ++part) delta += red[(size_t)part * N + c];
-        double sx = q_sx, lu = q_lu, l1 = q_l1, l2 = q_l2;
-        if (c != tid) {                                                                  // N > TH: the columns past the first TH
-            const size_t row = (size_t)p * N + c;
-            lu = a.LU[row]; l1 = a.LR1[row]; l2 = a.LR2[row];
-            sx = 0.0;
-            for (int b = 0; b < B; ++b) sx += Vc[(size_t)c * B + b] * a.convsum[(size_t)p + (size_t)N * b];
-        }
-        const double d = (delta - sx) + l1 - l2;                                         // ll1 - ll0
-        // rand(Bernoulli(exp(ll1 - logsumexp(ll0, ll1)))): u <= 1/(1 + e^{-d})  <=>  logit(u) <= d
-        const double anew = lu <= d ? 1.0 : 0.0;
-        const double aold = apl[c];
-        a.A[(size_t)p + (size_t)c * N] = anew;
-        a.dprev[c] = anew - aold;
-        nf += anew != aold;
-    }
-    nf = __syncthreads_count(nf);      // (non-zero where any thread saw a flip: only its being zero is read)
-    if (tid == 0) *a.nflip = nf;
-    DADJ_ST(7);
-    for (unsigned int i = tid; i <= ngrp; i += TH) __hip_atomic_store(&a.tick[32 * i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(&a.tick[32 * grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    DADJ_ST(5);
 }
 
+// (A cooperative launch holding every workgroup for all N steps -- entries and λ in registers, the decision announced through
+// a polled counter, the next step's tables fetched meanwhile -- was built and measured: 31.8 ms per sweep against 24.9.  With
+// 12 entries a thread the 128 registers do not hold words + λ + x, so a flip is carried by recomputing x for every entry of
+// a wave that holds one flipped column (13.6 µs a step, as much as the entries' pass itself), and the pass spills
+// (18.7 µs against 13.5); stamps in profiles/README.md.  Removed.)
 extern "C" nhp_status nhp_disc_resample_adjacency(nhp_ctx *ctx, const nhp_disc_dataset *ds, const double *lambda0,
                                                   const double *W, const double *theta, double *A, double dt,
                                                   const double *rho_matrix, double rho, const double *u,
@@ -682,25 +674,24 @@ extern "C" nhp_status nhp_disc_resample_adjacency(nhp_ctx *ctx, const nhp_disc_d
         nhp_set_error(ctx, "resample_adjacency: N = %d, B = %d exceed the LDS budget", ds->N, ds->B);
         return NHP_ENOTIMPL;
     }
-    // scratch after stage_bump's own block: λ (T·N, for the initial gather) | λ_occ | partial | group partials | V (all rows) |
-    // A's rows | logit u | log ρ | log(1-ρ) | dprev | u | ρ | tickets and the flip count
-    const size_t extra = TN + nocc + 2 + (size_t)nwg * N + (size_t)ngrp * N + NN * B + 4 * NN + N + 2 * NN + 4 * (size_t)(2 + ngrp) * 4 + 8;
+    // scratch after stage_bump's own block: λ (T·N, for the initial gather) | λ_occ | partial | group partials (two halves) |
+    // V (all rows) | A's rows | logit u | log ρ | log(1-ρ) | Σ_t x_t | u | ρ | tickets
+    const size_t extra = TN + nocc + 2 + (size_t)nwg * N + 2 * (size_t)ngrp * N + NN * B + 5 * NN + 2 * NN + 4 * (size_t)(2 + ngrp) * 4 + 16;
     double *E, *base, *x;
     NHP_TRY(nhp_disc_stage_bump(ctx, ds, lambda0, W, theta, A, dt, &E, &base, extra, &x, 0));
     double *dlam = x; x += TN;
     double *lam_occ = x + (((uintptr_t)x & 15) ? 1 : 0); x += nocc + 2;      // (16-byte aligned: read as double2)
     double *partial = x; x += (size_t)nwg * N;
-    double *gpartial = x; x += (size_t)ngrp * N;
+    double *gpartial = x; x += 2 * (size_t)ngrp * N;
     double *Vall = x; x += NN * B;
     double *AT = x; x += NN;
     double *LU = x; x += NN;
     double *LR1 = x; x += NN;
     double *LR2 = x; x += NN;
-    double *dprev = x; x += N;
+    double *SX = x; x += NN;
     double *d_u = x; x += NN;
     double *d_rho = x; x += NN;
-    unsigned int *tick = reinterpret_cast<unsigned int *>(x);            // 32 words per ticket, then the flip count
-    int *nflip = reinterpret_cast<int *>(tick + 32 * (size_t)(1 + ngrp));
+    unsigned int *tick = reinterpret_cast<unsigned int *>(x);            // 32 words per group ticket
     // stage_bump left W, θ, A on the device just before the extra block: recover the pointers
     double *dW = base + 2 * N, *dth = dW + NN, *dA = dth + NN * B;
     hipStream_t st = ctx->stream;
@@ -711,14 +702,14 @@ extern "C" nhp_status nhp_disc_resample_adjacency(nhp_ctx *ctx, const nhp_disc_d
     hipLaunchKernelGGL(k_dadj_gather, dim3((unsigned)((nocc + 255) / 256)), dim3(256), 0, st, dlam, ds->d_occ_t, ds->d_occ_c,
                        ds->nocc_pad, ds->T, lam_occ);
     hipLaunchKernelGGL(k_dadj_tables, dim3((unsigned)((N + 15) / 16), (unsigned)((N + 15) / 16)), dim3(256), 0, st, ds->N, ds->B, dt, dW, dth, dA,
-                       rho_matrix ? d_rho : nullptr, rho, u ? d_u : nullptr, seed, step, Vall, AT, LU, LR1, LR2);
-    NHP_HIP(ctx, hipMemsetAsync(tick, 0, 4 * (32 * (size_t)(1 + ngrp) + 2), st));
+                       rho_matrix ? d_rho : nullptr, rho, u ? d_u : nullptr, seed, step, Vall, AT, LU, LR1, LR2, ds->d_convsum, SX);
+    NHP_HIP(ctx, hipMemsetAsync(tick, 0, 4 * (32 * (size_t)(1 + ngrp) + 4), st));
     NHP_HIP(ctx, hipGetLastError());
     nhp_dadj_args a{};
-    a.N = ds->N; a.B = ds->B; a.gsz = (int)gsz; a.T = ds->T; a.conv = ds->d_conv; a.occ_pack = ds->d_occ_pack;
+    a.N = ds->N; a.B = ds->B; a.nspans = nwg; a.gsz = (int)gsz; a.T = ds->T; a.conv = ds->d_conv; a.occ_pack = ds->d_occ_pack;
     a.occ_t = ds->d_occ_t; a.occ_c = ds->d_occ_c; a.occ_off = ds->d_occ_off; a.span_t = ds->d_span_t; a.occ_s = ds->d_occ_s;
-    a.Vall = Vall; a.AT = AT; a.LU = LU; a.LR1 = LR1; a.LR2 = LR2; a.dprev = dprev; a.nflip = nflip; a.lam_occ = lam_occ;
-    a.partial = partial; a.gpartial = gpartial; a.tick = tick; a.A = dA; a.convsum = ds->d_convsum;
+    a.Vall = Vall; a.AT = AT; a.LU = LU; a.LR1 = LR1; a.LR2 = LR2; a.SX = SX; a.lam_occ = lam_occ;
+    a.partial = partial; a.gpartial = gpartial; a.tick = tick; a.A = dA;
 #ifdef DADJ_STAMP
     unsigned long long *d_st = nullptr;
     const int st_step = getenv("NHP_DADJ_STAMP_STEP") ? atoi(getenv("NHP_DADJ_STAMP_STEP")) : 100;
@@ -731,9 +722,9 @@ extern "C" nhp_status nhp_disc_resample_adjacency(nhp_ctx *ctx, const nhp_disc_d
     do {                                                                                                                           \
         if (lds > 64 * 1024)                                                                                                       \
             (void)hipFuncSetAttribute((const void *)k_dadj_step<BT, PK, VL, TH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        for (int p = 0; p < ds->N; ++p) {                                                                                          \
+        for (int p = 0; p <= ds->N; ++p) {                         /* launch N: the last row's decision alone */                  \
             DADJ_STAMP_ARG;                                                                                                        \
-            hipLaunchKernelGGL((k_dadj_step<BT, PK, VL, TH_>), dim3((unsigned)nwg), dim3(TH_), lds, st, p, a);                     \
+            hipLaunchKernelGGL((k_dadj_step<BT, PK, VL, TH_>), dim3(p < ds->N ? (unsigned)nwg : 1u), dim3(TH_), lds, st, p, a);    \
         }                                                                                                                          \
     } while (0)
 #define DADJ_TH(BT, PK, VL) do { if (th == 256) DADJ_GO(BT, PK, VL, 256); else if (th == 512) DADJ_GO(BT, PK, VL, 512); else DADJ_GO(BT, PK, VL, 1024); } while (0)

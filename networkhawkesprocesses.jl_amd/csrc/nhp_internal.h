@@ -267,7 +267,7 @@ struct nhp_disc_dataset {
     // balanced round of two workgroups per CU where T allows); within a span the occupied bins are sorted by (node, bin)
     // and padded with empty entries (count 0) to a multiple of 4, so a thread takes whole 16-byte groups of consecutive
     // entries that mostly share their node
-    int32_t da_nspans = 0;
+    int32_t da_nspans = 0, da_max_entries = 0;        // spans; the most entries (incl. padding) any span holds
     int64_t nocc_pad = 0;                             // entries incl. padding
     int32_t *d_occ_t = nullptr, *d_occ_c = nullptr;   // [nocc_pad] bin, node (0-based)
     double *d_occ_s = nullptr;                        // [nocc_pad] the count

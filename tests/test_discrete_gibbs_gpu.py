@@ -96,6 +96,40 @@ def test_adjacency_sweep_equals_the_literal_restatement(nhp, orc, N, T, B, L, ra
     assert not np.array_equal(want, A0)                             # the sweep did something
 
 
+@pytest.mark.parametrize("N,T,B,L,rate,spans,big", [(6, 1000, 8, 5, 0.2, 4, False), (40, 600, 4, 4, 0.05, 3, False),
+                                                     (4, 700, 8, 6, 0.3, 0, True), (5, 900, 3, 4, 0.4, 5, False),
+                                                     (9, 520, 8, 3, 1.2, 3, True)])
+def test_adjacency_sweep_over_long_spans(nhp, orc, monkeypatch, N, T, B, L, rate, spans, big):
+    """The step kernel's layouts (csrc/disc_gibbs.hip k_dadj_step): spans of up to 256 bins sorted by node (NHP_DADJ_SPANS cuts
+    the time axis as a 256-CU device cuts T = 1e5: ~200 bins a span), B = 8 / 4 compiled in and any other B at run time, and
+    a count past 255, which takes the unpacked entry arrays -- decisions against the oracle's literal restatement."""
+    if spans:
+        monkeypatch.setenv("NHP_DADJ_SPANS", str(spans))
+    proc, data = make_network(nhp, N, T, B, L, rate, seed=5 * N + T)
+    if big:
+        # (the node's own rate goes up with it: the reference takes log(pdf(Poisson(λ), s)), and a count of 300 under a rate
+        #  of 0.3 underflows the pdf -- ll0 = ll1 = -Inf, Bernoulli(NaN) -- which is not a case to reproduce)
+        data = data.copy()
+        data[N // 2, T // 3] = 300
+        lam0 = proc.baseline.λ.copy()
+        lam0[N // 2] = 280.0
+        proc.baseline.λ = lam0
+    proc.weights.W = proc.weights.W * N * 1.5
+    ds, conv = nhp.convolve(proc, data, fetch=True)
+    u = np.random.default_rng(11).uniform(size=(N, N))
+    A0 = proc.adjacency_matrix.copy()
+    want = orc.disc_resample_adjacency(data, conv, proc.baseline.λ, proc.weights.W, proc.impulses.θ, A0, 0.3, u, proc.dt)
+    links = nhp.disc_resample_adjacency_matrix_(proc, convolved=ds, u=u)
+    assert np.array_equal(proc.adjacency_matrix, want)
+    assert links == want.sum()
+    assert not np.array_equal(want, A0)
+    # a second sweep from the first one's result (flips of the last row carried, tables made anew)
+    u2 = np.random.default_rng(12).uniform(size=(N, N))
+    want2 = orc.disc_resample_adjacency(data, conv, proc.baseline.λ, proc.weights.W, proc.impulses.θ, want, 0.3, u2, proc.dt)
+    nhp.disc_resample_adjacency_matrix_(proc, convolved=ds, u=u2)
+    assert np.array_equal(proc.adjacency_matrix, want2)
+
+
 def test_network_counts_respect_the_mask_and_mcmc_runs(nhp, orc):
     proc, data = make_network(nhp, 6, 2000, 3, 6, 0.4, seed=21)
     ds, conv = nhp.convolve(proc, data, fetch=True)
