@@ -39,7 +39,10 @@ __device__ __attribute__((noinline)) double rp_next_u(double u_prev, int remaini
 // RP_TT x RP_CT = the tile (bins x child nodes), RP_TH threads.  What a launch moves is the staging traffic: per chunk of RP_KC
 // categories a tile fetches (RP_TT + RP_CT)·RP_KC doubles for RP_TT·RP_CT·rate occupied bins -- 78 GB per sweep at config 4 with
 // 64 x 128 tiles (5.6 TB/s out of L2 / the Infinity Cache: the bound of the 14 ms launch), half of that with 128 x 256.
-template <int RP_SLOTS, int RP_TT, int RP_CT, int RP_TH>
+// COLM: the list runs column by column, every column padded to a multiple of RP_SLOTS, and a thread's slots are consecutive
+// entries -- bins of ONE node: E[category, node] is read once per category for all of them (and consecutive lanes read
+// consecutive nodes: no bank conflicts there), which leaves (1 + SLOTS) / SLOTS LDS reads per multiply-add instead of 2.
+template <int RP_SLOTS, int RP_TT, int RP_CT, int RP_TH, bool COLM>
 __global__ __launch_bounds__(RP_TH) void k_disc_resample_parents(const double *__restrict__ dataT, const double *__restrict__ conv,
                                                                const double *__restrict__ E2, const double *__restrict__ base,
                                                                const double *__restrict__ baseT, int64_t T, int N, int B,
@@ -58,15 +61,45 @@ __global__ __launch_bounds__(RP_TH) void k_disc_resample_parents(const double *_
     // Occupied bins, listed bin-row by bin-row (entry = tl·RP_CT + cl): consecutive lanes then share a
     // bin row, so a wave's reads of a G row collapse to a few broadcast addresses and its reads of an E
     // row hit distinct banks.  Flags are gathered with coalesced loads (t fastest), then compacted in order.
-    unsigned char *occ = reinterpret_cast<unsigned char *>(&Et[0][0]);       // [RP_TT][RP_CT], before Et is used
+    unsigned char *occ = reinterpret_cast<unsigned char *>(&Et[0][0]);       // [RP_TT][RP_CT] (COLM: [RP_CT][RP_TT]), before Et is used
     for (int i = tid; i < RP_TT * RP_CT; i += RP_TH) {
         const int tl_ = i % RP_TT, cl_ = i / RP_TT;
         const int64_t t = t0 + tl_;
         const int c = c0 + cl_;
-        occ[tl_ * RP_CT + cl_] = (t < T && c < N && dataT[(size_t)t + (size_t)T * c] > 0.0) ? 1 : 0;
+        occ[COLM ? i : tl_ * RP_CT + cl_] = (t < T && c < N && dataT[(size_t)t + (size_t)T * c] > 0.0) ? 1 : 0;
     }
     __syncthreads();
-    {
+    if (COLM) {
+        // whole columns per wave; a column's entries in bin order, then padding (0xFFFF) up to a multiple of RP_SLOTS
+        static_assert(!COLM || (RP_TT % 64 == 0 && (RP_TT * RP_CT / (RP_TH / 64)) % RP_TT == 0 && RP_TT * RP_CT < 65535), "tile shape (column-major list)");
+        const int lane = tid & 63, wave = tid >> 6;
+        constexpr int CPW = RP_CT / (RP_TH / 64);                  // columns per wave
+        int cnt = 0;
+        for (int cl_ = wave * CPW; cl_ < (wave + 1) * CPW; ++cl_) {
+            int m = 0;
+#pragma unroll
+            for (int q = 0; q < RP_TT / 64; ++q) m += __popcll(__ballot(occ[cl_ * RP_TT + 64 * q + lane] != 0));
+            cnt += (m + RP_SLOTS - 1) / RP_SLOTS * RP_SLOTS;
+        }
+        if (lane == 0) wcnt[wave] = cnt;
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < wave; ++w) off += wcnt[w];
+        for (int cl_ = wave * CPW; cl_ < (wave + 1) * CPW; ++cl_) {
+            int m = 0;
+#pragma unroll
+            for (int q = 0; q < RP_TT / 64; ++q) {
+                const bool f = occ[cl_ * RP_TT + 64 * q + lane] != 0;
+                const unsigned long long bm = __ballot(f);
+                if (f) list[off + m + __popcll(bm & ((1ull << lane) - 1ull))] = (unsigned short)((64 * q + lane) * RP_CT + cl_);
+                m += __popcll(bm);
+            }
+            const int mp = (m + RP_SLOTS - 1) / RP_SLOTS * RP_SLOTS;
+            if (lane < mp - m) list[off + m + lane] = 0xFFFFu;
+            off += mp;
+        }
+        if (tid == RP_TH - 1) nb = off;
+    } else {
         const int lane = tid & 63, wave = tid >> 6;
         constexpr int PER_WAVE = RP_TT * RP_CT / (RP_TH / 64);
         int cnt = 0;
@@ -131,14 +164,17 @@ __global__ __launch_bounds__(RP_TH) void k_disc_resample_parents(const double *_
         double cum[RP_SLOTS], total[RP_SLOTS], thr[RP_SLOTS], u[RP_SLOTS];
 #pragma unroll
         for (int s = 0; s < RP_SLOTS; ++s) {
-            const int idx = b0 + tid + RP_TH * s;
-            const int e = idx < nbins ? list[idx] : 0;
+            const int idx = COLM ? b0 + tid * RP_SLOTS + s : b0 + tid + RP_TH * s;
+            const unsigned int e0 = idx < nbins ? list[idx] : 0xFFFFu;
+            const bool real = !COLM ? idx < nbins : e0 != 0xFFFFu;
+            const int e = real ? (int)e0 : 0;
             tl[s] = e / RP_CT; cl[s] = e % RP_CT;
-            n[s] = idx < nbins ? (int)dataT[(size_t)(t0 + tl[s]) + (size_t)T * (c0 + cl[s])] : 0;
+            n[s] = real ? (int)dataT[(size_t)(t0 + tl[s]) + (size_t)T * (c0 + cl[s])] : 0;
             j[s] = 0;
             cum[s] = n[s] > 0 ? (baseT ? baseT[(size_t)(t0 + tl[s]) + (size_t)T * (c0 + cl[s])] : base[c0 + cl[s]]) : 0.0;
             total[s] = 0.0; thr[s] = 0.0; u[s] = 0.0;
         }
+        const int clm = cl[0];                                       // (COLM: the slots' common column; a thread's first slot is never padding unless all are)
         // ---- walk 1: row totals
         fetch(0);
         for (int q0 = 0; q0 < K; q0 += RP_KC) {
@@ -148,8 +184,9 @@ __global__ __launch_bounds__(RP_TH) void k_disc_resample_parents(const double *_
             if (q0 + RP_KC < K) fetch(q0 + RP_KC);
 #pragma unroll 4
             for (int kk = 0; kk < RP_KC; ++kk) {
+                const double ec = Et[kk][clm];
 #pragma unroll
-                for (int s = 0; s < RP_SLOTS; ++s) cum[s] = cum[s] + Gt[kk][tl[s]] * Et[kk][cl[s]];
+                for (int s = 0; s < RP_SLOTS; ++s) cum[s] = cum[s] + Gt[kk][tl[s]] * (COLM ? ec : Et[kk][cl[s]]);
             }
         }
         // first thresholds; the baseline category
@@ -178,9 +215,10 @@ __global__ __launch_bounds__(RP_TH) void k_disc_resample_parents(const double *_
             __syncthreads();
             if (q0 + RP_KC < K) fetch(q0 + RP_KC);
             for (int kk = 0; kk < RP_KC; ++kk) {
+                const double ec = Et[kk][clm];
 #pragma unroll
                 for (int s = 0; s < RP_SLOTS; ++s) {
-                    cum[s] = cum[s] + Gt[kk][tl[s]] * Et[kk][cl[s]];
+                    cum[s] = cum[s] + Gt[kk][tl[s]] * (COLM ? ec : Et[kk][cl[s]]);
                     // ONE test per multiply-add: a bin with nothing left to place carries thr = +inf, and categories
                     // past K are staged as zeros (the sum cannot pass a threshold there that it had not passed before)
                     if (cum[s] > thr[s]) {
@@ -221,26 +259,31 @@ static nhp_status disc_parent_counts(nhp_ctx *ctx, const nhp_disc_dataset *ds, c
     // tile (bins x nodes, threads): the larger one halves the staging traffic per occupied bin where the problem fills it;
     // NHP_RP_TILE = "TT,CT,THREADS" overrides (64,128,256 | 128,128,512 | 128,256,1024), NHP_RP_SLOTS the slots per thread
     int TT = 64, CT = 128, TH = 256;
-    if (N >= 256 && ds->T >= 128 * 256) { TT = 128; CT = 256; TH = 1024; }
+    if (N >= 256 && ds->T >= 128 * 256) { TT = 128; CT = 128; TH = 512; }      // (column-major list: 12.4 ms; 128 x 256 x 1024 13.5, 64 x 128 x 256 14.3)
     if (const char *ts = getenv("NHP_RP_TILE")) sscanf(ts, "%d,%d,%d", &TT, &CT, &TH);
     if (!((TT == 64 && CT == 128 && TH == 256) || (TT == 128 && CT == 128 && TH == 512) || (TT == 128 && CT == 256 && TH == 1024))) { TT = 64; CT = 128; TH = 256; }
     dim3 grid((unsigned)((ds->T + TT - 1) / TT), (unsigned)((N + CT - 1) / CT));
     // occupied bins of a tile: the mean plus three standard deviations (a tile that overflows its slots walks twice)
     const double mean = (double)ds->nocc * (double)(TT * CT) / ((double)ds->T * (double)std::max<size_t>(N, (size_t)CT));
-    const double need = mean + 3.0 * sqrt(mean);
+    // column-major list (slots of a thread share their node): every column of the tile is padded to a multiple of the slots
+    static const int colm_env = getenv("NHP_RP_COLM") ? atoi(getenv("NHP_RP_COLM")) : 1;
+    const bool colm = colm_env != 0 && TT >= 64 && (TT * CT / (TH / 64)) % TT == 0;
     const char *fs = getenv("NHP_RP_SLOTS");
-    const int slots = fs ? atoi(fs) : (need <= 1.0 * TH ? 1 : need <= 2.0 * TH ? 2 : 4);
+    auto need_for = [&](int sl) { return mean + 3.0 * sqrt(mean) + (colm ? 0.5 * (sl - 1) * CT : 0.0); };
+    const int slots = fs ? atoi(fs) : (need_for(1) <= 1.0 * TH ? 1 : need_for(2) <= 2.0 * TH ? 2 : 4);
     const size_t lds = 8 * (size_t)RP_KC * (size_t)(TT + CT + 1) + 2 * (size_t)TT * CT;
-#define RP_LAUNCH(S, tt, ct, th)                                                                                                  \
+#define RP_LAUNCH(S, tt, ct, th, cm)                                                                                              \
     do {                                                                                                                          \
         if (lds > 64 * 1024)                                                                                                      \
-            (void)hipFuncSetAttribute((const void *)k_disc_resample_parents<S, tt, ct, th>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_disc_resample_parents<S, tt, ct, th>), grid, dim3(th), lds, st, ds->d_dataT, ds->d_conv, E2, base,  \
+            (void)hipFuncSetAttribute((const void *)k_disc_resample_parents<S, tt, ct, th, cm>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_disc_resample_parents<S, tt, ct, th, cm>), grid, dim3(th), lds, st, ds->d_dataT, ds->d_conv, E2, base, \
                            lambda0 ? nullptr : ds->d_baseT, ds->T, ds->N, ds->B, b_magic, seed, step, d_counts, ds->d_base_counts); \
     } while (0)
-#define RP_TILE(tt, ct, th) do { if (slots == 1) RP_LAUNCH(1, tt, ct, th); else if (slots == 2) RP_LAUNCH(2, tt, ct, th); else RP_LAUNCH(4, tt, ct, th); } while (0)
+#define RP_SL(tt, ct, th, cm) do { if (slots == 1) RP_LAUNCH(1, tt, ct, th, cm); else if (slots == 2) RP_LAUNCH(2, tt, ct, th, cm); else RP_LAUNCH(4, tt, ct, th, cm); } while (0)
+#define RP_TILE(tt, ct, th) do { if (colm) RP_SL(tt, ct, th, true); else RP_SL(tt, ct, th, false); } while (0)
     if (TT == 64) RP_TILE(64, 128, 256); else if (CT == 128) RP_TILE(128, 128, 512); else RP_TILE(128, 256, 1024);
 #undef RP_TILE
+#undef RP_SL
 #undef RP_LAUNCH
     if (ds->d_base_counts) const_cast<nhp_disc_dataset *>(ds)->base_counts_valid = true;
     NHP_HIP(ctx, hipGetLastError());
