@@ -85,6 +85,7 @@ def test_gradient_over_the_slices_one_item_per_node(nhp, orc, monkeypatch):
     independent terms -T, -cnt[p] included) and k_grad_init does not run.  A node without events and one with a single
     event are in the data."""
     N, M = 1040, 60000
+    monkeypatch.delenv("NHP_SLICES", raising=False)                 # (this test is about the slices' own route)
     monkeypatch.setenv("NHP_CHUNK", "4096")                         # (58 events a node: the 1.3 x mean item bound would cut some nodes in two)
     c = random_case(N, M, 4000.0, "exponential", 1.0, seed=31, nhp=nhp, orc=orc)
     n = c["nodes"].copy()

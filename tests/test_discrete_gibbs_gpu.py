@@ -96,9 +96,9 @@ def test_adjacency_sweep_equals_the_literal_restatement(nhp, orc, N, T, B, L, ra
     assert not np.array_equal(want, A0)                             # the sweep did something
 
 
-@pytest.mark.parametrize("N,T,B,L,rate,spans,big", [(6, 1000, 8, 5, 0.2, 4, False), (40, 600, 4, 4, 0.05, 3, False),
+@pytest.mark.parametrize("N,T,B,L,rate,spans,big", [(6, 1000, 8, 5, 0.2, 4, False), (24, 600, 4, 4, 0.05, 3, False),
                                                      (4, 700, 8, 6, 0.3, 0, True), (5, 900, 3, 4, 0.4, 5, False),
-                                                     (9, 520, 8, 3, 1.2, 3, True)])
+                                                     (5, 520, 8, 6, 0.3, 3, True)])
 def test_adjacency_sweep_over_long_spans(nhp, orc, monkeypatch, N, T, B, L, rate, spans, big):
     """The step kernel's layouts (csrc/disc_gibbs.hip k_dadj_step): spans of up to 256 bins sorted by node (NHP_DADJ_SPANS cuts
     the time axis as a 256-CU device cuts T = 1e5: ~200 bins a span), B = 8 / 4 compiled in and any other B at run time, and
