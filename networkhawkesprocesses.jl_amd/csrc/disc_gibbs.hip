@@ -711,7 +711,7 @@ extern "C" nhp_status nhp_disc_resample_adjacency(nhp_ctx *ctx, const nhp_disc_d
     const int ngrp = (nwg + NHP_DA_GROUP - 1) / NHP_DA_GROUP;
     const size_t gsz = std::max<size_t>(2 * B * (size_t)NHP_DA_SPAN, std::max<size_t>(N, 1024));
     const size_t lds_base = 8 * (gsz + 3 * N), lds_v = 8 * N * B;
-    const bool vlds = lds_base + lds_v <= 78 * 1024;                 // (two workgroups per CU)
+    const bool vlds = lds_base + lds_v <= 78 * 1024 && !(getenv("NHP_DADJ_VLDS") && atoi(getenv("NHP_DADJ_VLDS")) == 0);   // (two workgroups per CU)
     const size_t lds = lds_base + (vlds ? lds_v : 0);
     if (lds > 160 * 1024 - 64) {
         nhp_set_error(ctx, "resample_adjacency: N = %d, B = %d exceed the LDS budget", ds->N, ds->B);

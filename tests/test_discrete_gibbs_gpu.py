@@ -105,6 +105,9 @@ def test_adjacency_sweep_over_long_spans(nhp, orc, monkeypatch, N, T, B, L, rate
     a count past 255, which takes the unpacked entry arrays -- decisions against the oracle's literal restatement."""
     if spans:
         monkeypatch.setenv("NHP_DADJ_SPANS", str(spans))
+    if spans == 5:
+        monkeypatch.setenv("NHP_DADJ_VLDS", "0")                    # the row of V read from global memory (large N·B)
+        monkeypatch.setenv("NHP_DADJ_THREADS", "256")
     proc, data = make_network(nhp, N, T, B, L, rate, seed=5 * N + T)
     if big:
         # (the node's own rate goes up with it: the reference takes log(pdf(Poisson(λ), s)), and a count of 300 under a rate
