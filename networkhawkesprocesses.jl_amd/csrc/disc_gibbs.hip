@@ -22,6 +22,9 @@
 // at a time from Philox, so n events cost one walk).  One lane owns a bin's running sum, in the
 // reference's category order with separate multiply and add: counts equal the oracle's, bit for bit.
 #define RP_KC 16
+#ifndef RP_ABL
+#define RP_ABL 0        // (timing ablations, wrong results: 1 = no arithmetic in the walks, 2 = no global loads of the chunks)
+#endif
 #define RP_KEY 0xD15C0DE5EEDC0FFEull
 
 __device__ __attribute__((noinline)) double rp_next_u(double u_prev, int remaining, uint64_t seed, uint64_t step, uint64_t bin, int j)
@@ -42,12 +45,15 @@ __device__ __attribute__((noinline)) double rp_next_u(double u_prev, int remaini
 // COLM: the list runs column by column, every column padded to a multiple of RP_SLOTS, and a thread's slots are consecutive
 // entries -- bins of ONE node: E[category, node] is read once per category for all of them (and consecutive lanes read
 // consecutive nodes: no bank conflicts there), which leaves (1 + SLOTS) / SLOTS LDS reads per multiply-add instead of 2.
-template <int RP_SLOTS, int RP_TT, int RP_CT, int RP_TH, bool COLM>
-__global__ __launch_bounds__(RP_TH) void k_disc_resample_parents(const double *__restrict__ dataT, const double *__restrict__ conv,
+// CHK: walk 1 keeps the running sum at the start of each eighth of the category axis (registers); walk 2 then enters a bin's
+// chain at the eighth its first threshold falls into -- the same partial sum, bit for bit -- and leaves it when the bin's
+// events are placed: a bin with one event (97 % of them at 5 % occupancy) reads a sixteenth of the categories instead of all.
+template <int RP_SLOTS, int RP_TT, int RP_CT, int RP_TH, bool COLM, bool CHK>
+__global__ __launch_bounds__(RP_TH, 4) void k_disc_resample_parents(const double *__restrict__ dataT, const double *__restrict__ conv,
                                                                const double *__restrict__ E2, const double *__restrict__ base,
                                                                const double *__restrict__ baseT, int64_t T, int N, int B,
                                                                unsigned b_magic, uint64_t seed, uint64_t step,
-                                                               int *__restrict__ counts, int *__restrict__ base_counts)
+                                                               int *__restrict__ counts, int *__restrict__ base_counts, int xcd_ncy)
 {
 #pragma clang fp contract(off)
     extern __shared__ __align__(16) unsigned char rp_smem[];
@@ -56,8 +62,19 @@ __global__ __launch_bounds__(RP_TH) void k_disc_resample_parents(const double *_
     unsigned short *list = reinterpret_cast<unsigned short *>(rp_smem + 8 * RP_KC * (RP_TT + RP_CT + 1)); // [RP_TT * RP_CT]
     __shared__ int nb, wcnt[RP_TH / 64];
     const int tid = threadIdx.x, K = N * B;
-    const int64_t t0 = (int64_t)blockIdx.x * RP_TT;
-    const int c0 = blockIdx.y * RP_CT;
+    // Tile of a workgroup.  The node tiles of one bin range read the same rows of the 3.3 GB convolution; dispatched a grid
+    // row apart they each fetch them from HBM (the matrix does not stay in the Infinity Cache: 4 x 3.3 GB per walk with four
+    // node tiles).  xcd > 0: eight consecutive bin ranges x all node tiles share 8·ncy consecutive workgroup ids, node tile
+    // cy of bin range i at id cy·8 + i -- the siblings are dispatched together and, ids being dealt round-robin to the 8 XCDs,
+    // land on the same XCD: one of them misses, the others hit its L2.
+    int tx = blockIdx.x, cy = blockIdx.y;
+    if (xcd_ncy > 0) {
+        const int g8 = blockIdx.x / (8 * xcd_ncy), r = blockIdx.x % (8 * xcd_ncy);
+        cy = r / 8; tx = g8 * 8 + r % 8;
+        if ((int64_t)tx * RP_TT >= T) return;
+    }
+    const int64_t t0 = (int64_t)tx * RP_TT;
+    const int c0 = cy * RP_CT;
     // Occupied bins, listed bin-row by bin-row (entry = tl·RP_CT + cl): consecutive lanes then share a
     // bin row, so a wave's reads of a G row collapse to a few broadcast addresses and its reads of an E
     // row hit distinct banks.  Flags are gathered with coalesced loads (t fastest), then compacted in order.
@@ -137,6 +154,7 @@ __global__ __launch_bounds__(RP_TH) void k_disc_resample_parents(const double *_
     unsigned gmask = 0, emask = 0;            // which of the fetched values are real (applied when staged,
     auto fetch = [&](int q0) {                // so that the loads stay in flight under the arithmetic)
         gmask = 0; emask = 0;
+        if (RP_ABL == 2) return;
 #pragma unroll
         for (int r = 0; r < GN; ++r) {
             const int qr = q0 + g_k0 + (RP_TH / RP_TT) * r;
@@ -176,17 +194,26 @@ __global__ __launch_bounds__(RP_TH) void k_disc_resample_parents(const double *_
         }
         const int clm = cl[0];                                       // (COLM: the slots' common column; a thread's first slot is never padding unless all are)
         // ---- walk 1: row totals
+        constexpr int NSEG = CHK ? 8 : 1;
+        const int seg_len = CHK ? (((K + RP_KC - 1) / RP_KC + NSEG - 1) / NSEG) * RP_KC : K;     // categories per eighth (whole chunks)
+        double chk[NSEG][RP_SLOTS];
         fetch(0);
-        for (int q0 = 0; q0 < K; q0 += RP_KC) {
-            __syncthreads();
-            stage();
-            __syncthreads();
-            if (q0 + RP_KC < K) fetch(q0 + RP_KC);
-#pragma unroll 4
-            for (int kk = 0; kk < RP_KC; ++kk) {
-                const double ec = Et[kk][clm];
 #pragma unroll
-                for (int s = 0; s < RP_SLOTS; ++s) cum[s] = cum[s] + Gt[kk][tl[s]] * (COLM ? ec : Et[kk][cl[s]]);
+        for (int sg = 0; sg < NSEG; ++sg) {
+#pragma unroll
+            for (int s = 0; s < RP_SLOTS; ++s) chk[sg][s] = cum[s];
+            const int qb = min(K, (sg + 1) * seg_len);
+            for (int q0 = sg * seg_len; q0 < qb; q0 += RP_KC) {
+                __syncthreads();
+                stage();
+                __syncthreads();
+                if (q0 + RP_KC < K) fetch(q0 + RP_KC);
+#pragma unroll 4
+                for (int kk = 0; kk < (RP_ABL == 1 ? 0 : RP_KC); ++kk) {
+                    const double ec = Et[kk][clm];
+#pragma unroll
+                    for (int s = 0; s < RP_SLOTS; ++s) cum[s] = cum[s] + Gt[kk][tl[s]] * (COLM ? ec : Et[kk][cl[s]]);
+                }
             }
         }
         // first thresholds; the baseline category
@@ -207,6 +234,20 @@ __global__ __launch_bounds__(RP_TH) void k_disc_resample_parents(const double *_
             }
             if (j[s] >= n[s]) thr[s] = __builtin_inf();                      // nothing (left) to place: walk 2 never stops here
         }
+        // (CHK) where a bin's chain is entered: the last eighth whose starting sum has not passed the bin's next threshold
+        // (sums of non-negative terms: the running sum never decreases, so nothing is placed before that point)
+        int from[RP_SLOTS];
+#pragma unroll
+        for (int s = 0; s < RP_SLOTS; ++s) {
+            from[s] = 0;
+            if (CHK) {
+                int sg1 = 0;
+                double start = chk[0][s];
+#pragma unroll
+                for (int sg = 1; sg < NSEG; ++sg) { const bool le = chk[sg][s] <= thr[s]; sg1 += le ? 1 : 0; start = le ? chk[sg][s] : start; }
+                if (thr[s] < __builtin_inf()) { cum[s] = start; from[s] = sg1 * seg_len; }
+            }
+        }
         // ---- walk 2: categories by inverse CDF
         fetch(0);
         for (int q0 = 0; q0 < K; q0 += RP_KC) {
@@ -214,11 +255,13 @@ __global__ __launch_bounds__(RP_TH) void k_disc_resample_parents(const double *_
             stage();
             __syncthreads();
             if (q0 + RP_KC < K) fetch(q0 + RP_KC);
-            for (int kk = 0; kk < RP_KC; ++kk) {
-                const double ec = Et[kk][clm];
 #pragma unroll
-                for (int s = 0; s < RP_SLOTS; ++s) {
-                    cum[s] = cum[s] + Gt[kk][tl[s]] * (COLM ? ec : Et[kk][cl[s]]);
+            for (int s = 0; s < RP_SLOTS; ++s) {
+              if (CHK && !(q0 >= from[s] && thr[s] < __builtin_inf())) continue;
+              for (int kk = 0; kk < (RP_ABL == 1 ? 0 : RP_KC); ++kk) {
+                const double ec = Et[kk][COLM ? clm : cl[s]];
+                {
+                    cum[s] = cum[s] + Gt[kk][tl[s]] * ec;
                     // ONE test per multiply-add: a bin with nothing left to place carries thr = +inf, and categories
                     // past K are staged as zeros (the sum cannot pass a threshold there that it had not passed before)
                     if (cum[s] > thr[s]) {
@@ -231,6 +274,7 @@ __global__ __launch_bounds__(RP_TH) void k_disc_resample_parents(const double *_
                         } while (cum[s] > thr[s]);
                     }
                 }
+              }
             }
         }
 #pragma unroll
@@ -259,10 +303,13 @@ static nhp_status disc_parent_counts(nhp_ctx *ctx, const nhp_disc_dataset *ds, c
     // tile (bins x nodes, threads): the larger one halves the staging traffic per occupied bin where the problem fills it;
     // NHP_RP_TILE = "TT,CT,THREADS" overrides (64,128,256 | 128,128,512 | 128,256,1024), NHP_RP_SLOTS the slots per thread
     int TT = 64, CT = 128, TH = 256;
-    if (N >= 256 && ds->T >= 128 * 256) { TT = 128; CT = 128; TH = 512; }      // (column-major list: 12.4 ms; 128 x 256 x 1024 13.5, 64 x 128 x 256 14.3)
+    if (N >= 256 && ds->T >= 128 * 256) { TT = 128; CT = 128; TH = 512; }      // (10.6 ms; 128 x 256 x 1024 11.9, 64 x 128 x 256 12.4)
     if (const char *ts = getenv("NHP_RP_TILE")) sscanf(ts, "%d,%d,%d", &TT, &CT, &TH);
     if (!((TT == 64 && CT == 128 && TH == 256) || (TT == 128 && CT == 128 && TH == 512) || (TT == 128 && CT == 256 && TH == 1024))) { TT = 64; CT = 128; TH = 256; }
-    dim3 grid((unsigned)((ds->T + TT - 1) / TT), (unsigned)((N + CT - 1) / CT));
+    const int ntx = (int)((ds->T + TT - 1) / TT), ncy = (int)((N + CT - 1) / CT);
+    static const int xcd_env = getenv("NHP_RP_XCD") ? atoi(getenv("NHP_RP_XCD")) : 1;
+    const int xcd_ncy = xcd_env && ncy > 1 ? ncy : 0;
+    dim3 grid(xcd_ncy ? (unsigned)(((ntx + 7) / 8) * 8 * ncy) : (unsigned)ntx, xcd_ncy ? 1u : (unsigned)ncy);
     // occupied bins of a tile: the mean plus three standard deviations (a tile that overflows its slots walks twice)
     const double mean = (double)ds->nocc * (double)(TT * CT) / ((double)ds->T * (double)std::max<size_t>(N, (size_t)CT));
     // column-major list (slots of a thread share their node): every column of the tile is padded to a multiple of the slots
@@ -271,17 +318,21 @@ static nhp_status disc_parent_counts(nhp_ctx *ctx, const nhp_disc_dataset *ds, c
     const char *fs = getenv("NHP_RP_SLOTS");
     auto need_for = [&](int sl) { return mean + 3.0 * sqrt(mean) + (colm ? 0.5 * (sl - 1) * CT : 0.0); };
     const int slots = fs ? atoi(fs) : (need_for(1) <= 1.0 * TH ? 1 : need_for(2) <= 2.0 * TH ? 2 : 4);
-    const size_t lds = 8 * (size_t)RP_KC * (size_t)(TT + CT + 1) + 2 * (size_t)TT * CT;
-#define RP_LAUNCH(S, tt, ct, th, cm)                                                                                              \
+    const size_t lds = 8 * (size_t)RP_KC * (size_t)(TT + CT + 1) + 2 * (size_t)TT * CT;      // (a list of 2048 entries instead: no more workgroups per CU -- 128 registers)
+#define RP_LAUNCH(S, tt, ct, th, cm, ck)                                                                                          \
     do {                                                                                                                          \
         if (lds > 64 * 1024)                                                                                                      \
-            (void)hipFuncSetAttribute((const void *)k_disc_resample_parents<S, tt, ct, th, cm>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_disc_resample_parents<S, tt, ct, th, cm>), grid, dim3(th), lds, st, ds->d_dataT, ds->d_conv, E2, base, \
-                           lambda0 ? nullptr : ds->d_baseT, ds->T, ds->N, ds->B, b_magic, seed, step, d_counts, ds->d_base_counts); \
+            (void)hipFuncSetAttribute((const void *)k_disc_resample_parents<S, tt, ct, th, cm, ck>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_disc_resample_parents<S, tt, ct, th, cm, ck>), grid, dim3(th), lds, st, ds->d_dataT, ds->d_conv, E2, base, \
+                           lambda0 ? nullptr : ds->d_baseT, ds->T, ds->N, ds->B, b_magic, seed, step, d_counts, ds->d_base_counts, xcd_ncy); \
     } while (0)
-#define RP_SL(tt, ct, th, cm) do { if (slots == 1) RP_LAUNCH(1, tt, ct, th, cm); else if (slots == 2) RP_LAUNCH(2, tt, ct, th, cm); else RP_LAUNCH(4, tt, ct, th, cm); } while (0)
-#define RP_TILE(tt, ct, th) do { if (colm) RP_SL(tt, ct, th, true); else RP_SL(tt, ct, th, false); } while (0)
+#define RP_SL(tt, ct, th, cm, ck) do { if (slots == 1) RP_LAUNCH(1, tt, ct, th, cm, ck); else if (slots == 2) RP_LAUNCH(2, tt, ct, th, cm, ck); else RP_LAUNCH(4, tt, ct, th, cm, ck); } while (0)
+#define RP_CK(tt, ct, th, cm) do { if (chk) RP_SL(tt, ct, th, cm, true); else RP_SL(tt, ct, th, cm, false); } while (0)
+#define RP_TILE(tt, ct, th) do { if (colm) RP_CK(tt, ct, th, true); else RP_CK(tt, ct, th, false); } while (0)
+    static const int chk_env = getenv("NHP_RP_CHK") ? atoi(getenv("NHP_RP_CHK")) : 1;
+    const bool chk = chk_env != 0;
     if (TT == 64) RP_TILE(64, 128, 256); else if (CT == 128) RP_TILE(128, 128, 512); else RP_TILE(128, 256, 1024);
+#undef RP_CK
 #undef RP_TILE
 #undef RP_SL
 #undef RP_LAUNCH
