@@ -26,6 +26,23 @@
 #define RP_ABL 0        // (timing ablations, wrong results: 1 = no arithmetic in the walks, 2 = no global loads of the chunks)
 #endif
 #define RP_KEY 0xD15C0DE5EEDC0FFEull
+#ifdef RP_STAMP
+// (debug build, tools/dbg/rpstamps.py) per workgroup: s_memtime ticks spent, over the chunks of walk 1 [0..3] and walk 2 [4..7], in the
+// barrier before a chunk is staged, the wait for its loads, staging + barrier, and its arithmetic
+__device__ unsigned long long g_rp_stamps[8 * 4096];
+extern "C" int nhp_debug_rp_stamps(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rp_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#define RP_T() __builtin_amdgcn_s_memtime()
+#define RP_ST_A() const unsigned long long ta = RP_T(); __syncthreads(); const unsigned long long tb0 = RP_T(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long tb = RP_T()
+#define RP_ST_C() const unsigned long long tc = RP_T()
+#define RP_ST_D(w) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); { const unsigned long long td = RP_T(); st[4 * (w)] += tb0 - ta; st[4 * (w) + 1] += tb - tb0; st[4 * (w) + 2] += tc - tb; st[4 * (w) + 3] += td - tc; }
+#else
+#define RP_ST_A() __syncthreads()
+#define RP_ST_C() do { } while (0)
+#define RP_ST_D(w) do { } while (0)
+#endif
 
 __device__ __attribute__((noinline)) double rp_next_u(double u_prev, int remaining, uint64_t seed, uint64_t step, uint64_t bin, int j)
 {
@@ -193,6 +210,9 @@ __global__ __launch_bounds__(RP_TH, 4) void k_disc_resample_parents(const double
             total[s] = 0.0; thr[s] = 0.0; u[s] = 0.0;
         }
         const int clm = cl[0];                                       // (COLM: the slots' common column; a thread's first slot is never padding unless all are)
+#ifdef RP_STAMP
+        unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
         // ---- walk 1: row totals
         constexpr int NSEG = CHK ? 8 : 1;
         const int seg_len = CHK ? (((K + RP_KC - 1) / RP_KC + NSEG - 1) / NSEG) * RP_KC : K;     // categories per eighth (whole chunks)
@@ -204,9 +224,10 @@ __global__ __launch_bounds__(RP_TH, 4) void k_disc_resample_parents(const double
             for (int s = 0; s < RP_SLOTS; ++s) chk[sg][s] = cum[s];
             const int qb = min(K, (sg + 1) * seg_len);
             for (int q0 = sg * seg_len; q0 < qb; q0 += RP_KC) {
-                __syncthreads();
+                RP_ST_A();
                 stage();
                 __syncthreads();
+                RP_ST_C();
                 if (q0 + RP_KC < K) fetch(q0 + RP_KC);
 #pragma unroll 4
                 for (int kk = 0; kk < (RP_ABL == 1 ? 0 : RP_KC); ++kk) {
@@ -214,6 +235,7 @@ __global__ __launch_bounds__(RP_TH, 4) void k_disc_resample_parents(const double
 #pragma unroll
                     for (int s = 0; s < RP_SLOTS; ++s) cum[s] = cum[s] + Gt[kk][tl[s]] * (COLM ? ec : Et[kk][cl[s]]);
                 }
+                RP_ST_D(0);
             }
         }
         // first thresholds; the baseline category
@@ -251,13 +273,24 @@ __global__ __launch_bounds__(RP_TH, 4) void k_disc_resample_parents(const double
         // ---- walk 2: categories by inverse CDF
         fetch(0);
         for (int q0 = 0; q0 < K; q0 += RP_KC) {
-            __syncthreads();
+            RP_ST_A();
             stage();
             __syncthreads();
+            RP_ST_C();
             if (q0 + RP_KC < K) fetch(q0 + RP_KC);
 #pragma unroll
             for (int s = 0; s < RP_SLOTS; ++s) {
               if (CHK && !(q0 >= from[s] && thr[s] < __builtin_inf())) continue;
+              if (RP_ABL != 1) {
+                  // The chunk's sum first, without a test: straight-line, its LDS reads in flight together.  The running sum never
+                  // decreases, so if the chunk ends at or below the threshold nothing is placed inside it -- the common case (a bin
+                  // places an event in one or two of its chunks).  The loop below, with its test per category, costs an LDS
+                  // round trip per category: run for every chunk it was 62 % of walk 2 (tools/dbg/rpstamps.py).
+                  double e = cum[s];
+#pragma unroll
+                  for (int kk = 0; kk < RP_KC; ++kk) e = e + Gt[kk][tl[s]] * Et[kk][COLM ? clm : cl[s]];
+                  if (!(e > thr[s])) { cum[s] = e; continue; }
+              }
               for (int kk = 0; kk < (RP_ABL == 1 ? 0 : RP_KC); ++kk) {
                 const double ec = Et[kk][COLM ? clm : cl[s]];
                 {
@@ -276,7 +309,14 @@ __global__ __launch_bounds__(RP_TH, 4) void k_disc_resample_parents(const double
                 }
               }
             }
+            RP_ST_D(1);
         }
+#ifdef RP_STAMP
+        if (tid == 0) {
+            const unsigned int wg = blockIdx.x + gridDim.x * blockIdx.y;
+            if (wg < 4096) for (int k = 0; k < 8; ++k) g_rp_stamps[8 * wg + k] = st[k];
+        }
+#endif
 #pragma unroll
         for (int s = 0; s < RP_SLOTS; ++s)                                    // capped at the last category
             if (j[s] < n[s]) atomicAdd(&counts[(size_t)(c0 + cl[s]) + (size_t)N * K], n[s] - j[s]);
