@@ -190,6 +190,64 @@ def test_config4_intensity_and_loglik_at_full_size(nhp, orc, config4):
     assert np.allclose(lam2 - base, 2.0 * (lam - base), rtol=1e-12, atol=1e-16)
 
 
+def test_config4_adjacency_sweep_rows_at_full_size(nhp, orc, config4):
+    """One sweep of the discrete adjacency matrix at config-4 scale (N = 512, B = 8, T = 1e5: 2.56e6 occupied bins, 513 launches
+    of k_dadj_step over 512 spans of ~195 bins), explicit uniforms.  The literal restatement costs N²·T·N·B = 1e14 terms, so the
+    definition is applied to single entries: rows 0 and 1 of a few columns from the intensity under the OLD matrix, and the
+    LAST row from the intensity under the sweep's own earlier decisions of that column (the GEMM of the intensity test) --
+    which is where an error of the λ carried through 511 steps would show."""
+    c = config4
+    N, B, L, T, data = c["N"], c["B"], c["L"], c["T"], c["data"]
+    rng = np.random.default_rng(21)
+    A0 = (rng.uniform(size=(N, N)) < 0.5).astype(np.float64)
+    W = np.asfortranarray(c["W"] * 2.0)                                # (links that matter a little more)
+    imp = c["proc"].impulses
+    net = nhp.DiscreteNetworkHawkesProcess(nhp.DiscreteHomogeneousProcess(c["lam0"], 1.0), imp, nhp.DenseWeightModel(W), A0.copy(),
+                                           nhp.BernoulliNetworkModel(0.3, N), 1.0)
+    u = rng.uniform(size=(N, N))
+    lam_old = nhp.intensity(net, c["ds"])                              # T x N under A0
+    nhp.disc_resample_adjacency_matrix_(net, convolved=c["ds"], u=u)
+    A1 = net.adjacency_matrix.copy()
+    assert set(np.unique(A1)) <= {0.0, 1.0} and not np.array_equal(A1, A0)
+    phi = orc.disc_basis(L, B, 1.0)
+    prior = np.log(0.3) - np.log(0.7)
+    logit_u = np.log(u / (1.0 - u))
+
+    def xs(p, col):                                                    # x_t = W dt Σ_b Ŝ[t, p, b] θ[p, c, b]
+        conv_p = orc.disc_convolve(data[p:p + 1], phi)[:, 0, :]        # T x B
+        return W[p, col] * (conv_p @ c["th"][p, col, :])
+
+    def decide(lam_col, a_old, x, s, p, col):
+        l0 = lam_col - a_old * x
+        occ = s > 0
+        d = float(np.sum(s[occ] * (np.log(l0[occ] + x[occ]) - np.log(l0[occ]))) - x.sum() + prior)
+        return d, (1.0 if logit_u[p, col] <= d else 0.0)
+
+    checked = 0
+    for col in (0, 77, 300, 511):
+        s = data[col].astype(np.float64)
+        lam_col = lam_old[:, col].copy()
+        for p in (0, 1):
+            x = xs(p, col)
+            d, a_new = decide(lam_col, A0[p, col], x, s, p, col)
+            if abs(d - logit_u[p, col]) > 1e-6:                        # (a draw this close to the odds is not a test of anything)
+                assert A1[p, col] == a_new, (p, col, d, logit_u[p, col])
+                checked += 1
+            lam_col += (A1[p, col] - A0[p, col]) * x                   # what the sweep carried into the next row
+    # the last row: λ under the sweep's decisions for rows < N-1 of the column and the old entry of row N-1
+    state = A1.copy()
+    state[N - 1, :] = A0[N - 1, :]
+    net.adjacency_matrix = state
+    lam_state = nhp.intensity(net, c["ds"])
+    for col in (0, 77, 300, 511):
+        x = xs(N - 1, col)
+        d, a_new = decide(lam_state[:, col], A0[N - 1, col], x, data[col].astype(np.float64), N - 1, col)
+        if abs(d - logit_u[N - 1, col]) > 1e-6:
+            assert A1[N - 1, col] == a_new, (col, d, logit_u[N - 1, col])
+            checked += 1
+    assert checked >= 8
+
+
 def test_config4_vb_step_invariants_at_full_size(nhp, config4):
     import copy
     from scipy.special import digamma
