@@ -347,13 +347,13 @@ static nhp_status disc_parent_counts(nhp_ctx *ctx, const nhp_disc_dataset *ds, c
     if (const char *ts = getenv("NHP_RP_TILE")) sscanf(ts, "%d,%d,%d", &TT, &CT, &TH);
     if (!((TT == 64 && CT == 128 && TH == 256) || (TT == 128 && CT == 128 && TH == 512) || (TT == 128 && CT == 256 && TH == 1024))) { TT = 64; CT = 128; TH = 256; }
     const int ntx = (int)((ds->T + TT - 1) / TT), ncy = (int)((N + CT - 1) / CT);
-    static const int xcd_env = getenv("NHP_RP_XCD") ? atoi(getenv("NHP_RP_XCD")) : 1;
+    const int xcd_env = getenv("NHP_RP_XCD") ? atoi(getenv("NHP_RP_XCD")) : 1;
     const int xcd_ncy = xcd_env && ncy > 1 ? ncy : 0;
     dim3 grid(xcd_ncy ? (unsigned)(((ntx + 7) / 8) * 8 * ncy) : (unsigned)ntx, xcd_ncy ? 1u : (unsigned)ncy);
     // occupied bins of a tile: the mean plus three standard deviations (a tile that overflows its slots walks twice)
     const double mean = (double)ds->nocc * (double)(TT * CT) / ((double)ds->T * (double)std::max<size_t>(N, (size_t)CT));
     // column-major list (slots of a thread share their node): every column of the tile is padded to a multiple of the slots
-    static const int colm_env = getenv("NHP_RP_COLM") ? atoi(getenv("NHP_RP_COLM")) : 1;
+    const int colm_env = getenv("NHP_RP_COLM") ? atoi(getenv("NHP_RP_COLM")) : 1;
     const bool colm = colm_env != 0 && TT >= 64 && (TT * CT / (TH / 64)) % TT == 0;
     const char *fs = getenv("NHP_RP_SLOTS");
     auto need_for = [&](int sl) { return mean + 3.0 * sqrt(mean) + (colm ? 0.5 * (sl - 1) * CT : 0.0); };
@@ -369,7 +369,7 @@ static nhp_status disc_parent_counts(nhp_ctx *ctx, const nhp_disc_dataset *ds, c
 #define RP_SL(tt, ct, th, cm, ck) do { if (slots == 1) RP_LAUNCH(1, tt, ct, th, cm, ck); else if (slots == 2) RP_LAUNCH(2, tt, ct, th, cm, ck); else RP_LAUNCH(4, tt, ct, th, cm, ck); } while (0)
 #define RP_CK(tt, ct, th, cm) do { if (chk) RP_SL(tt, ct, th, cm, true); else RP_SL(tt, ct, th, cm, false); } while (0)
 #define RP_TILE(tt, ct, th) do { if (colm) RP_CK(tt, ct, th, true); else RP_CK(tt, ct, th, false); } while (0)
-    static const int chk_env = getenv("NHP_RP_CHK") ? atoi(getenv("NHP_RP_CHK")) : 1;
+    const int chk_env = getenv("NHP_RP_CHK") ? atoi(getenv("NHP_RP_CHK")) : 1;
     const bool chk = chk_env != 0;
     if (TT == 64) RP_TILE(64, 128, 256); else if (CT == 128) RP_TILE(128, 128, 512); else RP_TILE(128, 256, 1024);
 #undef RP_CK

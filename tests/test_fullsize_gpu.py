@@ -190,6 +190,37 @@ def test_config4_intensity_and_loglik_at_full_size(nhp, orc, config4):
     assert np.allclose(lam2 - base, 2.0 * (lam - base), rtol=1e-12, atol=1e-16)
 
 
+def test_parent_counts_through_the_large_tile(nhp, orc):
+    """The parent-count kernel as config 4 runs it -- 128 x 128 bins x nodes a workgroup of 512 threads, two bins per thread from
+    the column-major list, the second walk entered at a checkpoint, the node tiles of a bin range on one XCD (ids cy·8 + i)
+    -- which the small cases of tests/test_discrete_gibbs_gpu.py never reach (N >= 256 and T >= 32768 select it).  N = 256,
+    B = 8 (2048 categories), T = 32768 at 5 % occupancy: counts equal the oracle's, bit for bit; the other list and walk
+    variants give the same counts."""
+    import os
+    N, B, L, T = 256, 8, 12, 32768
+    rng = np.random.default_rng(5)
+    data = rng.poisson(0.05, (N, T)).astype(np.int64)
+    data[7, 1000] = 9                                                   # a bin with many events: thresholds in several eighths
+    th = rng.dirichlet(np.ones(B), (N, N))
+    th[:, :, -1] = 1.0 - th[:, :, :-1].sum(axis=2)
+    imp = nhp.DiscreteGaussianImpulseResponse.__new__(nhp.DiscreteGaussianImpulseResponse)
+    imp.θ, imp.γ, imp.γv, imp.nlags, imp.dt, imp.ϕ = np.asfortranarray(th), 1.0, np.ones_like(th), L, 1.0, None
+    proc = nhp.DiscreteStandardHawkesProcess(nhp.DiscreteHomogeneousProcess(rng.uniform(0.02, 0.08, N), 1.0), imp,
+                                             nhp.DenseWeightModel(np.asfortranarray(rng.uniform(0, 1, (N, N)) / N)), 1.0)
+    ds, conv = nhp.convolve(proc, data, fetch=True)
+    got = nhp.resample_parent_counts(proc, convolved=ds, seed=3, step=2)
+    assert np.array_equal(got.sum(axis=1), data.sum(axis=1))
+    want = orc.disc_resample_parents(data, conv, proc.baseline.λ, proc.weights.W, proc.impulses.θ, proc.dt, seed=3, step=2)
+    assert np.array_equal(got, want)
+    for env in ({"NHP_RP_CHK": "0"}, {"NHP_RP_COLM": "0"}, {"NHP_RP_XCD": "0"}, {"NHP_RP_TILE": "128,256,1024"}):
+        os.environ.update(env)
+        try:
+            assert np.array_equal(nhp.resample_parent_counts(proc, convolved=ds, seed=3, step=2), want), env
+        finally:
+            for k in env:
+                del os.environ[k]
+
+
 def test_config4_adjacency_sweep_rows_at_full_size(nhp, orc, config4):
     """One sweep of the discrete adjacency matrix at config-4 scale (N = 512, B = 8, T = 1e5: 2.56e6 occupied bins, 513 launches
     of k_dadj_step over 512 spans of ~195 bins), explicit uniforms.  The literal restatement costs N²·T·N·B = 1e14 terms, so the
