@@ -23,7 +23,7 @@
 // reference's category order with separate multiply and add: counts equal the oracle's, bit for bit.
 #define RP_KC 16
 #ifndef RP_ABL
-#define RP_ABL 0        // (timing ablations, wrong results: 1 = no arithmetic in the walks, 2 = no global loads of the chunks)
+#define RP_ABL 0        // (timing ablations, wrong results: 1 = no arithmetic in the walks, 2 = no global loads of the chunks, 3 = conflict-free G reads)
 #endif
 #define RP_KEY 0xD15C0DE5EEDC0FFEull
 #ifdef RP_STAMP
@@ -208,6 +208,10 @@ __global__ __launch_bounds__(RP_TH, 4) void k_disc_resample_parents(const double
             j[s] = 0;
             cum[s] = n[s] > 0 ? (baseT ? baseT[(size_t)(t0 + tl[s]) + (size_t)T * (c0 + cl[s])] : base[c0 + cl[s]]) : 0.0;
             total[s] = 0.0; thr[s] = 0.0; u[s] = 0.0;
+        }
+        if (RP_ABL == 3) {                                           // (timing only: G reads without bank conflicts)
+#pragma unroll
+            for (int s = 0; s < RP_SLOTS; ++s) tl[s] = (tid + 32 * s / RP_SLOTS * 0 + s * 37) % RP_TT;
         }
         const int clm = cl[0];                                       // (COLM: the slots' common column; a thread's first slot is never padding unless all are)
 #ifdef RP_STAMP
