@@ -65,7 +65,10 @@ __device__ __attribute__((noinline)) double rp_next_u(double u_prev, int remaini
 // CHK: walk 1 keeps the running sum at the start of each eighth of the category axis (registers); walk 2 then enters a bin's
 // chain at the eighth its first threshold falls into -- the same partial sum, bit for bit -- and leaves it when the bin's
 // events are placed: a bin with one event (97 % of them at 5 % occupancy) reads a sixteenth of the categories instead of all.
-template <int RP_SLOTS, int RP_TT, int RP_CT, int RP_TH, bool COLM, bool CHK>
+// XCHG (with CHK): between the walks the bins still to be placed change lanes through LDS, ordered by the eighth their chain is
+// entered at -- a wave then holds bins of one or two eighths and skips the chunks of the others whole (scattered, some lane of
+// nearly every wave was inside its range in every chunk: the skipping of CHK was per lane only).
+template <int RP_SLOTS, int RP_TT, int RP_CT, int RP_TH, bool COLM, bool CHK, bool XCHG>
 __global__ __launch_bounds__(RP_TH, 4) void k_disc_resample_parents(const double *__restrict__ dataT, const double *__restrict__ conv,
                                                                const double *__restrict__ E2, const double *__restrict__ base,
                                                                const double *__restrict__ baseT, int64_t T, int N, int B,
@@ -274,6 +277,60 @@ __global__ __launch_bounds__(RP_TH, 4) void k_disc_resample_parents(const double
                 if (thr[s] < __builtin_inf()) { cum[s] = start; from[s] = sg1 * seg_len; }
             }
         }
+        if (CHK && XCHG && nbins <= RP_TH * RP_SLOTS) {                      // (one round of bins: the list's LDS is free as well)
+            static_assert(!XCHG || RP_SLOTS == 2, "the exchange hands a thread two consecutive places");
+            constexpr int XCAP = RP_TH * RP_SLOTS, XSIDE = 256;
+            static_assert(!XCHG || 256 + XCAP * 20 + XSIDE * 24 <= 8 * RP_KC * (RP_TT + RP_CT + 1) + 2 * RP_TT * RP_CT, "exchange buffers fit the kernel's LDS");
+            int *xc = reinterpret_cast<int *>(rp_smem);                       // [0..7] bins per eighth, [8] bins with several events left, [9] gave up, [16..24] starts
+            unsigned int *xpk = reinterpret_cast<unsigned int *>(rp_smem + 256);                  // [XCAP] tl | cl << 8 | eighth << 16 | several << 19 | side index << 20
+            double *xthr = reinterpret_cast<double *>(rp_smem + 256 + 4 * XCAP);                   // [XCAP]
+            double *xcum = xthr + XCAP;                                                            // [XCAP]
+            double *xtot = xcum + XCAP, *xu = xtot + XSIDE;                                        // [XSIDE] each
+            unsigned int *xnj = reinterpret_cast<unsigned int *>(xu + XSIDE);                      // [XSIDE] n | j << 16
+            __syncthreads();                                                  // walk 1's chunk is done with
+            if (tid < 32) xc[tid] = 0;
+            __syncthreads();
+            int rank[RP_SLOTS], side[RP_SLOTS];
+#pragma unroll
+            for (int s = 0; s < RP_SLOTS; ++s) {
+                rank[s] = -1; side[s] = -1;
+                if (thr[s] < __builtin_inf()) {
+                    rank[s] = atomicAdd(&xc[from[s] / seg_len], 1);
+                    if (n[s] - j[s] > 1) { side[s] = atomicAdd(&xc[8], 1); if (side[s] >= XSIDE || n[s] > 65535) xc[9] = 1; }
+                }
+            }
+            __syncthreads();
+            if (tid == 0) { int acc = 0; for (int g = 0; g < 8; ++g) { xc[16 + g] = acc; acc += xc[g]; } xc[24] = acc; }
+            __syncthreads();
+            if (xc[9] == 0) {                                                 // (uniform)
+#pragma unroll
+                for (int s = 0; s < RP_SLOTS; ++s) {
+                    if (rank[s] >= 0) {
+                        const int sg = from[s] / seg_len, d = xc[16 + sg] + rank[s];
+                        xpk[d] = (unsigned int)tl[s] | (unsigned int)cl[s] << 8 | (unsigned int)sg << 16 | (side[s] >= 0 ? 1u << 19 | (unsigned int)side[s] << 20 : 0u);
+                        xthr[d] = thr[s]; xcum[d] = cum[s];
+                        if (side[s] >= 0) { xtot[side[s]] = total[s]; xu[side[s]] = u[s]; xnj[side[s]] = (unsigned int)n[s] | (unsigned int)j[s] << 16; }
+                    }
+                }
+                __syncthreads();
+                const int nact = xc[24];
+#pragma unroll
+                for (int s = 0; s < RP_SLOTS; ++s) {
+                    const int d = tid * RP_SLOTS + s;
+                    n[s] = 0; j[s] = 0; thr[s] = __builtin_inf(); from[s] = 0;
+                    if (d < nact) {
+                        const unsigned int pk = xpk[d];
+                        tl[s] = (int)(pk & 255u); cl[s] = (int)(pk >> 8 & 255u); from[s] = (int)(pk >> 16 & 7u) * seg_len;
+                        thr[s] = xthr[d]; cum[s] = xcum[d];
+                        n[s] = 1;                                             // one event left: no further threshold, total and u unused
+                        if (pk >> 19 & 1u) {
+                            const int m = (int)(pk >> 20);
+                            total[s] = xtot[m]; u[s] = xu[m]; n[s] = (int)(xnj[m] & 65535u); j[s] = (int)(xnj[m] >> 16);
+                        }
+                    }
+                }
+            }
+        }
         // ---- walk 2: categories by inverse CDF
         fetch(0);
         for (int q0 = 0; q0 < K; q0 += RP_KC) {
@@ -313,7 +370,7 @@ __global__ __launch_bounds__(RP_TH, 4) void k_disc_resample_parents(const double
                   double pre[RP_KC];
                   double e = cum[s];
 #pragma unroll
-                  for (int kk = 0; kk < RP_KC; ++kk) { e = e + Gt[kk][tl[s]] * Et[kk][COLM ? clm : cl[s]]; pre[kk] = e; }
+                  for (int kk = 0; kk < RP_KC; ++kk) { e = e + Gt[kk][tl[s]] * Et[kk][cl[s]]; pre[kk] = e; }
                   if (e > thr[s]) {
                       const int c = c0 + cl[s];
                       const uint64_t bin = (uint64_t)(t0 + tl[s]) + (uint64_t)T * (uint64_t)c;
@@ -377,20 +434,22 @@ static nhp_status disc_parent_counts(nhp_ctx *ctx, const nhp_disc_dataset *ds, c
     const bool colm = colm_env != 0 && TT >= 64 && (TT * CT / (TH / 64)) % TT == 0;
     const char *fs = getenv("NHP_RP_SLOTS");
     auto need_for = [&](int sl) { return mean + 3.0 * sqrt(mean) + (colm ? 0.5 * (sl - 1) * CT : 0.0); };
-    const int slots = fs ? atoi(fs) : (need_for(1) <= 1.0 * TH ? 1 : need_for(2) <= 2.0 * TH ? 2 : 4);
+    // (four bins a thread measured 17-35 ms against 9-12 with two and a second round over the tile's list: only by request)
+    const int slots = fs ? atoi(fs) : (need_for(1) <= 1.0 * TH ? 1 : 2);
     const size_t lds = 8 * (size_t)RP_KC * (size_t)(TT + CT + 1) + 2 * (size_t)TT * CT;      // (a list of 2048 entries instead: no more workgroups per CU -- 128 registers)
-#define RP_LAUNCH(S, tt, ct, th, cm, ck)                                                                                          \
+#define RP_LAUNCH(S, tt, ct, th, cm, ck, xg)                                                                                      \
     do {                                                                                                                          \
         if (lds > 64 * 1024)                                                                                                      \
-            (void)hipFuncSetAttribute((const void *)k_disc_resample_parents<S, tt, ct, th, cm, ck>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_disc_resample_parents<S, tt, ct, th, cm, ck>), grid, dim3(th), lds, st, ds->d_dataT, ds->d_conv, E2, base, \
+            (void)hipFuncSetAttribute((const void *)k_disc_resample_parents<S, tt, ct, th, cm, ck, xg>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_disc_resample_parents<S, tt, ct, th, cm, ck, xg>), grid, dim3(th), lds, st, ds->d_dataT, ds->d_conv, E2, base, \
                            lambda0 ? nullptr : ds->d_baseT, ds->T, ds->N, ds->B, b_magic, seed, step, d_counts, ds->d_base_counts, xcd_ncy); \
     } while (0)
-#define RP_SL(tt, ct, th, cm, ck) do { if (slots == 1) RP_LAUNCH(1, tt, ct, th, cm, ck); else if (slots == 2) RP_LAUNCH(2, tt, ct, th, cm, ck); else RP_LAUNCH(4, tt, ct, th, cm, ck); } while (0)
+#define RP_SL(tt, ct, th, cm, ck) do { if (slots == 1) RP_LAUNCH(1, tt, ct, th, cm, ck, false); else if (slots == 2) { if (ck && xchg) RP_LAUNCH(2, tt, ct, th, cm, ck, ck); else RP_LAUNCH(2, tt, ct, th, cm, ck, false); } else RP_LAUNCH(4, tt, ct, th, cm, ck, false); } while (0)
 #define RP_CK(tt, ct, th, cm) do { if (chk) RP_SL(tt, ct, th, cm, true); else RP_SL(tt, ct, th, cm, false); } while (0)
 #define RP_TILE(tt, ct, th) do { if (colm) RP_CK(tt, ct, th, true); else RP_CK(tt, ct, th, false); } while (0)
     const int chk_env = getenv("NHP_RP_CHK") ? atoi(getenv("NHP_RP_CHK")) : 1;
     const bool chk = chk_env != 0;
+    const bool xchg = !(getenv("NHP_RP_XCHG") && atoi(getenv("NHP_RP_XCHG")) == 0);
     if (TT == 64) RP_TILE(64, 128, 256); else if (CT == 128) RP_TILE(128, 128, 512); else RP_TILE(128, 256, 1024);
 #undef RP_CK
 #undef RP_TILE
