@@ -21,7 +21,9 @@
 // running sum with the bin's ascending thresholds u_(1) < u_(2) < ... (order statistics generated one
 // at a time from Philox, so n events cost one walk).  One lane owns a bin's running sum, in the
 // reference's category order with separate multiply and add: counts equal the oracle's, bit for bit.
-#define RP_KC 16
+#ifndef RP_KC
+#define RP_KC 16        // categories a chunk (variant builds: 8 / 32, tools/dbg notes)
+#endif
 #ifndef RP_ABL
 #define RP_ABL 0        // (timing ablations, wrong results: 1 = no arithmetic in the walks, 2 = no global loads of the chunks, 3 = conflict-free G reads)
 #endif
