@@ -558,10 +558,14 @@ extern "C" nhp_status nhp_disc_gibbs_step(nhp_ctx *ctx, const nhp_disc_dataset *
 //  * x of the previous step is recomputed for the columns that flipped instead of being stored and re-read for all;
 //  * log((l0 + x)/l0) is an atanh series where x is small against l0 (dadj_logratio);
 //  * a workgroup leaves its row of partial sums, the last of each group of NHP_DA_GROUP adds its group's rows (every row
-//    requested before the first is used: a serial `sum += load` is one L2 round trip per row), and row p is DECIDED AT
-//    THE START OF LAUNCH p + 1 by every workgroup for itself from the group rows (128 KB out of L2) -- a second ticket
-//    and one deciding workgroup at the end of the launch, with everybody else gone, cost 3.5 µs more a step.
-// 55 µs (two launches) -> 29 µs a step at config-4 scale; 36.2 -> 23.6 ms per sweep, 7.5 ms of which are the intensity GEMM
+//    requested before the first is used: a serial `sum += load` is one L2 round trip per row) and adds the result, with
+//    atomics, into the step's ONE row of sums (three rows in rotation, the one a launch adds to zeroed two launches before);
+//    row p is DECIDED AT THE START OF LAUNCH p + 1 by every workgroup for itself from that row -- a second ticket and one
+//    deciding workgroup at the end of the launch, with everybody else gone, cost 3.5 µs more a step; 32 group rows read by
+//    every workgroup (128 KB each, 64 MB a step out of L2) 2 µs more.  The order of a column's 32 atomic additions varies
+//    from run to run, as does the order of the LDS atomics inside a workgroup: two runs differ where |d - logit u| is
+//    within rounding of zero.
+// 55 µs (two launches) -> 27 µs a step at config-4 scale; 36.2 -> 22.6 ms per sweep, 7.5 ms of which are the intensity GEMM
 // and the tables before the first step.
 __global__ __launch_bounds__(256) void k_dadj_gather(const double *__restrict__ lam, const int32_t *__restrict__ occ_t,
                                                      const int32_t *__restrict__ occ_c, int64_t nocc, int64_t T,
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(256) void k_dadj_tables(int N, int B, double dt, co
 }
 
 #ifndef NHP_DA_GROUP
-#define NHP_DA_GROUP 16     // workgroups whose rows one of them adds; the next launch reads nspans / GROUP rows (8: 24.9, 16: 23.6, 32: 24.3, 64: 27.3 ms per sweep)
+#define NHP_DA_GROUP 16     // workgroups whose rows one of them adds; the next launch reads nspans / GROUP rows (4: 23.1, 8: 22.6, 16: 22.5, 32: 24.2 ms per sweep)
 #endif
 #ifndef DADJ_ABL
 #define DADJ_ABL 0      // (timing ablations: wrong results)
@@ -658,7 +662,7 @@ struct nhp_dadj_args {
     const double *occ_s;
     const double *Vall, *AT, *LU, *LR1, *LR2, *SX;
     double *lam_occ;
-    double *partial, *gpartial;          // [workgroups][N], [2][groups][N]: step p's group rows in half p & 1
+    double *partial, *gpartial;          // [workgroups][N], [3][N]: step p's sums in row p mod 3
     unsigned int *tick;                  // [groups] words 32 apart
     double *A;
     unsigned long long *stamps;          // (DADJ_STAMP builds: 8 per workgroup)
@@ -698,18 +702,13 @@ __global__ __launch_bounds__(TH, TH / 128) void k_dadj_step(int p, nhp_dadj_args
     const unsigned int nwg = a.nspans, grp = blockIdx.x / NHP_DA_GROUP, ngrp = (nwg + NHP_DA_GROUP - 1) / NHP_DA_GROUP;
     const unsigned int gfirst = grp * NHP_DA_GROUP, gsize = min((unsigned int)NHP_DA_GROUP, nwg - gfirst);
     auto decide = [&]() __attribute__((always_inline)) {
-        const double *gp = a.gpartial + (size_t)((p - 1) & 1) * ngrp * N;
+        // (the group rows of step p - 1 were added into ONE row by their groups' last workgroups: 4 KB to read here, not 128)
+        const double *gp = a.gpartial + (size_t)((p - 1) % 3) * N;
+        if (blockIdx.x == 0 && p < N) for (int c = tid; c < N; c += TH) a.gpartial[(size_t)((p + 1) % 3) * N + c] = 0.0;   // for the launch after this one
         for (int c = tid; c < N; c += TH) {
             const size_t row = (size_t)(p - 1) * N + c;
             const double lu = a.LU[row], l1 = a.LR1[row], l2 = a.LR2[row], sx = a.SX[row], aold = a.AT[row];
-            double delta = 0.0;
-            for (unsigned int g0 = 0; g0 < ngrp; g0 += 16) {
-                double r[16];
-#pragma unroll
-                for (unsigned int k = 0; k < 16; ++k) r[k] = gp[(size_t)(g0 + k < ngrp ? g0 + k : g0) * N + c];
-#pragma unroll
-                for (unsigned int k = 0; k < 16; ++k) delta += g0 + k < ngrp ? r[k] : 0.0;
-            }
+            const double delta = gp[c];
             const double d = (delta - sx) + l1 - l2;                                     // ll1 - ll0
             // rand(Bernoulli(exp(ll1 - logsumexp(ll0, ll1)))): u <= 1/(1 + e^{-d})  <=>  logit(u) <= d
             const double anew = lu <= d ? 1.0 : 0.0;
@@ -844,7 +843,7 @@ __global__ __launch_bounds__(TH, TH / 128) void k_dadj_step(int p, nhp_dadj_args
     __syncthreads();
     DADJ_ST(4);
     if (!flag) return;
-    double *gout = a.gpartial + ((size_t)(p & 1) * ngrp + grp) * N;
+    double *gout = a.gpartial + (size_t)(p % 3) * N;
     for (int c = tid; c < N; c += TH) {
         double sum = 0.0;
         for (unsigned int k0 = 0; k0 < NHP_DA_GROUP; k0 += 16) {
@@ -855,7 +854,7 @@ __global__ __launch_bounds__(TH, TH / 128) void k_dadj_step(int p, nhp_dadj_args
 #pragma unroll
             for (unsigned int k = 0; k < 16; ++k) sum += k0 + k < gsize ? r[k] : 0.0;
         }
-        gout[c] = sum;                                              // (read by the next launch)
+        atomicAdd(&gout[c], sum);                                   // (the row the next launch reads; zeroed two launches ago)
     }
     if (tid == 0) __hip_atomic_store(&a.tick[32 * grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     DADJ_ST(5);
@@ -891,13 +890,13 @@ extern "C" nhp_status nhp_disc_resample_adjacency(nhp_ctx *ctx, const nhp_disc_d
     }
     // scratch after stage_bump's own block: λ (T·N, for the initial gather) | λ_occ | partial | group partials (two halves) |
     // V (all rows) | A's rows | logit u | log ρ | log(1-ρ) | Σ_t x_t | u | ρ | tickets
-    const size_t extra = TN + nocc + 2 + (size_t)nwg * N + 2 * (size_t)ngrp * N + NN * B + 5 * NN + 2 * NN + 4 * (size_t)(2 + ngrp) * 4 + 16;
+    const size_t extra = TN + nocc + 2 + (size_t)nwg * N + std::max<size_t>(2 * (size_t)ngrp, 3) * N + NN * B + 5 * NN + 2 * NN + 4 * (size_t)(2 + ngrp) * 4 + 16;
     double *E, *base, *x;
     NHP_TRY(nhp_disc_stage_bump(ctx, ds, lambda0, W, theta, A, dt, &E, &base, extra, &x, 0));
     double *dlam = x; x += TN;
     double *lam_occ = x + (((uintptr_t)x & 15) ? 1 : 0); x += nocc + 2;      // (16-byte aligned: read as double2)
     double *partial = x; x += (size_t)nwg * N;
-    double *gpartial = x; x += 2 * (size_t)ngrp * N;
+    double *gpartial = x; x += std::max<size_t>(2 * (size_t)ngrp, 3) * N;               // (three rows of N are used: the steps' sums, p mod 3)
     double *Vall = x; x += NN * B;
     double *AT = x; x += NN;
     double *LU = x; x += NN;
@@ -919,6 +918,7 @@ extern "C" nhp_status nhp_disc_resample_adjacency(nhp_ctx *ctx, const nhp_disc_d
     hipLaunchKernelGGL(k_dadj_tables, dim3((unsigned)((N + 15) / 16), (unsigned)((N + 15) / 16)), dim3(256), 0, st, ds->N, ds->B, dt, dW, dth, dA,
                        rho_matrix ? d_rho : nullptr, rho, u ? d_u : nullptr, seed, step, Vall, AT, LU, LR1, LR2, ds->d_convsum, SX);
     NHP_HIP(ctx, hipMemsetAsync(tick, 0, 4 * (32 * (size_t)(1 + ngrp) + 4), st));
+    NHP_HIP(ctx, hipMemsetAsync(gpartial, 0, 8 * 3 * N, st));
     NHP_HIP(ctx, hipGetLastError());
     nhp_dadj_args a{};
     a.N = ds->N; a.B = ds->B; a.nspans = nwg; a.gsz = (int)gsz; a.T = ds->T; a.conv = ds->d_conv; a.occ_pack = ds->d_occ_pack;
