@@ -379,7 +379,7 @@ extern "C" void nhp_cont_dataset_destroy(nhp_cont_dataset *ds)
     (void)hipStreamSynchronize(ds->ctx->stream);
     (void)hipFree(ds->d_times); (void)hipFree(ds->d_nodes); (void)hipFree(ds->d_child); (void)hipFree(ds->d_child_w); (void)hipFree(ds->d_wpos); (void)hipFree(ds->d_ev); (void)hipFree(ds->d_ev8); (void)hipFree(ds->d_poff); (void)hipFree(ds->d_plist); (void)hipFree(ds->d_plq); (void)hipFree(ds->d_pnode);
     (void)hipFree(ds->d_sl_row); (void)hipFree(ds->d_sl_item0); (void)hipFree(ds->d_sl_lo); (void)hipFree(ds->d_sl_hi);
-    (void)hipFree(ds->d_sl_L); (void)hipFree(ds->d_sl_Q);
+    (void)hipFree(ds->d_sl_L); (void)hipFree(ds->d_sl_Q); (void)hipFree(ds->d_sl_D);
     (void)hipFree(ds->d_ps_row); (void)hipFree(ds->d_ps_perm); (void)hipFree(ds->d_ps_lo); (void)hipFree(ds->d_ps_hi);
     (void)hipFree(ds->d_boff); (void)hipFree(ds->d_items); (void)hipFree(ds->d_cnt); (void)hipFree(ds->d_pn);
     (void)hipFree(ds->d_adj_k); (void)hipFree(ds->d_adj_p); (void)hipFree(ds->d_adj_dt); (void)hipFree(ds->d_adj_lq); (void)hipFree(ds->d_adj_start); (void)hipFree(ds->d_adj_off); (void)hipFree(ds->d_adj_group); (void)hipFree(ds->d_child_cut);

@@ -524,9 +524,12 @@ static nhp_status run_sampler(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nh
     // NHP_SAMPLER=1 | 8 forces a kernel (8 still respects the threshold).
     const int force = getenv("NHP_SAMPLER") ? atoi(getenv("NHP_SAMPLER")) : 0;
     const double kbar = ds->M > 0 ? (double)ds->pairs / (double)ds->M : 0.0;
-    // logit-normal impulses on a sliced dataset: one lane per child over the slice planes (cont_slices.hip; same bits)
+    // a sliced dataset (up to 160 pairs per event): one lane per child over the slice planes (cont_slices.hip; same bits) --
+    // logit-normal impulses through the planes of logit(x) and 1/(x(1-x)), exponential ones through the plane of exact
+    // delays (NHP_SAMPLER_EXPO_SLICES=0: not; measured at K̄ = 8 / 16 / 32 / 64: 54 / 90 / 175 / 346 µs against 80 / 118 / 269 / 488)
     bool sliced = false;
-    if (!expo && !force) {
+    const int es = getenv("NHP_SAMPLER_EXPO_SLICES") ? atoi(getenv("NHP_SAMPLER_EXPO_SLICES")) : 1;
+    if (!force && (!expo || es != 0)) {
         NHP_TRY(nhp_launch_sampler_slices(ctx, ds, m, d_u, seed, step, want_parents ? o->parents : nullptr,
                                           want_parents ? o->pnodes : nullptr, o->pn_b, o->dt_b, d_err, &sliced));
     }

@@ -730,7 +730,29 @@ __global__ __launch_bounds__(256) void k_slices_build_lq(nhp_cont_args a, nhp_sl
     }
 }
 
-template <int BLOCK, int CACHE>
+// Exponential impulses: the sampler's weights are a·w·θ·e^{-θΔt} of the EXACT Δt = t_i - t_j (the slices' 37-bit delay would
+// change the low bits of a weight and, once in a long while, the index the scan stops at: the sampler's contract is bit
+// equality with the sequential reference).  One more plane, the delays as doubles, made once per dataset like L and Q.
+__global__ __launch_bounds__(256) void k_slices_build_d(nhp_cont_args a, nhp_slices sl, double *__restrict__ D)
+{
+    const nhp_item it = a.items[blockIdx.x];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nchild = it.kend - it.kbeg;
+    const int s0 = sl.item0[blockIdx.x], ns = sl.item0[blockIdx.x + 1] - s0;
+    for (int j = w; j < ns; j += 4) {
+        const uint32_t row0 = sl.row[s0 + j];
+        const int K = (int)(sl.row[s0 + j + 1] - row0);
+        const int kk = 64 * j + lane;
+        nhp_child ch;
+        ch.t = 0.0; ch.first = 0; ch.idx = 0;
+        if (kk < nchild) ch = a.child_w[it.kbeg + kk];
+        const int len = ch.idx - ch.first;
+        for (int r = 0; r < K; ++r)
+            D[((size_t)row0 + (size_t)r) * 64 + (size_t)lane] = r < len ? ch.t - a.ev[ch.idx - 1 - r].t : 0.0;
+    }
+}
+
+template <int BLOCK, int CACHE, int IMP>
 __global__ __launch_bounds__(BLOCK) void k_sampler_slices(nhp_cont_args a, nhp_slices sl, const double *__restrict__ L, const double *__restrict__ Q,
                                                            const double *__restrict__ u, uint64_t seed, uint64_t step,
                                                            int64_t *__restrict__ parents, int64_t *__restrict__ pnodes,
@@ -751,7 +773,8 @@ __global__ __launch_bounds__(BLOCK) void k_sampler_slices(nhp_cont_args a, nhp_s
         const size_t k = (size_t)p + (size_t)c * N;
         double wv = a.W[k];
         if (a.A) wv = a.A[k] * wv;
-        col[p] = make_double2(a.p1[k], __builtin_sqrt(a.p2[k]));
+        if (IMP == NHP_IMPULSE_EXPONENTIAL) col[p] = make_double2(a.p1[k], wv);          // {rate, a·w}: k_sampler<0>'s column
+        else col[p] = make_double2(a.p1[k], __builtin_sqrt(a.p2[k]));
         colw[p] = wv;
     }
     if (tid == 0) { col[N] = make_double2(0.0, 0.0); colw[N] = 0.0; }
@@ -759,18 +782,20 @@ __global__ __launch_bounds__(BLOCK) void k_sampler_slices(nhp_cont_args a, nhp_s
     double *wc = cache + (size_t)w * CACHE * 64 + lane;
     const int nsh = sl.nsh;
     struct chunk { uint32_t hi[C]; double l[C], q[C]; };
+    // (exponential: L is the plane of exact delays, Q is not read)
     auto request = [&](chunk &qq, const uint32_t row0, const int r) {
         const size_t o = ((size_t)row0 + (size_t)r) * 64;
 #pragma unroll
         for (int x = 0; x < C; ++x) {
             qq.hi[x] = sl.hi[o + x * 64 + lane];
             qq.l[x] = L[o + x * 64 + lane];
-            qq.q[x] = Q[o + x * 64 + lane];
+            qq.q[x] = IMP == NHP_IMPULSE_EXPONENTIAL ? 0.0 : Q[o + x * 64 + lane];
         }
     };
     auto weight = [&](const uint32_t h, const double l, const double q) {
         const int p = (int)(h >> nsh);
         const double2 cq = col[p];
+        if (IMP == NHP_IMPULSE_EXPONENTIAL) return cq.y * nhp_pdf_exponential(cq.x, l);   // the operations of samp_weight<0>
         return colw[p] * nhp_pdf_logitnormal_cached(cq.x, cq.y, make_double2(l, q));
     };
     for (int j = w; j < ns; j += NW) {
@@ -818,7 +843,7 @@ __global__ __launch_bounds__(BLOCK) void k_sampler_slices(nhp_cont_args a, nhp_s
             if (k >= nreal) return base;
             if (k < CACHE) return wc[(size_t)k * 64];
             const size_t o = ((size_t)row0 + (size_t)k) * 64 + lane;
-            return weight(sl.hi[o], L[o], Q[o]);
+            return weight(sl.hi[o], L[o], IMP == NHP_IMPULSE_EXPONENTIAL ? 0.0 : Q[o]);
         };
         int kk2 = 0;
         double cp = live ? wk_at(0) / s : 0.0;
@@ -1090,7 +1115,8 @@ nhp_status nhp_launch_sampler_slices(nhp_ctx *ctx, const nhp_cont_dataset *cds, 
 {
     *launched = false;
     // (only windows below Julia's pairwise-sum threshold: the slice kernel sums sequentially)
-    if (!cds->d_sl_row || cds->n_items <= 0 || m->impulse_kind != NHP_IMPULSE_LOGITNORMAL || cds->sl_max_rows + 1 > 1024) return NHP_OK;
+    const bool expo = m->impulse_kind == NHP_IMPULSE_EXPONENTIAL;
+    if (!cds->d_sl_row || cds->n_items <= 0 || (!expo && m->impulse_kind != NHP_IMPULSE_LOGITNORMAL) || cds->sl_max_rows + 1 > 1024) return NHP_OK;
     if ((getenv("NHP_SLICES") && atoi(getenv("NHP_SLICES")) == 0) || (getenv("NHP_SAMPLER_SLICES") && atoi(getenv("NHP_SAMPLER_SLICES")) == 0)) return NHP_OK;
     int B = 512, CACHE = 8;
     if (const char *cfg = getenv("NHP_SAMPLER_CFG")) sscanf(cfg, "%d,%d", &B, &CACHE);
@@ -1102,7 +1128,14 @@ nhp_status nhp_launch_sampler_slices(nhp_ctx *ctx, const nhp_cont_dataset *cds, 
     NHP_TRY(ensure_slices(ctx, cds, a));
     nhp_cont_dataset *ds = const_cast<nhp_cont_dataset *>(cds);
     const nhp_slices sl = slices_view(ds);
-    if (!ds->d_sl_L) {
+    if (expo && !ds->d_sl_D) {
+        const size_t n = ((size_t)ds->sl_rows + 16) * 64;
+        if (hipMalloc((void **)&ds->d_sl_D, 8 * n) != hipSuccess) { (void)hipGetLastError(); ds->d_sl_D = nullptr; return NHP_OK; }
+        NHP_HIP(ctx, hipMemsetAsync(ds->d_sl_D + (size_t)ds->sl_rows * 64, 0, 8 * 16 * 64, ctx->stream));
+        hipLaunchKernelGGL(k_slices_build_d, dim3((unsigned)ds->n_items), dim3(256), 0, ctx->stream, a, sl, ds->d_sl_D);
+        NHP_HIP(ctx, hipGetLastError());
+    }
+    if (!expo && !ds->d_sl_L) {
         const size_t n = ((size_t)ds->sl_rows + 16) * 64;
         if (hipMalloc((void **)&ds->d_sl_L, 8 * n) != hipSuccess || hipMalloc((void **)&ds->d_sl_Q, 8 * n) != hipSuccess) {
             (void)hipGetLastError();
@@ -1118,10 +1151,17 @@ nhp_status nhp_launch_sampler_slices(nhp_ctx *ctx, const nhp_cont_dataset *cds, 
     dim3 grid((unsigned)ds->n_items);
 #define NHP_SAMP(b, cc)                                                                                                \
     do {                                                                                                               \
-        if (lds > 64 * 1024)                                                                                           \
-            (void)hipFuncSetAttribute((const void *)k_sampler_slices<b, cc>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_sampler_slices<b, cc>), grid, dim3(b), lds, ctx->stream, a, sl, (const double *)ds->d_sl_L,   \
-                           (const double *)ds->d_sl_Q, d_u, seed, step, parents, pnodes, pn_b, dt_b, d_err);          \
+        if (expo) {                                                                                                    \
+            if (lds > 64 * 1024)                                                                                       \
+                (void)hipFuncSetAttribute((const void *)k_sampler_slices<b, cc, NHP_IMPULSE_EXPONENTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_sampler_slices<b, cc, NHP_IMPULSE_EXPONENTIAL>), grid, dim3(b), lds, ctx->stream, a, sl, (const double *)ds->d_sl_D, \
+                               (const double *)nullptr, d_u, seed, step, parents, pnodes, pn_b, dt_b, d_err);      \
+        } else {                                                                                                       \
+            if (lds > 64 * 1024)                                                                                       \
+                (void)hipFuncSetAttribute((const void *)k_sampler_slices<b, cc, NHP_IMPULSE_LOGITNORMAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_sampler_slices<b, cc, NHP_IMPULSE_LOGITNORMAL>), grid, dim3(b), lds, ctx->stream, a, sl, (const double *)ds->d_sl_L, \
+                               (const double *)ds->d_sl_Q, d_u, seed, step, parents, pnodes, pn_b, dt_b, d_err);      \
+        }                                                                                                              \
     } while (0)
     if (B == 256 && CACHE == 8) NHP_SAMP(256, 8); else if (B == 256) NHP_SAMP(256, 16);
     else if (CACHE == 8) NHP_SAMP(512, 8); else NHP_SAMP(512, 16);

@@ -121,6 +121,7 @@ struct nhp_cont_dataset {
     // the operation sequence of nhp_logitnormal_data (the bits of d_plq), in the same rows as d_sl_lo / d_sl_hi (whose node
     // field the consumers read); padding records hold {0, 0}.  Built at the first logit-normal parent sweep over the slices.
     double *d_sl_L = nullptr, *d_sl_Q = nullptr;   // [(sl_rows + 16) * 64] each
+    double *d_sl_D = nullptr;                       // [(sl_rows + 16) * 64] exact delays t_i - t_j (exponential parent sampler)
     int64_t sl_rows = 0;
     int32_t n_slices = 0, sl_nb = 0;    // node bits
     int32_t sl_max_rows = 0;            // most rows of one slice

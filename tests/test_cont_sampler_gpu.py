@@ -170,14 +170,17 @@ def test_both_sampler_kernels_give_the_oracle_indices(nhp, orc, which, kind, mon
 
 
 
-@pytest.mark.parametrize("network,lgcp", [(False, False), (True, True)])
-def test_slice_sampler_gives_the_oracle_indices(nhp, orc, network, lgcp, monkeypatch):
-    """Logit-normal impulses on a sliced dataset draw their parents one lane per child over the slice planes
+@pytest.mark.parametrize("kind,network,lgcp", [("logitnormal", False, False), ("logitnormal", True, True),
+                                               ("exponential", False, False), ("exponential", True, True)])
+def test_slice_sampler_gives_the_oracle_indices(nhp, orc, kind, network, lgcp, monkeypatch):
+    """A sliced dataset draws its parents one lane per child over the slice planes -- logit-normal impulses through the planes
+    of logit(x) and 1/(x(1-x)), exponential ones through the plane of exact delays
     (k_sampler_slices: rows coalesced, the first 8 or 16 weights of a child kept in LDS for the scan, later ones evaluated
     again).  Windows from empty to ~60 parents -- well past the cache -- ties and a burst in the data: indices, parent nodes
     and statistics equal the oracle's and the lane-per-child kernel's (NHP_SAMPLER_SLICES=0), for every (workgroup, cache) shape,
     with explicit uniforms and with the Philox stream."""
-    c = random_case(9, 7000, 350.0, "logitnormal", 1.2, network=network, lgcp=lgcp, seed=41, nhp=nhp, orc=orc)
+    c = random_case(9, 7000, 350.0, kind, 1.2, network=network, lgcp=lgcp, seed=41, nhp=nhp, orc=orc)
+    monkeypatch.delenv("NHP_SAMPLER_EXPO_SLICES", raising=False)
     t = c["times"].copy()
     t[500:530:2] = t[501:531:2]
     t[3000:3060] = np.sort(np.random.default_rng(8).uniform(t[3000], t[3000] + 0.9, 60))
@@ -194,6 +197,7 @@ def test_slice_sampler_gives_the_oracle_indices(nhp, orc, network, lgcp, monkeyp
         monkeypatch.delenv("NHP_SAMPLER_CFG", raising=False)
         if cfg == "off":
             monkeypatch.setenv("NHP_SAMPLER_SLICES", "0")
+            monkeypatch.setenv("NHP_SAMPLER_EXPO_SLICES", "0")
         elif cfg:
             monkeypatch.setenv("NHP_SAMPLER_CFG", cfg)
         p, pn, st = nhp.resample_parents(c["proc"], data, u=u, with_stats=True)
@@ -209,6 +213,7 @@ def test_slice_sampler_gives_the_oracle_indices(nhp, orc, network, lgcp, monkeyp
         assert np.array_equal(p2, w2) and np.array_equal(pn2, wn2), cfg
     monkeypatch.delenv("NHP_SAMPLER_SLICES", raising=False)
     monkeypatch.delenv("NHP_SAMPLER_CFG", raising=False)
+    monkeypatch.delenv("NHP_SAMPLER_EXPO_SLICES", raising=False)
 
 
 def test_logitnormal_pair_cache_keeps_every_index(nhp, monkeypatch):
