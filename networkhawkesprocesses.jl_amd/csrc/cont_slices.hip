@@ -867,6 +867,147 @@ __global__ __launch_bounds__(BLOCK) void k_sampler_slices(nhp_cont_args a, nhp_s
     }
 }
 
+// ---- logit-normal impulses over the child slices: log-likelihood -------------------------------------------------------------
+// The same walk as k_windowed_slices -- one lane per child, rows of 64 records, most recent parent first -- with the record's
+// node from the `hi` plane and the data half of its pdf, {logit(x), 1/(x(1-x))}, from the planes the parent sampler keeps
+// (sl_L, sl_Q: k_slices_build_lq), the column {μ, √τ} and a·w in LDS: a term is a·w · nhp_pdf_logitnormal_cached, the pair
+// cache's arithmetic.  A separate kernel so that the exponential one's code is not touched.
+template <int BLOCK, int C, bool FLAT>
+__global__ __launch_bounds__(BLOCK) void k_windowed_slices_ln(nhp_cont_args a, nhp_slices sl, const double *__restrict__ L, const double *__restrict__ Q,
+                                                               int mask_integral, double *__restrict__ partials, unsigned int *__restrict__ counter,
+                                                               double *__restrict__ out)
+{
+    constexpr int NW = BLOCK / 64;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *red = reinterpret_cast<double *>(smem);                 // [2 * NW <= 32] + flag at [32]
+    double2 *col = reinterpret_cast<double2 *>(smem + 320);         // [N + 1] {μ, √τ}; [N] = {0, 0}
+    double *colw = reinterpret_cast<double *>(col + a.N + 1);       // [N + 1] a·w; [N] = 0
+    const int tid = threadIdx.x, lane = tid & 63;
+    const nhp_item it = a.items[blockIdx.x];
+    const int c = it.node, N = a.N;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchild = it.kend - it.kbeg;
+    const int s0 = sl.item0[blockIdx.x], ns = sl.item0[blockIdx.x + 1] - s0;
+    struct chunk { uint32_t hi[C]; double l[C], q[C]; };
+    auto request = [&](chunk &qq, const uint32_t row0, const int r) {
+        const size_t o = ((size_t)row0 + (size_t)r) * 64;
+#pragma unroll
+        for (int u = 0; u < C; ++u) {
+            qq.hi[u] = sl.hi[o + u * 64 + lane];
+            qq.l[u] = L[o + u * 64 + lane];
+            qq.q[u] = Q[o + u * 64 + lane];
+        }
+    };
+    int j = w;
+    uint32_t row0 = 0;
+    int K = 0;
+    chunk qa, qb;
+    double integ = 0.0;
+    for (int p0 = 0; p0 < N; p0 += BLOCK) {
+        const int p = p0 + tid;
+        const size_t k = (size_t)(p < N ? p : 0) + (size_t)c * N;
+        const double w_ = a.W[k], mu = a.p1[k], tau = a.p2[k], a_ = a.A ? a.A[k] : 1.0, cnt_ = it.first ? a.cnt[p < N ? p : 0] : 0.0;
+        if (p0 == 0) {
+            if (j < ns) { row0 = sl.row[s0 + j]; K = (int)(sl.row[s0 + j + 1] - row0); }
+            asm volatile("" ::: "memory");
+            request(qa, row0, 0);
+            asm volatile("" ::: "memory");
+        }
+        if (p < N) {
+            double wv = w_, wint = w_;
+            if (a.A) { wv = a_ * wv; if (mask_integral) wint = wv; }
+            col[p] = make_double2(mu, __builtin_sqrt(tau));
+            colw[p] = wv;
+            integ += cnt_ * wint;
+        }
+    }
+    if (tid == 0) { col[N] = make_double2(0.0, 0.0); colw[N] = 0.0; }
+    if (out && it.first) integ += sl_baseline_integral_col(a, c);
+    __syncthreads();
+    const double lam0 = FLAT ? a.lambda0[c] : 0.0;
+    const int nsh = sl.nsh;
+    auto term = [&](const uint32_t h, const double l, const double q) {
+        const int p = (int)(h >> nsh);
+        const double2 cq = col[p];
+        return colw[p] * nhp_pdf_logitnormal_cached(cq.x, cq.y, make_double2(l, q));
+    };
+    auto sum = [&](const chunk &qq, const int r, const int K, double s) {
+        if (r + C <= K) {
+            double t[C];
+#pragma unroll
+            for (int u = 0; u < C; ++u) t[u] = term(qq.hi[u], qq.l[u], qq.q[u]);
+#pragma unroll
+            for (int u = 0; u < C; ++u) s += t[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < C; ++u)
+                if (r + u < K) s += term(qq.hi[u], qq.l[u], qq.q[u]);
+        }
+        return s;
+    };
+    double prod = 1.0;
+    int pexp = 0;
+    while (j < ns) {
+        const int jn = j + NW;
+        uint32_t row0n = 0;
+        int Kn = 0;
+        if (jn < ns) { row0n = sl.row[s0 + jn]; Kn = (int)(sl.row[s0 + jn + 1] - row0n); }
+        double s = 0.0;
+        if (K <= 0) request(qa, row0n, 0);
+        for (int r0 = 0; r0 < K; r0 += 2 * C) {
+            request(qb, row0, r0 + C);
+            asm volatile("" ::: "memory");
+            s = sum(qa, r0, K, s);
+            const bool more = r0 + 2 * C < K;
+            request(qa, more ? row0 : row0n, more ? r0 + 2 * C : 0);
+            asm volatile("" ::: "memory");
+            s = sum(qb, r0 + C, K, s);
+        }
+        const int kk = 64 * j + lane;
+        if (kk < nchild) {
+            const double tk = FLAT ? 0.0 : a.child_w[it.kbeg + kk].t;
+            const double lam = (FLAT ? lam0 : sl_baseline(a, c, tk)) + s;
+            prod *= lam < 0.0 ? __builtin_nan("") : __builtin_amdgcn_frexp_mant(lam);
+            pexp += __builtin_amdgcn_frexp_exp(lam);
+        }
+        pexp += __builtin_amdgcn_frexp_exp(prod);
+        prod = __builtin_amdgcn_frexp_mant(prod);
+        j = jn; row0 = row0n; K = Kn;
+    }
+    double acc = nhp_log(prod) + (double)pexp * 6.93147180559945286e-01;
+    if (prod == 0.0) acc = -__builtin_inf();
+    double blk = acc, blk_int = integ;
+    nhp_block_sum2_n<NW>(blk, blk_int, red);
+    if (!out) {
+        if (tid == 0) { partials[2 * (size_t)blockIdx.x] = blk; partials[2 * (size_t)blockIdx.x + 1] = blk_int; }
+        return;
+    }
+    int *flag = reinterpret_cast<int *>(red + 32);                  // the fused second stage of k_windowed_slices
+    if (tid == 0) {
+        __hip_atomic_store(&partials[2 * (size_t)blockIdx.x], blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&partials[2 * (size_t)blockIdx.x + 1], blk_int, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int nb = gridDim.x, sh = blockIdx.x % NHP_SL_SHARDS;
+        const unsigned int pop = (nb - sh + NHP_SL_SHARDS - 1) / NHP_SL_SHARDS;
+        const unsigned int used = nb < NHP_SL_SHARDS ? nb : NHP_SL_SHARDS;
+        int last = 0;
+        if (__hip_atomic_fetch_add(&counter[32 * (1 + sh)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pop - 1)
+            last = __hip_atomic_fetch_add(&counter[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == used - 1;
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    double sl_ = 0.0, si = 0.0;
+    for (unsigned int i = tid; i < gridDim.x; i += BLOCK) {
+        sl_ += __hip_atomic_load(&partials[2 * (size_t)i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        si += __hip_atomic_load(&partials[2 * (size_t)i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    nhp_block_sum2_n<NW>(sl_, si, red);
+    if (tid == 0) *out = (0.0 - si) + sl_;
+    for (int i = tid; i <= NHP_SL_SHARDS; i += BLOCK)
+        __hip_atomic_store(&counter[32 * i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 static nhp_slices slices_view(const nhp_cont_dataset *ds)
 {
     nhp_slices sl;
@@ -1033,6 +1174,52 @@ nhp_status nhp_launch_windowed_slices(nhp_ctx *ctx, const nhp_cont_dataset *ds, 
     return launch_slices(ctx, ds, m, mask_integral, d_out, nullptr, false, launched);
 }
 
+static nhp_status ensure_lq_planes(nhp_ctx *ctx, nhp_cont_dataset *ds, const nhp_cont_args &a, const nhp_slices &sl, bool *ok);
+
+// logit-normal impulses: the same call for k_windowed_slices_ln (NHP_SLICES_LN=0: the pair-cache kernel)
+nhp_status nhp_launch_windowed_slices_ln(nhp_ctx *ctx, const nhp_cont_dataset *cds, const nhp_cont_model *m, int mask_integral,
+                                         double *d_out, bool *launched)
+{
+    *launched = false;
+    if (!cds->d_sl_row || cds->n_items <= 0 || m->impulse_kind != NHP_IMPULSE_LOGITNORMAL) return NHP_OK;
+    if ((getenv("NHP_SLICES") && atoi(getenv("NHP_SLICES")) == 0) || (getenv("NHP_SLICES_LN") && atoi(getenv("NHP_SLICES_LN")) == 0)) return NHP_OK;
+    const size_t lds = 320 + 24 * ((size_t)cds->N + 1);
+    if (lds > 160 * 1024) return NHP_OK;
+    NHP_HIP(ctx, hipSetDevice(ctx->device));
+    NHP_TRY(nhp_ctx_reserve_partials(ctx, 2 * (size_t)cds->n_items));
+    nhp_cont_args a = nhp_make_args(cds, m);
+    NHP_TRY(ensure_slices(ctx, cds, a));
+    nhp_cont_dataset *ds = const_cast<nhp_cont_dataset *>(cds);
+    const nhp_slices sl = slices_view(ds);
+    bool planes = false;
+    NHP_TRY(ensure_lq_planes(ctx, ds, a, sl, &planes));
+    if (!planes) return NHP_OK;
+    const int per_item = (ds->max_item + 63) / 64;
+    const double mean_rows = ds->n_slices > 0 ? (double)ds->sl_rows / (double)ds->n_slices : 0.0;
+    // (metric size, µs per evaluation: 512 threads x 2 rows 35.2, 512 x 4 37.0, 256 x 2 34.3, 256 x 4 36.8, 64 x 2 48.9; the pair cache 39.5)
+    int B = per_item >= 3 ? 256 : 64, C = mean_rows >= 32.0 ? 4 : 2;
+    if (const char *cfg = getenv("NHP_SLICES_LN_CFG")) sscanf(cfg, "%d,%d", &B, &C);
+    if (!((B == 64 || B == 256 || B == 512) && (C == 2 || C == 4))) { B = 256; C = 2; }
+    const bool flat = m->baseline_kind == NHP_BASELINE_HOMOGENEOUS;
+    dim3 grid((unsigned)ds->n_items);
+#define NHP_LNL(b, cc, f)                                                                                             \
+    do {                                                                                                              \
+        if (lds > 64 * 1024)                                                                                          \
+            (void)hipFuncSetAttribute((const void *)k_windowed_slices_ln<b, cc, f>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_windowed_slices_ln<b, cc, f>), grid, dim3(b), lds, ctx->stream, a, sl, (const double *)ds->d_sl_L,  \
+                           (const double *)ds->d_sl_Q, mask_integral, ctx->d_partials, ctx->d_counter, d_out);       \
+    } while (0)
+#define NHP_LNC(b, cc) do { if (flat) NHP_LNL(b, cc, true); else NHP_LNL(b, cc, false); } while (0)
+    if (B == 64) { if (C == 2) NHP_LNC(64, 2); else NHP_LNC(64, 4); }
+    else if (B == 256) { if (C == 2) NHP_LNC(256, 2); else NHP_LNC(256, 4); }
+    else { if (C == 2) NHP_LNC(512, 2); else NHP_LNC(512, 4); }
+#undef NHP_LNC
+#undef NHP_LNL
+    NHP_HIP(ctx, hipGetLastError());
+    *launched = true;
+    return NHP_OK;
+}
+
 // Log-likelihood -> *d_out and gradient -> d_grad [P] of the dataset's own windows (mask_integral = 1: the windowed route's
 // masked integral).  When every item is its node's only one, the dataset is whole and the baseline flat, the kernel stores
 // every entry of the gradient itself; otherwise k_grad_init (cont_grad.hip) must have run on d_grad (*needs_init).
@@ -1110,6 +1297,26 @@ nhp_status nhp_launch_slices_batch(nhp_ctx *ctx, const nhp_cont_dataset *ds, con
     return NHP_OK;
 }
 
+// the planes of logit(x) and 1/(x(1-x)), made at the first call that wants them (data only); *ok = false: no room
+static nhp_status ensure_lq_planes(nhp_ctx *ctx, nhp_cont_dataset *ds, const nhp_cont_args &a, const nhp_slices &sl, bool *ok)
+{
+    *ok = true;
+    if (ds->d_sl_L) return NHP_OK;
+    const size_t n = ((size_t)ds->sl_rows + 16) * 64;
+    if (hipMalloc((void **)&ds->d_sl_L, 8 * n) != hipSuccess || hipMalloc((void **)&ds->d_sl_Q, 8 * n) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(ds->d_sl_L); (void)hipFree(ds->d_sl_Q);
+        ds->d_sl_L = nullptr; ds->d_sl_Q = nullptr;
+        *ok = false;
+        return NHP_OK;
+    }
+    NHP_HIP(ctx, hipMemsetAsync(ds->d_sl_L + (size_t)ds->sl_rows * 64, 0, 8 * 16 * 64, ctx->stream));
+    NHP_HIP(ctx, hipMemsetAsync(ds->d_sl_Q + (size_t)ds->sl_rows * 64, 0, 8 * 16 * 64, ctx->stream));
+    hipLaunchKernelGGL(k_slices_build_lq, dim3((unsigned)ds->n_items), dim3(256), 0, ctx->stream, a, sl, ds->d_sl_L, ds->d_sl_Q);
+    NHP_HIP(ctx, hipGetLastError());
+    return NHP_OK;
+}
+
 nhp_status nhp_launch_sampler_slices(nhp_ctx *ctx, const nhp_cont_dataset *cds, const nhp_cont_model *m, const double *d_u, uint64_t seed,
                                      uint64_t step, int64_t *parents, int64_t *pnodes, int32_t *pn_b, double *dt_b, int *d_err, bool *launched)
 {
@@ -1135,18 +1342,10 @@ nhp_status nhp_launch_sampler_slices(nhp_ctx *ctx, const nhp_cont_dataset *cds, 
         hipLaunchKernelGGL(k_slices_build_d, dim3((unsigned)ds->n_items), dim3(256), 0, ctx->stream, a, sl, ds->d_sl_D);
         NHP_HIP(ctx, hipGetLastError());
     }
-    if (!expo && !ds->d_sl_L) {
-        const size_t n = ((size_t)ds->sl_rows + 16) * 64;
-        if (hipMalloc((void **)&ds->d_sl_L, 8 * n) != hipSuccess || hipMalloc((void **)&ds->d_sl_Q, 8 * n) != hipSuccess) {
-            (void)hipGetLastError();
-            (void)hipFree(ds->d_sl_L); (void)hipFree(ds->d_sl_Q);
-            ds->d_sl_L = nullptr; ds->d_sl_Q = nullptr;
-            return NHP_OK;                                          // no room: the caller keeps its other kernel
-        }
-        NHP_HIP(ctx, hipMemsetAsync(ds->d_sl_L + (size_t)ds->sl_rows * 64, 0, 8 * 16 * 64, ctx->stream));
-        NHP_HIP(ctx, hipMemsetAsync(ds->d_sl_Q + (size_t)ds->sl_rows * 64, 0, 8 * 16 * 64, ctx->stream));
-        hipLaunchKernelGGL(k_slices_build_lq, dim3((unsigned)ds->n_items), dim3(256), 0, ctx->stream, a, sl, ds->d_sl_L, ds->d_sl_Q);
-        NHP_HIP(ctx, hipGetLastError());
+    if (!expo) {
+        bool planes = false;
+        NHP_TRY(ensure_lq_planes(ctx, ds, a, sl, &planes));
+        if (!planes) return NHP_OK;                                 // no room: the caller keeps its other kernel
     }
     dim3 grid((unsigned)ds->n_items);
 #define NHP_SAMP(b, cc)                                                                                                \

@@ -368,20 +368,30 @@ def test_pair_list_and_packed_records_agree_with_the_exact_records(nhp, orc, net
     # the same bits per term as the kernel that evaluates the whole pdf
     cl = random_case(12, 6000, 500.0, "logitnormal", 1.0, network=network, lgcp=lgcp, seed=11, nhp=nhp, orc=orc)
     wantl = orc.loglik(cl["om"], t, cl["nodes"], cl["T"], recursive=False)
+    # (round 3: first in line is the slices' twin, k_windowed_slices_ln -- one lane per child over the planes of logit(x) and
+    #  1/(x(1-x)) the parent sampler keeps; NHP_SLICES_LN=0 gives the pair kernel, NHP_PLIST=0 the whole pdf per record)
     gl = {}
-    for name, off in (("pairs", None), ("records", "0")):
-        if off is None:
-            monkeypatch.delenv("NHP_PLIST", raising=False)
-        else:
-            monkeypatch.setenv("NHP_PLIST", off)
+    for name, env in (("slices", {}), ("pairs", {"NHP_SLICES_LN": "0"}), ("records", {"NHP_PLIST": "0"})):
+        for k in ("NHP_PLIST", "NHP_SLICES_LN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         nhp.invalidate_device_datasets()
         gl[name] = nhp.loglikelihood(cl["proc"], (t, cl["nodes"], cl["T"]), recursive=False)
         assert rel(gl[name], wantl) < TOL, name
-    assert rel(gl["pairs"], gl["records"]) < 1e-13
+    assert rel(gl["pairs"], gl["records"]) < 1e-13 and rel(gl["slices"], gl["records"]) < 1e-13
     monkeypatch.delenv("NHP_PLIST", raising=False)
+    monkeypatch.delenv("NHP_SLICES_LN", raising=False)
+    for cfg in ("64,2", "64,4", "256,2", "256,4", "512,2", "512,4"):
+        monkeypatch.setenv("NHP_SLICES_LN_CFG", cfg)
+        assert rel(nhp.loglikelihood(cl["proc"], (t, cl["nodes"], cl["T"]), recursive=False), wantl) < TOL, cfg
+    monkeypatch.delenv("NHP_SLICES_LN_CFG", raising=False)
+    monkeypatch.setenv("NHP_SLICES_LN", "0")
     for cfg in ("2,2,256", "4,1,512", "8,2,1024"):
         monkeypatch.setenv("NHP_PAIRS_CFG", cfg)
         assert rel(nhp.loglikelihood(cl["proc"], (t, cl["nodes"], cl["T"]), recursive=False), wantl) < TOL, cfg
+    monkeypatch.delenv("NHP_PAIRS_CFG", raising=False)
+    monkeypatch.delenv("NHP_SLICES_LN", raising=False)
 
 
 def test_child_slices_at_a_thousand_nodes(nhp, orc, monkeypatch):
