@@ -668,6 +668,110 @@ struct nhp_dadj_args {
     unsigned long long *stamps;          // (DADJ_STAMP builds: 8 per workgroup)
 };
 
+// λ of the occupied bins under the current adjacency matrix -- the sweep's starting point -- without the T x N intensity GEMM
+// (6.2 ms at config-4 scale for the 5 % of bins that are occupied).  The spans and entry lists of the step kernel: a workgroup
+// keeps its entries' λ in registers and walks the N parents once, row p of V and of A and its span of Ŝ staged per parent
+// (requested one parent ahead): λ += a[p,c] · Σ_b Ŝ[t,p,b] V[p,c,b], parents in order, b innermost -- the order of the
+// reference's own sum.  No exchange between workgroups, one launch.  Entries beyond 12 a thread: the GEMM.
+template <int BT, int TH>
+__global__ __launch_bounds__(TH, TH / 128) void k_dadj_lambda0(nhp_dadj_args a, const double *__restrict__ base, const double *__restrict__ baseT)
+{
+    extern __shared__ __align__(16) double dsm[];
+    constexpr int B = BT, PRE = 3;
+    const int N = a.N, tid = threadIdx.x;
+    double *Gt = dsm;                                       // [B][SPAN]
+    double *apl = Gt + (size_t)B * NHP_DA_SPAN;             // [N]
+    double *Vl = apl + N;                                   // [N·B]
+    const int64_t t0 = a.span_t[blockIdx.x];
+    const int span = a.span_t[blockIdx.x + 1] - (int)t0;
+    const int i0 = a.occ_off[blockIdx.x], i1 = a.occ_off[blockIdx.x + 1];
+    const int per = ((i1 - i0 + 4 * TH - 1) / (4 * TH)) * 4;            // <= 4·PRE (host)
+    const int mine = i0 + tid * per, mend = min(mine + per, i1);
+    const int tb = (int)(t0 % NHP_DA_SPAN);
+    uint4 pw[PRE];
+    double lam[4 * PRE];
+#pragma unroll
+    for (int g = 0; g < PRE; ++g) {
+        const int bs = mine + 4 * g;
+        pw[g] = make_uint4(0u, 0u, 0u, 0u);
+        if (bs < mend) pw[g] = *reinterpret_cast<const uint4 *>(a.occ_pack + bs);
+        const uint32_t w4[4] = {pw[g].x, pw[g].y, pw[g].z, pw[g].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = (int)(w4[j] >> 16), tt = ((int)(w4[j] & 255u) - tb) & (NHP_DA_SPAN - 1);
+            lam[4 * g + j] = bs < mend ? (baseT ? baseT[(size_t)(t0 + tt) + (size_t)a.T * c] : base[c]) : 0.0;
+        }
+    }
+    constexpr int GN = (B * NHP_DA_SPAN + TH - 1) / TH, VN = 4;
+    const int nv2 = N * B / 2;
+    double rg[GN];
+    double2 rv[VN];
+    double ra[2];
+    auto fetch = [&](int p) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < GN; ++r) {
+            const int e = tid + TH * r, b = e / NHP_DA_SPAN, tt = e % NHP_DA_SPAN;
+            const int64_t t = t0 + tt;
+            const bool ok = e < B * NHP_DA_SPAN && tt < span && t < a.T;
+            rg[r] = ok ? a.conv[(size_t)t + (size_t)a.T * ((size_t)p + (size_t)N * b)] : 0.0;
+        }
+        const double2 *src = reinterpret_cast<const double2 *>(a.Vall + (size_t)p * N * B);
+#pragma unroll
+        for (int r = 0; r < VN; ++r) { const int e = tid + TH * r; rv[r] = e < nv2 ? src[e] : make_double2(0.0, 0.0); }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { const int c = tid + TH * r; ra[r] = c < N ? a.AT[(size_t)p * N + c] : 0.0; }
+    };
+    fetch(0);
+    for (int p = 0; p < N; ++p) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < GN; ++r) { const int e = tid + TH * r; if (e < B * NHP_DA_SPAN) Gt[e] = rg[r]; }
+        {
+            double2 *dst = reinterpret_cast<double2 *>(Vl);
+#pragma unroll
+            for (int r = 0; r < VN; ++r) { const int e = tid + TH * r; if (e < nv2) dst[e] = rv[r]; }
+            for (int e = tid + TH * VN; e < nv2; e += TH) dst[e] = reinterpret_cast<const double2 *>(a.Vall + (size_t)p * N * B)[e];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) { const int c = tid + TH * r; if (c < N) apl[c] = ra[r]; }
+            for (int c = tid + 2 * TH; c < N; c += TH) apl[c] = a.AT[(size_t)p * N + c];
+        }
+        __syncthreads();
+        if (p + 1 < N) fetch(p + 1);
+        int c_cur = -1;
+        double apc = 0.0;
+        double v[B];
+#pragma unroll
+        for (int g = 0; g < PRE; ++g) {
+            if (mine + 4 * g < mend) {
+                const uint32_t w4[4] = {pw[g].x, pw[g].y, pw[g].z, pw[g].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = (int)(w4[j] >> 16);
+                    if (c != c_cur) {
+                        c_cur = c; apc = apl[c];
+                        if (apc != 0.0) {
+#pragma unroll
+                            for (int b = 0; b < B; ++b) v[b] = Vl[(size_t)c * B + b];
+                        }
+                    }
+                    if (apc != 0.0) {
+                        const int tt = ((int)(w4[j] & 255u) - tb) & (NHP_DA_SPAN - 1);
+                        lam[4 * g + j] += apc * dadj_x<BT>(Gt, tt, v, B);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < PRE; ++g) {
+        const int bs = mine + 4 * g;
+        if (bs < mend) {
+            *reinterpret_cast<double2 *>(a.lam_occ + bs) = make_double2(lam[4 * g], lam[4 * g + 1]);
+            *reinterpret_cast<double2 *>(a.lam_occ + bs + 2) = make_double2(lam[4 * g + 2], lam[4 * g + 3]);
+        }
+    }
+}
+
 #ifdef DADJ_STAMP
 #define DADJ_ST(k) do { if (tid == 0 && a.stamps) a.stamps[8 * (size_t)blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -911,10 +1015,15 @@ extern "C" nhp_status nhp_disc_resample_adjacency(nhp_ctx *ctx, const nhp_disc_d
     hipStream_t st = ctx->stream;
     if (u) NHP_HIP(ctx, hipMemcpyAsync(d_u, u, 8 * NN, hipMemcpyHostToDevice, st));
     if (rho_matrix) NHP_HIP(ctx, hipMemcpyAsync(d_rho, rho_matrix, 8 * NN, hipMemcpyHostToDevice, st));
-    // λ under the current A (GEMM-1), gathered at the occupied bins
-    NHP_TRY(nhp_disc_launch_intensity(ctx, ds, E, base, lambda0 == nullptr, dlam));
-    hipLaunchKernelGGL(k_dadj_gather, dim3((unsigned)((nocc + 255) / 256)), dim3(256), 0, st, dlam, ds->d_occ_t, ds->d_occ_c,
-                       ds->nocc_pad, ds->T, lam_occ);
+    // λ under the current A at the occupied bins: from the entry lists themselves (k_dadj_lambda0) where a thread's share fits
+    // its registers, else the T x N intensity GEMM and a gather (NHP_DADJ_LAMBDA0=0: always the GEMM)
+    const bool lam_pass = ds->d_occ_pack && vlds && (ds->B == 8 || ds->B == 4) && ds->da_max_entries <= 12 * 512 && 2 * 512 >= (int)N &&
+                          !(getenv("NHP_DADJ_LAMBDA0") && atoi(getenv("NHP_DADJ_LAMBDA0")) == 0);
+    if (!lam_pass) {
+        NHP_TRY(nhp_disc_launch_intensity(ctx, ds, E, base, lambda0 == nullptr, dlam));
+        hipLaunchKernelGGL(k_dadj_gather, dim3((unsigned)((nocc + 255) / 256)), dim3(256), 0, st, dlam, ds->d_occ_t, ds->d_occ_c,
+                           ds->nocc_pad, ds->T, lam_occ);
+    }
     hipLaunchKernelGGL(k_dadj_tables, dim3((unsigned)((N + 15) / 16), (unsigned)((N + 15) / 16)), dim3(256), 0, st, ds->N, ds->B, dt, dW, dth, dA,
                        rho_matrix ? d_rho : nullptr, rho, u ? d_u : nullptr, seed, step, Vall, AT, LU, LR1, LR2, ds->d_convsum, SX);
     NHP_HIP(ctx, hipMemsetAsync(tick, 0, 4 * (32 * (size_t)(1 + ngrp) + 4), st));
@@ -925,6 +1034,17 @@ extern "C" nhp_status nhp_disc_resample_adjacency(nhp_ctx *ctx, const nhp_disc_d
     a.occ_t = ds->d_occ_t; a.occ_c = ds->d_occ_c; a.occ_off = ds->d_occ_off; a.span_t = ds->d_span_t; a.occ_s = ds->d_occ_s;
     a.Vall = Vall; a.AT = AT; a.LU = LU; a.LR1 = LR1; a.LR2 = LR2; a.SX = SX; a.lam_occ = lam_occ;
     a.partial = partial; a.gpartial = gpartial; a.tick = tick; a.A = dA;
+    if (lam_pass) {
+        const size_t l0 = 8 * ((size_t)B * NHP_DA_SPAN + N + N * B);
+        if (ds->B == 8) {
+            if (l0 > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_dadj_lambda0<8, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l0);
+            hipLaunchKernelGGL((k_dadj_lambda0<8, 512>), dim3((unsigned)nwg), dim3(512), l0, st, a, (const double *)base, (const double *)(lambda0 ? nullptr : ds->d_baseT));
+        } else {
+            if (l0 > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_dadj_lambda0<4, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l0);
+            hipLaunchKernelGGL((k_dadj_lambda0<4, 512>), dim3((unsigned)nwg), dim3(512), l0, st, a, (const double *)base, (const double *)(lambda0 ? nullptr : ds->d_baseT));
+        }
+        NHP_HIP(ctx, hipGetLastError());
+    }
 #ifdef DADJ_STAMP
     unsigned long long *d_st = nullptr;
     const int st_step = getenv("NHP_DADJ_STAMP_STEP") ? atoi(getenv("NHP_DADJ_STAMP_STEP")) : 100;
