@@ -565,8 +565,8 @@ extern "C" nhp_status nhp_disc_gibbs_step(nhp_ctx *ctx, const nhp_disc_dataset *
 //    every workgroup (128 KB each, 64 MB a step out of L2) 2 µs more.  The order of a column's 32 atomic additions varies
 //    from run to run, as does the order of the LDS atomics inside a workgroup: two runs differ where |d - logit u| is
 //    within rounding of zero.
-// 55 µs (two launches) -> 27 µs a step at config-4 scale; 36.2 -> 22.6 ms per sweep, 7.5 ms of which are the intensity GEMM
-// and the tables before the first step.
+// 55 µs (two launches) -> 27 µs a step at config-4 scale; 36.2 -> 20.0 ms per sweep, 4.1 ms of which are k_dadj_lambda0
+// before the first step (the T x N intensity GEMM and a gather before: 6.3 ms).
 __global__ __launch_bounds__(256) void k_dadj_gather(const double *__restrict__ lam, const int32_t *__restrict__ occ_t,
                                                      const int32_t *__restrict__ occ_c, int64_t nocc, int64_t T,
                                                      double *__restrict__ lam_occ)
