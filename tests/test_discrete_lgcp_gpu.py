@@ -84,3 +84,26 @@ def test_mcmc_and_mle_run_with_the_discrete_lgcp_baseline(nhp):
     assert fit.maximum > ll0 - abs(ll0)            # finite, sane
     with pytest.raises(NotImplementedError):
         nhp.update_(proc, data, nhp.convolve(proc, data))
+
+
+def test_adjacency_sweep_with_a_per_bin_baseline(nhp, monkeypatch):
+    """resample_adjacency_matrix! on a network process whose baseline is the per-bin LGCP curve: the sweep's starting λ of the
+    occupied bins comes from the entry lists (k_dadj_lambda0: base read per bin) or from the intensity GEMM's epilogue
+    (NHP_DADJ_LAMBDA0=0) -- the same decisions for the same uniforms; B = 4 so that the list route is taken."""
+    proc, data, rng = make(nhp, N=6, T=900, B=4, L=6, G=11, seed=9)
+    N = data.shape[0]
+    A0 = (rng.uniform(size=(N, N)) < 0.5).astype(np.float64)
+    u = rng.uniform(size=(N, N))
+    got = {}
+    for name, env in (("lists", None), ("gemm", "0")):
+        if env is None:
+            monkeypatch.delenv("NHP_DADJ_LAMBDA0", raising=False)
+        else:
+            monkeypatch.setenv("NHP_DADJ_LAMBDA0", env)
+        net = nhp.DiscreteNetworkHawkesProcess(proc.baseline, proc.impulses, nhp.DenseWeightModel(proc.weights.W * N * 1.5), A0.copy(),
+                                               nhp.BernoulliNetworkModel(0.3, N), proc.dt)
+        ds = nhp.convolve(net, data)
+        nhp.disc_resample_adjacency_matrix_(net, convolved=ds, u=u)
+        got[name] = net.adjacency_matrix.copy()
+    monkeypatch.delenv("NHP_DADJ_LAMBDA0", raising=False)
+    assert np.array_equal(got["lists"], got["gemm"]) and not np.array_equal(got["lists"], A0)
