@@ -95,11 +95,8 @@ def test_adjacency_sweep_with_a_per_bin_baseline(nhp, monkeypatch):
     A0 = (rng.uniform(size=(N, N)) < 0.5).astype(np.float64)
     u = rng.uniform(size=(N, N))
     got = {}
-    for name, env in (("lists", None), ("gemm", "0")):
-        if env is None:
-            monkeypatch.delenv("NHP_DADJ_LAMBDA0", raising=False)
-        else:
-            monkeypatch.setenv("NHP_DADJ_LAMBDA0", env)
+    for name, env in (("lists", "1"), ("gemm", "0")):
+        monkeypatch.setenv("NHP_DADJ_LAMBDA0", env)
         net = nhp.DiscreteNetworkHawkesProcess(proc.baseline, proc.impulses, nhp.DenseWeightModel(proc.weights.W * N * 1.5), A0.copy(),
                                                nhp.BernoulliNetworkModel(0.3, N), proc.dt)
         ds = nhp.convolve(net, data)

@@ -9,7 +9,7 @@ N, B, L, T = 512, 8, 32, 100_000
 rng = np.random.default_rng(0)
 data = np.asfortranarray(rng.poisson(float(os.environ.get("DG_RATE", 0.1)), (N, T)).astype(np.int64))
 th = np.asfortranarray(np.full((N, N, B), 1.0 / B))
-A = (rng.uniform(size=(N, N)) < 0.5).astype(np.float64)
+A = (rng.uniform(size=(N, N)) < float(os.environ.get("A_DENSITY", 0.5))).astype(np.float64)
 proc = nhp.DiscreteNetworkHawkesProcess(nhp.DiscreteHomogeneousProcess(np.full(N, 0.05), 1.0),
                                         nhp.DiscreteGaussianImpulseResponse(th, L, 1.0),
                                         nhp.DenseWeightModel(np.full((N, N), 1.0 / N)), A,
