@@ -1114,9 +1114,9 @@ static nhp_status run_windowed(nhp_ctx *ctx, const nhp_cont_dataset *ds, const n
         NHP_TRY(nhp_launch_windowed_slices(ctx, ds, m, mask_integral, d_out, &launched));
         if (launched) return NHP_OK;
     }
-    if (!child_w && !d_lambda && d_out && m->impulse_kind == NHP_IMPULSE_LOGITNORMAL && !plist_off) {     // ... and the logit-normal twin
+    if (!child_w && (d_out || d_lambda) && m->impulse_kind == NHP_IMPULSE_LOGITNORMAL && !plist_off) {     // ... and the logit-normal twin (λ out as well)
         bool launched = false;
-        NHP_TRY(nhp_launch_windowed_slices_ln(ctx, ds, m, mask_integral, d_out, &launched));
+        NHP_TRY(nhp_launch_windowed_slices_ln(ctx, ds, m, mask_integral, d_out, d_lambda, &launched));
         if (launched) return NHP_OK;
     }
     if (!child_w && ds->d_poff && !plist_off && G <= 16 && (expo_p || nhp_ensure_pair_cache(ctx, ds, &a) == NHP_OK)) {

@@ -875,7 +875,7 @@ __global__ __launch_bounds__(BLOCK) void k_sampler_slices(nhp_cont_args a, nhp_s
 template <int BLOCK, int C, bool FLAT>
 __global__ __launch_bounds__(BLOCK) void k_windowed_slices_ln(nhp_cont_args a, nhp_slices sl, const double *__restrict__ L, const double *__restrict__ Q,
                                                                int mask_integral, double *__restrict__ partials, unsigned int *__restrict__ counter,
-                                                               double *__restrict__ out)
+                                                               double *__restrict__ out, double *__restrict__ lambda_out)
 {
     constexpr int NW = BLOCK / 64;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -969,6 +969,7 @@ __global__ __launch_bounds__(BLOCK) void k_windowed_slices_ln(nhp_cont_args a, n
             const double lam = (FLAT ? lam0 : sl_baseline(a, c, tk)) + s;
             prod *= lam < 0.0 ? __builtin_nan("") : __builtin_amdgcn_frexp_mant(lam);
             pexp += __builtin_amdgcn_frexp_exp(lam);
+            if (lambda_out) lambda_out[a.child_w[it.kbeg + kk].idx] = lam;           // (total_intensity, the two-pass gradient's 1/λ)
         }
         pexp += __builtin_amdgcn_frexp_exp(prod);
         prod = __builtin_amdgcn_frexp_mant(prod);
@@ -1178,7 +1179,7 @@ static nhp_status ensure_lq_planes(nhp_ctx *ctx, nhp_cont_dataset *ds, const nhp
 
 // logit-normal impulses: the same call for k_windowed_slices_ln (NHP_SLICES_LN=0: the pair-cache kernel)
 nhp_status nhp_launch_windowed_slices_ln(nhp_ctx *ctx, const nhp_cont_dataset *cds, const nhp_cont_model *m, int mask_integral,
-                                         double *d_out, bool *launched)
+                                         double *d_out, double *d_lambda, bool *launched)
 {
     *launched = false;
     if (!cds->d_sl_row || cds->n_items <= 0 || m->impulse_kind != NHP_IMPULSE_LOGITNORMAL) return NHP_OK;
@@ -1207,7 +1208,7 @@ nhp_status nhp_launch_windowed_slices_ln(nhp_ctx *ctx, const nhp_cont_dataset *c
         if (lds > 64 * 1024)                                                                                          \
             (void)hipFuncSetAttribute((const void *)k_windowed_slices_ln<b, cc, f>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_windowed_slices_ln<b, cc, f>), grid, dim3(b), lds, ctx->stream, a, sl, (const double *)ds->d_sl_L,  \
-                           (const double *)ds->d_sl_Q, mask_integral, ctx->d_partials, ctx->d_counter, d_out);       \
+                           (const double *)ds->d_sl_Q, mask_integral, ctx->d_partials, ctx->d_counter, d_out, d_lambda); \
     } while (0)
 #define NHP_LNC(b, cc) do { if (flat) NHP_LNL(b, cc, true); else NHP_LNL(b, cc, false); } while (0)
     if (B == 64) { if (C == 2) NHP_LNC(64, 2); else NHP_LNC(64, 4); }

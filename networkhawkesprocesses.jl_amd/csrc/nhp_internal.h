@@ -331,7 +331,7 @@ nhp_status nhp_ensure_pair_cache(nhp_ctx *ctx, const nhp_cont_dataset *ds, nhp_c
 nhp_status nhp_launch_windowed_slices(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, int mask_integral,
                                       double *d_out, bool *launched);
 nhp_status nhp_launch_windowed_slices_ln(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, int mask_integral,
-                                      double *d_out, bool *launched);
+                                      double *d_out, double *d_lambda, bool *launched);
 // the same with the analytic gradient (params! order, P doubles at d_grad) from one fused launch over the child and the
 // parent slices; *launched = false when the pair is not covered
 nhp_status nhp_launch_grad_slices(nhp_ctx *ctx, const nhp_cont_dataset *ds, const nhp_cont_model *m, double *d_out, double *d_grad,
